@@ -1,0 +1,856 @@
+/*
+ * lmik_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY) for the batched LM-IK hot path of jstmn/cppflow.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product (cppflow_amd/) never imports, links or calls anything under oracle/.
+ *
+ * It restates, in plain scalar C, the algorithm of the reference's pose-only Levenberg-Marquardt step and of its
+ * batched collision masks, in the reference's own operation order:
+ *
+ *   orc_pose_errors      <- cppflow/optimization_utils.py:802-820   get_6d_pose_errors
+ *   orc_lm_step          <- cppflow/optimization.py:61-92           levenberg_marquardt_only_pose
+ *                           (scale rows :77-80, A = J^T J + lambda I :85-86, b = J^T e :87, LU solve :88, x+delta :90-92)
+ *   orc_clamp            <- cppflow/optimization_utils.py:823-833   clamp_to_joint_limits
+ *   orc_pose_metrics     <- cppflow/evaluation_utils.py:113-116,134-141 positional_errors / rotational_errors
+ *                           (geodesic formula quoted at cppflow/data_types.py:408-411)
+ *   orc_self_dists/orc_env_dists + orc_masks
+ *                        <- cppflow/collision_detection.py:27-69    min over pairs/links, "< 0", OR over obstacles
+ *   orc_jlim_mask        <- cppflow/search.py:25-52                 joint_limit_almost_violations_3d
+ *   orc_ext_cost         <- cppflow/search.py:14-15,146-150         100*jlim + 1000*env + 1000*self
+ *   orc_angular_changes  <- cppflow/evaluation_utils.py:144-154
+ *   orc_seed_validity    <- cppflow/optimization_utils.py:845-884 + cppflow/evaluation_utils.py:29-75
+ *
+ * THIRD-PARTY ARITHMETIC.  Forward kinematics, the geometric Jacobian, capsule distances and the quaternion helpers
+ * are methods of `jrl` 0.1.2 @ ef4c2f6eb1ba84395ff0bb01d5b7713854df6908 (reference pyproject.toml:12,
+ * uv.lock:907-909), which is NOT vendored in /root/reference and not installable here.  Their published semantics are
+ * restated from the reference's call sites:
+ *   - FK pose layout [x y z qw qx qy qz]              (README.md:8, cppflow/ros2/ros2_utils.py:19-35)
+ *   - Jacobian rows 0:3 angular, 3:6 linear, world    (cppflow/optimization.py:77-80, optimization_utils.py:806-808)
+ *   - prismatic Jacobian column = [0; axis]           (tests/optimization_utils_test.py:377-402)
+ *   - w-first Hamilton quaternions; geodesic = 2*acos(clamp(dot, -1+1e-7, 1-1e-7)) folded to [0, pi]
+ *   - capsule-capsule: closed-form segment-segment distance minus radii
+ *   - capsule-cuboid: exact segment / axis-aligned-box distance minus radius (jrl's own algorithm is unknown;
+ *     this definition is the build's, DESIGN.md "capsule-cuboid distance")
+ * PARITY PINNING: the reference holds no numeric FK / Jacobian / distance vector for its robots, so absolute model
+ * values are "parity unpinned"; the oracle is pinned against every known-answer test the reference does hold for
+ * this path (tests/test_oracle_kats.py lists them with file:line).
+ *
+ * Two builds of this one file:
+ *   liborc64.so  (default)   REAL = double, libm sin/cos      -> ground truth
+ *   liborc32.so  (-DORC_F32) REAL = float, canonical fp32 op order with explicit fmaf and the Cody-Waite sincos below,
+ *                            compiled -ffp-contract=off       -> bit-level reference for masks / FK
+ * The interface is double in both (inputs must be fp32-representable for the f32 build to be exact on entry).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifdef ORC_F32
+typedef float REAL;
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#define SQRT(a) sqrtf(a)
+#define ATAN2(a, b) atan2f((a), (b))
+#define ASIN(a) asinf(a)
+#define ACOS(a) acosf(a)
+#define FABS(a) fabsf(a)
+#define FMOD(a, b) fmodf((a), (b))
+#define RC(x) x##f
+#else
+typedef double REAL;
+#define FMA(a, b, c) fma((a), (b), (c))
+#define SQRT(a) sqrt(a)
+#define ATAN2(a, b) atan2((a), (b))
+#define ASIN(a) asin(a)
+#define ACOS(a) acos(a)
+#define FABS(a) fabs(a)
+#define FMOD(a, b) fmod((a), (b))
+#define RC(x) x
+#endif
+
+#define ORC_MAX_DOF 16
+#define ORC_MAX_CAPS 24
+#define ORC_MAX_PAIRS 128
+#define ORC_MAX_OBS 8
+
+typedef struct {
+    int ndof;
+    REAL F[ORC_MAX_DOF][12]; /* canonical fixed transforms: R row-major (9) then t (3) */
+    REAL Fee[12];
+    int jtype[ORC_MAX_DOF]; /* 0 revolute about local z, 1 prismatic along local z */
+    REAL lo[ORC_MAX_DOF], hi[ORC_MAX_DOF];
+    int ncaps;
+    int cap_link[ORC_MAX_CAPS]; /* -1 = base */
+    REAL cap_p0[ORC_MAX_CAPS][3], cap_p1[ORC_MAX_CAPS][3], cap_r[ORC_MAX_CAPS];
+    int npairs;
+    int pair_a[ORC_MAX_PAIRS], pair_b[ORC_MAX_PAIRS];
+} orc_robot;
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* robot handle                                                                                                     */
+
+void* orc_robot_create(int ndof, const double* F, const double* Fee, const int* jtype, const double* lo,
+                       const double* hi, int ncaps, const int* cap_link, const double* cap_p0, const double* cap_p1,
+                       const double* cap_r, int npairs, const int* pairs) {
+    if (ndof < 1 || ndof > ORC_MAX_DOF || ncaps < 0 || ncaps > ORC_MAX_CAPS || npairs < 0 || npairs > ORC_MAX_PAIRS)
+        return NULL;
+    orc_robot* rb = (orc_robot*)calloc(1, sizeof(orc_robot));
+    rb->ndof = ndof;
+    for (int j = 0; j < ndof; ++j) {
+        for (int k = 0; k < 12; ++k) rb->F[j][k] = (REAL)F[j * 12 + k];
+        rb->jtype[j] = jtype[j];
+        rb->lo[j] = (REAL)lo[j];
+        rb->hi[j] = (REAL)hi[j];
+    }
+    for (int k = 0; k < 12; ++k) rb->Fee[k] = (REAL)Fee[k];
+    rb->ncaps = ncaps;
+    for (int c = 0; c < ncaps; ++c) {
+        rb->cap_link[c] = cap_link[c];
+        for (int k = 0; k < 3; ++k) {
+            rb->cap_p0[c][k] = (REAL)cap_p0[c * 3 + k];
+            rb->cap_p1[c][k] = (REAL)cap_p1[c * 3 + k];
+        }
+        rb->cap_r[c] = (REAL)cap_r[c];
+    }
+    rb->npairs = npairs;
+    for (int p = 0; p < npairs; ++p) {
+        rb->pair_a[p] = pairs[2 * p];
+        rb->pair_b[p] = pairs[2 * p + 1];
+    }
+    return rb;
+}
+
+void orc_robot_destroy(void* rb) { free(rb); }
+
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
+int orc_is_f32(void) {
+#ifdef ORC_F32
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* sin / cos                                                                                                        */
+
+#ifdef ORC_F32
+/* Cody-Waite reduction by pi/2 (3 constants) + Cephes single-precision minimax polynomials on [-pi/4, pi/4].
+ * Written with explicit fmaf so that the HIP kernels (which use the same formula) agree bit for bit. */
+static void sincos_real(float x, float* s, float* c) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188e-8f, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    float sn = fmaf(r * z, ps, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    float cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    int q = ((int)k) & 3;
+    float so = (q & 1) ? cs : sn;
+    float co = (q & 1) ? sn : cs;
+    if (q == 1 || q == 2) co = -co;
+    if (q >= 2) so = -so;
+    *s = so;
+    *c = co;
+}
+#else
+static void sincos_real(double x, double* s, double* c) {
+    *s = sin(x);
+    *c = cos(x);
+}
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* forward kinematics in canonical order                                                                            */
+
+typedef struct {
+    REAL R[9];
+    REAL p[3];
+} frame_t;
+
+/* p' = R*t + p ;  A = R*Fr   (canonical order: k = 0 product first, then fma k = 1, k = 2) */
+static void apply_fixed(const frame_t* in, const REAL* Fk, frame_t* out) {
+    const REAL* Fr = Fk;
+    const REAL* Ft = Fk + 9;
+    for (int i = 0; i < 3; ++i) {
+        const REAL r0 = in->R[3 * i], r1 = in->R[3 * i + 1], r2 = in->R[3 * i + 2];
+        out->p[i] = FMA(r2, Ft[2], FMA(r1, Ft[1], FMA(r0, Ft[0], in->p[i])));
+        for (int c = 0; c < 3; ++c) out->R[3 * i + c] = FMA(r2, Fr[6 + c], FMA(r1, Fr[3 + c], r0 * Fr[c]));
+    }
+}
+
+/* motion about / along local z */
+static void apply_joint(frame_t* f, int jtype, REAL q) {
+    if (jtype == 0) {
+        REAL s, c;
+        sincos_real(q, &s, &c);
+        for (int i = 0; i < 3; ++i) {
+            const REAL a0 = f->R[3 * i], a1 = f->R[3 * i + 1];
+            f->R[3 * i] = FMA(s, a1, c * a0);
+            f->R[3 * i + 1] = FMA(c, a1, -(s * a0));
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) f->p[i] = FMA(f->R[3 * i + 2], q, f->p[i]);
+    }
+}
+
+/* link frames after each joint's motion (frames[j]), joint axes/origins (for the Jacobian) and the ee frame */
+static void fk_chain(const orc_robot* rb, const REAL* q, frame_t* links, REAL (*axis)[3], REAL (*origin)[3],
+                     frame_t* ee) {
+    frame_t cur;
+    memset(&cur, 0, sizeof(cur));
+    cur.R[0] = cur.R[4] = cur.R[8] = (REAL)1;
+    for (int j = 0; j < rb->ndof; ++j) {
+        frame_t nxt;
+        apply_fixed(&cur, rb->F[j], &nxt);
+        if (axis) {
+            for (int i = 0; i < 3; ++i) {
+                axis[j][i] = nxt.R[3 * i + 2];
+                origin[j][i] = nxt.p[i];
+            }
+        }
+        apply_joint(&nxt, rb->jtype[j], q[j]);
+        cur = nxt;
+        if (links) links[j] = cur;
+    }
+    if (ee) apply_fixed(&cur, rb->Fee, ee);
+}
+
+/* rotation matrix -> unit quaternion, w first; the branch with the largest of (w, x, y, z) is used so the divisor is
+ * >= 1 (restates the 4-candidate scheme of jrl.math_utils.rotation_matrix_to_quaternion; sign: largest component > 0) */
+static void mat_to_quat(const REAL* R, REAL* q) {
+    const REAL m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
+               m22 = R[8];
+    const REAL one = (REAL)1;
+    REAL qa[4];
+    qa[0] = one + m00 + m11 + m22;
+    qa[1] = one + m00 - m11 - m22;
+    qa[2] = one - m00 + m11 - m22;
+    qa[3] = one - m00 - m11 + m22;
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (qa[i] > qa[best]) best = i;
+    const REAL d = SQRT(qa[best] > 0 ? qa[best] : 0); /* = 2*|component| */
+    const REAL inv = RC(0.5) / d;
+    switch (best) {
+        case 0:
+            q[0] = RC(0.5) * d;
+            q[1] = (m21 - m12) * inv;
+            q[2] = (m02 - m20) * inv;
+            q[3] = (m10 - m01) * inv;
+            break;
+        case 1:
+            q[0] = (m21 - m12) * inv;
+            q[1] = RC(0.5) * d;
+            q[2] = (m10 + m01) * inv;
+            q[3] = (m02 + m20) * inv;
+            break;
+        case 2:
+            q[0] = (m02 - m20) * inv;
+            q[1] = (m10 + m01) * inv;
+            q[2] = RC(0.5) * d;
+            q[3] = (m12 + m21) * inv;
+            break;
+        default:
+            q[0] = (m10 - m01) * inv;
+            q[1] = (m20 + m02) * inv;
+            q[2] = (m21 + m12) * inv;
+            q[3] = RC(0.5) * d;
+            break;
+    }
+}
+
+static void frame_to_pose(const frame_t* f, REAL* pose) {
+    pose[0] = f->p[0];
+    pose[1] = f->p[1];
+    pose[2] = f->p[2];
+    mat_to_quat(f->R, pose + 3);
+}
+
+/* x[n,d] -> poses[n,7]   (Robot.forward_kinematics) */
+void orc_fk(const void* h, const double* x, int n, double* poses) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], pose[7];
+        frame_t ee;
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        fk_chain(rb, q, NULL, NULL, NULL, &ee);
+        frame_to_pose(&ee, pose);
+        for (int k = 0; k < 7; ++k) poses[(size_t)r * 7 + k] = pose[k];
+    }
+}
+
+/* x[n,d] -> link frames [n, d+1, 12] (R row-major, p); entry d is the ee frame.  Debug / test helper. */
+void orc_link_frames(const void* h, const double* x, int n, double* out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF];
+        frame_t links[ORC_MAX_DOF + 1];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        fk_chain(rb, q, links, NULL, NULL, &links[d]);
+        for (int j = 0; j <= d; ++j) {
+            double* o = out + ((size_t)r * (d + 1) + j) * 12;
+            for (int k = 0; k < 9; ++k) o[k] = links[j].R[k];
+            for (int k = 0; k < 3; ++k) o[9 + k] = links[j].p[k];
+        }
+    }
+}
+
+/* geometric Jacobian [6,d]: rows 0:3 angular, 3:6 linear, world frame */
+static void jacobian_row(const orc_robot* rb, const REAL* q, REAL* J /*[6*d]*/, frame_t* ee) {
+    const int d = rb->ndof;
+    REAL axis[ORC_MAX_DOF][3], origin[ORC_MAX_DOF][3];
+    fk_chain(rb, q, NULL, axis, origin, ee);
+    for (int j = 0; j < d; ++j) {
+        const REAL* z = axis[j];
+        if (rb->jtype[j] == 0) {
+            const REAL rx = ee->p[0] - origin[j][0], ry = ee->p[1] - origin[j][1], rz = ee->p[2] - origin[j][2];
+            J[0 * d + j] = z[0];
+            J[1 * d + j] = z[1];
+            J[2 * d + j] = z[2];
+            J[3 * d + j] = z[1] * rz - z[2] * ry;
+            J[4 * d + j] = z[2] * rx - z[0] * rz;
+            J[5 * d + j] = z[0] * ry - z[1] * rx;
+        } else {
+            J[0 * d + j] = J[1 * d + j] = J[2 * d + j] = 0;
+            J[3 * d + j] = z[0];
+            J[4 * d + j] = z[1];
+            J[5 * d + j] = z[2];
+        }
+    }
+}
+
+void orc_jacobian(const void* h, const double* x, int n, double* Jout) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], J[6 * ORC_MAX_DOF];
+        frame_t ee;
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        jacobian_row(rb, q, J, &ee);
+        for (int k = 0; k < 6 * d; ++k) Jout[(size_t)r * 6 * d + k] = J[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* quaternion helpers (jrl.math_utils semantics)                                                         */
+
+static void quat_conj(const REAL* q, REAL* o) {
+    o[0] = q[0];
+    o[1] = -q[1];
+    o[2] = -q[2];
+    o[3] = -q[3];
+}
+
+static void quat_mul(const REAL* a, const REAL* b, REAL* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+static void quat_to_rpy(const REAL* q, REAL* rpy) {
+    const REAL q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    rpy[0] = ATAN2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2));
+    REAL sp = 2 * (q0 * q2 - q3 * q1);
+    if (sp > 1) sp = 1;
+    if (sp < -1) sp = -1;
+    rpy[1] = ASIN(sp);
+    rpy[2] = ATAN2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+}
+
+/* get_6d_pose_errors, cppflow/optimization_utils.py:802-820: e = [roll, pitch, yaw, x, y, z] errors */
+static void pose_error_row(const REAL* cur, const REAL* tgt, REAL* e) {
+    REAL inv[4], qe[4];
+    for (int i = 0; i < 3; ++i) e[3 + i] = tgt[i] - cur[i]; /* :813-814 */
+    quat_conj(cur + 3, inv);                                /* :816 */
+    quat_mul(tgt + 3, inv, qe);                             /* :817 */
+    quat_to_rpy(qe, e);                                     /* :818-819 */
+}
+
+void orc_pose_errors(const void* h, const double* x, const double* target, int n, double* e_out, double* cur_out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], cur[7], tgt[7], e[6];
+        frame_t ee;
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        for (int k = 0; k < 7; ++k) tgt[k] = (REAL)target[(size_t)r * 7 + k];
+        fk_chain(rb, q, NULL, NULL, NULL, &ee);
+        frame_to_pose(&ee, cur);
+        pose_error_row(cur, tgt, e);
+        for (int k = 0; k < 6; ++k) e_out[(size_t)r * 6 + k] = e[k];
+        if (cur_out)
+            for (int k = 0; k < 7; ++k) cur_out[(size_t)r * 7 + k] = cur[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* dense solves                                                                                                     */
+
+/* LU with partial pivoting, as torch.linalg.solve (getrf/getrs) does; A[d*d] row-major is destroyed. */
+static int lu_solve(REAL* A, REAL* b, int d) {
+    for (int k = 0; k < d; ++k) {
+        int piv = k;
+        REAL best = FABS(A[k * d + k]);
+        for (int i = k + 1; i < d; ++i)
+            if (FABS(A[i * d + k]) > best) {
+                best = FABS(A[i * d + k]);
+                piv = i;
+            }
+        if (best == 0) return -1;
+        if (piv != k) {
+            for (int c = 0; c < d; ++c) {
+                REAL t = A[k * d + c];
+                A[k * d + c] = A[piv * d + c];
+                A[piv * d + c] = t;
+            }
+            REAL t = b[k];
+            b[k] = b[piv];
+            b[piv] = t;
+        }
+        for (int i = k + 1; i < d; ++i) {
+            const REAL m = A[i * d + k] / A[k * d + k];
+            A[i * d + k] = m;
+            for (int c = k + 1; c < d; ++c) A[i * d + c] -= m * A[k * d + c];
+            b[i] -= m * b[k];
+        }
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        REAL s = b[i];
+        for (int c = i + 1; c < d; ++c) s -= A[i * d + c] * b[c];
+        b[i] = s / A[i * d + i];
+    }
+    return 0;
+}
+
+/* Cholesky A = L L^T (reference cppflow/optimization.py:95-113 uses this for the full step; test_cholesky property) */
+static int chol_solve(REAL* A, REAL* b, int d) {
+    for (int j = 0; j < d; ++j) {
+        REAL s = A[j * d + j];
+        for (int k = 0; k < j; ++k) s -= A[j * d + k] * A[j * d + k];
+        if (!(s > 0)) return -1;
+        const REAL l = SQRT(s);
+        A[j * d + j] = l;
+        for (int i = j + 1; i < d; ++i) {
+            REAL t = A[i * d + j];
+            for (int k = 0; k < j; ++k) t -= A[i * d + k] * A[j * d + k];
+            A[i * d + j] = t / l;
+        }
+    }
+    for (int i = 0; i < d; ++i) {
+        REAL s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[i * d + k] * b[k];
+        b[i] = s / A[i * d + i];
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        REAL s = b[i];
+        for (int k = i + 1; k < d; ++k) s -= A[k * d + i] * b[k];
+        b[i] = s / A[i * d + i];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* LM step                                                                                                          */
+
+/* one row of levenberg_marquardt_only_pose (cppflow/optimization.py:61-92).  J and e are returned SCALED, as the
+ * reference scales them in place before returning them (:77-80, :90-92).  Returns 0, or -1 if the solve broke down. */
+static int lm_step_row(const orc_robot* rb, const REAL* q, const REAL* tgt, REAL lambda, REAL a_pos, REAL a_rot,
+                       int solver, REAL* q_new, REAL* J, REAL* e) {
+    const int d = rb->ndof;
+    REAL cur[7];
+    frame_t ee;
+    jacobian_row(rb, q, J, &ee);  /* :74 */
+    frame_to_pose(&ee, cur);
+    pose_error_row(cur, tgt, e);  /* :73 */
+    for (int i = 0; i < 3; ++i) { /* :77-80 */
+        e[3 + i] *= a_pos;
+        e[i] *= a_rot;
+        for (int j = 0; j < d; ++j) {
+            J[(3 + i) * d + j] *= a_pos;
+            J[i * d + j] *= a_rot;
+        }
+    }
+    REAL A[ORC_MAX_DOF * ORC_MAX_DOF], b[ORC_MAX_DOF];
+    for (int i = 0; i < d; ++i) { /* :85-87 */
+        for (int j = 0; j < d; ++j) {
+            REAL s = 0;
+            for (int k = 0; k < 6; ++k) s += J[k * d + i] * J[k * d + j];
+            A[i * d + j] = s + (i == j ? lambda : (REAL)0);
+        }
+        REAL s = 0;
+        for (int k = 0; k < 6; ++k) s += J[k * d + i] * e[k];
+        b[i] = s;
+    }
+    const int rc = solver == 1 ? chol_solve(A, b, d) : lu_solve(A, b, d); /* :88 */
+    for (int j = 0; j < d; ++j) q_new[j] = q[j] + b[j];                    /* :90-92 */
+    return rc;
+}
+
+/* x[n,d], target[n,7] (already stacked, optimization.py:399-401) -> x_new[n,d], optional J[n,6,d], e[n,6].
+ * solver: 0 = LU with partial pivoting (torch.linalg.solve), 1 = Cholesky.  Returns number of rows whose solve failed. */
+int orc_lm_step(const void* h, const double* x, const double* target, int n, double lambda, double a_pos,
+                double a_rot, int solver, double* x_new, double* J_out, double* e_out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    int fails = 0;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], qn[ORC_MAX_DOF], tgt[7], J[6 * ORC_MAX_DOF], e[6];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        for (int k = 0; k < 7; ++k) tgt[k] = (REAL)target[(size_t)r * 7 + k];
+        if (lm_step_row(rb, q, tgt, (REAL)lambda, (REAL)a_pos, (REAL)a_rot, solver, qn, J, e) != 0) ++fails;
+        for (int j = 0; j < d; ++j) x_new[(size_t)r * d + j] = qn[j];
+        if (J_out)
+            for (int k = 0; k < 6 * d; ++k) J_out[(size_t)r * 6 * d + k] = J[k];
+        if (e_out)
+            for (int k = 0; k < 6; ++k) e_out[(size_t)r * 6 + k] = e[k];
+    }
+    return fails;
+}
+
+/* clamp_to_joint_limits, cppflow/optimization_utils.py:831-833 (in place) */
+void orc_clamp(const void* h, double* x, int n) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r)
+        for (int j = 0; j < d; ++j) {
+            REAL v = (REAL)x[(size_t)r * d + j];
+            if (v < rb->lo[j]) v = rb->lo[j];
+            if (v > rb->hi[j]) v = rb->hi[j];
+            x[(size_t)r * d + j] = v;
+        }
+}
+
+/* K iterations of { pose-only step ; clamp } -- the pose branch of the loop at cppflow/optimization.py:251-259 */
+int orc_lm_steps(const void* h, const double* x, const double* target, int n, int n_steps, double lambda,
+                 double a_pos, double a_rot, int solver, double* x_out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    int fails = 0;
+#pragma omp parallel for reduction(+ : fails) schedule(static)
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], qn[ORC_MAX_DOF], tgt[7], J[6 * ORC_MAX_DOF], e[6];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        for (int k = 0; k < 7; ++k) tgt[k] = (REAL)target[(size_t)r * 7 + k];
+        for (int it = 0; it < n_steps; ++it) {
+            if (lm_step_row(rb, q, tgt, (REAL)lambda, (REAL)a_pos, (REAL)a_rot, solver, qn, J, e) != 0) ++fails;
+            for (int j = 0; j < d; ++j) {
+                REAL v = qn[j];
+                if (v < rb->lo[j]) v = rb->lo[j];
+                if (v > rb->hi[j]) v = rb->hi[j];
+                q[j] = v;
+            }
+        }
+        for (int j = 0; j < d; ++j) x_out[(size_t)r * d + j] = q[j];
+    }
+    return fails;
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* pose-error metrics                                                                                               */
+
+/* positional_errors / rotational_errors (cppflow/evaluation_utils.py:134-141): ||t_target - t_cur||_2 in metres and the
+ * geodesic quaternion distance in radians: dot clipped to [-1,1], then 2*acos(clamp(dot, -1+1e-7, 1-1e-7))
+ * (formula quoted at cppflow/data_types.py:408-411), folded into [0, pi] so that q and -q are the same rotation. */
+void orc_pose_metrics(const void* h, const double* x, const double* target, int n, double* pos_err_m,
+                      double* rot_err_rad) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    const REAL pi = RC(3.14159265358979323846);
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], cur[7], tgt[7];
+        frame_t ee;
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        for (int k = 0; k < 7; ++k) tgt[k] = (REAL)target[(size_t)r * 7 + k];
+        fk_chain(rb, q, NULL, NULL, NULL, &ee);
+        frame_to_pose(&ee, cur);
+        const REAL dx = tgt[0] - cur[0], dy = tgt[1] - cur[1], dz = tgt[2] - cur[2];
+        pos_err_m[r] = SQRT(dx * dx + dy * dy + dz * dz);
+        REAL dot = tgt[3] * cur[3] + tgt[4] * cur[4] + tgt[5] * cur[5] + tgt[6] * cur[6];
+        if (dot > 1) dot = 1;
+        if (dot < -1) dot = -1;
+        const REAL eps = RC(1e-7);
+        if (dot > 1 - eps) dot = 1 - eps;
+        if (dot < -1 + eps) dot = -1 + eps;
+        REAL dist = 2 * ACOS(dot);
+        /* |remainder(dist + pi, 2 pi) - pi| */
+        REAL m = FMOD(dist + pi, 2 * pi);
+        if (m < 0) m += 2 * pi;
+        rot_err_rad[r] = FABS(m - pi);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* collision distances (canonical order)                                                                            */
+
+static inline REAL dot3(const REAL* a, const REAL* b) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
+static inline REAL clamp01(REAL v) { return v < 0 ? (REAL)0 : (v > 1 ? (REAL)1 : v); }
+
+/* closest distance between segments P1Q1 and P2Q2 (non-degenerate), Ericson "Real-Time Collision Detection" 5.1.9 */
+static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2) {
+    REAL d1[3], d2[3], rr[3];
+    for (int i = 0; i < 3; ++i) {
+        d1[i] = Q1[i] - P1[i];
+        d2[i] = Q2[i] - P2[i];
+        rr[i] = P1[i] - P2[i];
+    }
+    const REAL a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, rr), c = dot3(d1, rr), b = dot3(d1, d2);
+    const REAL denom = FMA(a, e, -(b * b));
+    REAL s = denom > 0 ? clamp01(FMA(b, f, -(c * e)) / denom) : (REAL)0;
+    REAL t = FMA(b, s, f) / e;
+    if (t < 0) {
+        t = 0;
+        s = clamp01(-c / a);
+    } else if (t > 1) {
+        t = 1;
+        s = clamp01((b - c) / a);
+    }
+    REAL df[3];
+    for (int i = 0; i < 3; ++i) df[i] = FMA(d1[i], s, P1[i]) - FMA(d2[i], t, P2[i]);
+    return SQRT(dot3(df, df));
+}
+
+/* g(t) = 1/2 d/dt dist^2(P + t D, box) = sum_i D_i * (x_i - clamp(x_i, lo_i, hi_i)) : nondecreasing, piecewise linear */
+static REAL seg_box_g(const REAL* P, const REAL* D, const REAL* lo, const REAL* hi, REAL t) {
+    REAL ex[3];
+    for (int i = 0; i < 3; ++i) {
+        const REAL x = FMA(D[i], t, P[i]);
+        const REAL cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+        ex[i] = x - cl;
+    }
+    return dot3(D, ex);
+}
+
+/* exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 if they intersect).
+ * dist^2 along the segment is convex and piecewise quadratic; its half-derivative g is evaluated at t = 0, t = 1 and at
+ * the (clamped) parameters where a coordinate crosses a box face; the minimiser is the root of g, bracketed by the
+ * largest candidate with g <= 0 and the smallest with g >= 0, between which g is linear. */
+static REAL seg_box_dist(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi) {
+    REAL D[3], cand[8], gv[8];
+    for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
+    cand[0] = 0;
+    cand[1] = 1;
+    for (int i = 0; i < 3; ++i) {
+        const REAL inv = D[i] != 0 ? (REAL)1 / D[i] : (REAL)0;
+        cand[2 + 2 * i] = clamp01((lo[i] - P0[i]) * inv);
+        cand[3 + 2 * i] = clamp01((hi[i] - P0[i]) * inv);
+    }
+    for (int k = 0; k < 8; ++k) gv[k] = seg_box_g(P0, D, lo, hi, cand[k]);
+    REAL t;
+    if (gv[0] >= 0) {
+        t = 0;
+    } else if (gv[1] <= 0) {
+        t = 1;
+    } else {
+        REAL tl = 0, gl = gv[0], tr = 1, gr = gv[1];
+        for (int k = 2; k < 8; ++k) {
+            if (gv[k] <= 0 && cand[k] >= tl) {
+                tl = cand[k];
+                gl = gv[k];
+            }
+            if (gv[k] >= 0 && cand[k] <= tr) {
+                tr = cand[k];
+                gr = gv[k];
+            }
+        }
+        const REAL dg = gr - gl;
+        t = dg > 0 ? FMA(tr - tl, (-gl) / dg, tl) : tl;
+    }
+    REAL ex[3];
+    for (int i = 0; i < 3; ++i) {
+        const REAL x = FMA(D[i], t, P0[i]);
+        const REAL cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+        ex[i] = x - cl;
+    }
+    return SQRT(dot3(ex, ex));
+}
+
+static void capsule_endpoints(const orc_robot* rb, const REAL* q, REAL (*w0)[3], REAL (*w1)[3]) {
+    frame_t links[ORC_MAX_DOF];
+    fk_chain(rb, q, links, NULL, NULL, NULL);
+    for (int c = 0; c < rb->ncaps; ++c) {
+        const int li = rb->cap_link[c];
+        if (li < 0) {
+            for (int i = 0; i < 3; ++i) {
+                w0[c][i] = rb->cap_p0[c][i];
+                w1[c][i] = rb->cap_p1[c][i];
+            }
+        } else {
+            const frame_t* f = &links[li];
+            for (int i = 0; i < 3; ++i) {
+                const REAL r0 = f->R[3 * i], r1 = f->R[3 * i + 1], r2 = f->R[3 * i + 2];
+                w0[c][i] = FMA(r2, rb->cap_p0[c][2], FMA(r1, rb->cap_p0[c][1], FMA(r0, rb->cap_p0[c][0], f->p[i])));
+                w1[c][i] = FMA(r2, rb->cap_p1[c][2], FMA(r1, rb->cap_p1[c][1], FMA(r0, rb->cap_p1[c][0], f->p[i])));
+            }
+        }
+    }
+}
+
+/* Robot.self_collision_distances: x[n,d] -> dists[n,P] (signed: segment distance - r_a - r_b), SURVEY a11 */
+void orc_self_dists(const void* h, const double* x, int n, double* dists) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        capsule_endpoints(rb, q, w0, w1);
+        for (int p = 0; p < rb->npairs; ++p) {
+            const int a = rb->pair_a[p], b = rb->pair_b[p];
+            const REAL dist = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]);
+            dists[(size_t)r * rb->npairs + p] = dist - (rb->cap_r[a] + rb->cap_r[b]);
+        }
+    }
+}
+
+/* Robot.env_collision_distances for ONE axis-aligned cuboid given by its world-frame corners lo/hi:
+ * x[n,d] -> dists[n,L] (signed: segment-box distance - r), column i <-> i-th capsule, SURVEY a12 */
+void orc_env_dists(const void* h, const double* x, int n, const double* box_lo, const double* box_hi, double* dists) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    REAL lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+        lo[i] = (REAL)box_lo[i];
+        hi[i] = (REAL)box_hi[i];
+    }
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        capsule_endpoints(rb, q, w0, w1);
+        for (int c = 0; c < rb->ncaps; ++c)
+            dists[(size_t)r * rb->ncaps + c] = seg_box_dist(w0[c], w1[c], lo, hi) - rb->cap_r[c];
+    }
+}
+
+/* capsule world endpoints [n, L, 6] (test helper) */
+void orc_capsule_endpoints(const void* h, const double* x, int n, double* out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        capsule_endpoints(rb, q, w0, w1);
+        for (int c = 0; c < rb->ncaps; ++c)
+            for (int i = 0; i < 3; ++i) {
+                out[((size_t)r * rb->ncaps + c) * 6 + i] = w0[c][i];
+                out[((size_t)r * rb->ncaps + c) * 6 + 3 + i] = w1[c][i];
+            }
+    }
+}
+
+/* qpaths_batched_{self,env}_collisions (cppflow/collision_detection.py:27-69) + joint_limit_almost_violations_3d
+ * (cppflow/search.py:25-52) + q_costs_external (cppflow/search.py:146-150) for n = k*T rows.
+ * jl_lo / jl_hi are the already-padded limits (l + eps, u - eps; search.py:46-51).  Any output may be NULL. */
+void orc_masks(const void* h, const double* x, int n, int nobs, const double* box_lo /*[O,3]*/,
+               const double* box_hi /*[O,3]*/, const double* jl_lo, const double* jl_hi, uint8_t* self_mask,
+               uint8_t* env_mask, uint8_t* jlim_mask, double* ext_cost, double* min_self, double* min_env) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        capsule_endpoints(rb, q, w0, w1);
+        REAL ms = INFINITY;
+        for (int p = 0; p < rb->npairs; ++p) {
+            const int a = rb->pair_a[p], b = rb->pair_b[p];
+            const REAL v = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]) - (rb->cap_r[a] + rb->cap_r[b]);
+            if (v < ms) ms = v;
+        }
+        int env = 0;
+        REAL me_all = INFINITY;
+        for (int o = 0; o < nobs; ++o) {
+            REAL lo[3], hi[3], me = INFINITY;
+            for (int i = 0; i < 3; ++i) {
+                lo[i] = (REAL)box_lo[o * 3 + i];
+                hi[i] = (REAL)box_hi[o * 3 + i];
+            }
+            for (int c = 0; c < rb->ncaps; ++c) {
+                const REAL v = seg_box_dist(w0[c], w1[c], lo, hi) - rb->cap_r[c];
+                if (v < me) me = v;
+            }
+            env |= (me < 0); /* collision_detection.py:39-43 */
+            if (me < me_all) me_all = me;
+        }
+        const int self = (ms < 0); /* collision_detection.py:66-68 */
+        int jl = 0;
+        if (jl_lo && jl_hi)
+            for (int j = 0; j < d; ++j) jl |= (q[j] < (REAL)jl_lo[j]) | (q[j] > (REAL)jl_hi[j]); /* search.py:52 */
+        if (self_mask) self_mask[r] = (uint8_t)self;
+        if (env_mask) env_mask[r] = (uint8_t)env;
+        if (jlim_mask) jlim_mask[r] = (uint8_t)jl;
+        if (ext_cost) ext_cost[r] = 100.0 * jl + 1000.0 * env + 1000.0 * self; /* search.py:14-15,146-150 */
+        if (min_self) min_self[r] = ms;
+        if (min_env) min_env[r] = me_all;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* trajectory metrics                                                                                               */
+
+static REAL wrap_pi(REAL dq) {
+    /* torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153) */
+    const REAL pi = RC(3.14159265358979323846);
+    REAL m = FMOD(dq + pi, 2 * pi);
+    if (m < 0) m += 2 * pi;
+    return m - pi;
+}
+
+/* angular_changes: qpath[T,c] -> [T-1,c] */
+void orc_angular_changes(const double* qpath, int T, int c, double* out) {
+    for (int t = 0; t + 1 < T; ++t)
+        for (int j = 0; j < c; ++j)
+            out[(size_t)t * c + j] =
+                wrap_pi((REAL)qpath[(size_t)(t + 1) * c + j] - (REAL)qpath[(size_t)t * c + j]);
+}
+
+/* validity half of x_is_valid for every seed (cppflow/optimization_utils.py:845-884, evaluation_utils.py:29-75):
+ * x[S*W,d], target[S*W,7] -> per seed: max pos err (cm), max rot err (deg), mjac revolute (deg), mjac prismatic (cm). */
+void orc_seed_validity(const void* h, const double* x, const double* target, int S, int W, double* out /*[S,4]*/) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    const REAL rad2deg = RC(57.29577951308232087680);
+    double* pe = (double*)malloc(sizeof(double) * (size_t)W);
+    double* re = (double*)malloc(sizeof(double) * (size_t)W);
+    for (int s = 0; s < S; ++s) {
+        const double* xs = x + (size_t)s * W * d;
+        orc_pose_metrics(h, xs, target + (size_t)s * W * 7, W, pe, re);
+        REAL mp = 0, mr = 0, mrev = 0, mpri = 0;
+        for (int w = 0; w < W; ++w) {
+            const REAL a = (REAL)100 * (REAL)pe[w], b = rad2deg * (REAL)re[w];
+            if (a > mp) mp = a;
+            if (b > mr) mr = b;
+        }
+        for (int w = 0; w + 1 < W; ++w)
+            for (int j = 0; j < d; ++j) {
+                const REAL dq = (REAL)xs[(size_t)(w + 1) * d + j] - (REAL)xs[(size_t)w * d + j];
+                if (rb->jtype[j] == 0) {
+                    const REAL v = FABS(rad2deg * wrap_pi(dq));
+                    if (v > mrev) mrev = v;
+                } else {
+                    const REAL v = FABS((REAL)100 * dq);
+                    if (v > mpri) mpri = v;
+                }
+            }
+        out[s * 4 + 0] = mp;
+        out[s * 4 + 1] = mr;
+        out[s * 4 + 2] = mrev;
+        out[s * 4 + 3] = mpri;
+    }
+    free(pe);
+    free(re);
+}

@@ -1,0 +1,225 @@
+"""ctypes loader for the CPU oracle (oracle/lmik_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+cppflow_amd/ does.  `Oracle(chain, f32=False)` wraps liborc64.so (fp64 ground truth) or liborc32.so (canonical-order
+fp32, the bit-level reference for masks and FK).  All arrays cross the boundary as float64 numpy arrays.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force: bool = False) -> None:
+    """Compile liborc64.so / liborc32.so with the Makefile next to this file (gcc)."""
+    args = ["make", "-C", _HERE]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+
+
+def _lib(f32: bool):
+    name = "liborc32.so" if f32 else "liborc64.so"
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
+        if not os.path.exists(path):
+            build()
+        lib = ctypes.CDLL(path)
+        lib.orc_robot_create.restype = ctypes.c_void_p
+        lib.orc_robot_create.argtypes = [
+            ctypes.c_int, _dp, _dp, _ip, _dp, _dp, ctypes.c_int, _ip, _dp, _dp, _dp, ctypes.c_int, _ip,
+        ]  # fmt: skip
+        lib.orc_robot_destroy.argtypes = [ctypes.c_void_p]
+        lib.orc_set_threads.argtypes = [ctypes.c_int]
+        lib.orc_fk.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
+        lib.orc_link_frames.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
+        lib.orc_jacobian.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
+        lib.orc_pose_errors.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, _dp, _dp]
+        lib.orc_lm_step.restype = ctypes.c_int
+        lib.orc_lm_step.argtypes = [
+            ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+            _dp, _dp, _dp,
+        ]  # fmt: skip
+        lib.orc_clamp.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int]
+        lib.orc_lm_steps.restype = ctypes.c_int
+        lib.orc_lm_steps.argtypes = [
+            ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+            ctypes.c_int, _dp,
+        ]  # fmt: skip
+        lib.orc_pose_metrics.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, _dp, _dp]
+        lib.orc_self_dists.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
+        lib.orc_env_dists.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp, _dp]
+        lib.orc_capsule_endpoints.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
+        lib.orc_masks.argtypes = [
+            ctypes.c_void_p, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _u8p, _u8p, _u8p, _dp, _dp, _dp,
+        ]  # fmt: skip
+        lib.orc_angular_changes.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp]
+        lib.orc_seed_validity.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]
+        _LIBS[name] = lib
+    return _LIBS[name]
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Oracle:
+    """One robot bound to one oracle build.  `chain` is a cppflow_amd.robot_model.CanonicalChain (plain arrays)."""
+
+    def __init__(self, chain, f32: bool = False, threads: int = 1):
+        self.f32 = f32
+        self.lib = _lib(f32)
+        self.chain = chain
+        self.ndof = int(chain.ndof)
+        self.n_caps = int(chain.cap_link.shape[0])
+        self.n_pairs = int(chain.pairs.shape[0])
+        F, Fee = _d(chain.F), _d(chain.F_ee)
+        jt = np.ascontiguousarray(chain.jtype, dtype=np.int32)
+        lo, hi = _d(chain.lo), _d(chain.hi)
+        cl = np.ascontiguousarray(chain.cap_link, dtype=np.int32)
+        p0, p1, cr = _d(chain.cap_p0), _d(chain.cap_p1), _d(chain.cap_r)
+        pairs = np.ascontiguousarray(chain.pairs, dtype=np.int32)
+        self.h = self.lib.orc_robot_create(
+            self.ndof, _p(F), _p(Fee), jt.ctypes.data_as(_ip), _p(lo), _p(hi), self.n_caps, cl.ctypes.data_as(_ip),
+            _p(p0), _p(p1), _p(cr), self.n_pairs, pairs.ctypes.data_as(_ip),
+        )  # fmt: skip
+        assert self.h, "orc_robot_create failed"
+        self.lib.orc_set_threads(threads)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.orc_robot_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_threads(self, n: int):
+        self.lib.orc_set_threads(int(n))
+
+    def _x(self, x):
+        x = _d(x)
+        assert x.ndim == 2 and x.shape[1] == self.ndof, x.shape
+        return x
+
+    def fk(self, x):
+        x = self._x(x)
+        out = np.empty((x.shape[0], 7))
+        self.lib.orc_fk(self.h, _p(x), x.shape[0], _p(out))
+        return out
+
+    def link_frames(self, x):
+        x = self._x(x)
+        out = np.empty((x.shape[0], self.ndof + 1, 12))
+        self.lib.orc_link_frames(self.h, _p(x), x.shape[0], _p(out))
+        return out
+
+    def jacobian(self, x):
+        x = self._x(x)
+        out = np.empty((x.shape[0], 6, self.ndof))
+        self.lib.orc_jacobian(self.h, _p(x), x.shape[0], _p(out))
+        return out
+
+    def pose_errors(self, x, target):
+        x, target = self._x(x), _d(target)
+        assert target.shape == (x.shape[0], 7)
+        e, cur = np.empty((x.shape[0], 6)), np.empty((x.shape[0], 7))
+        self.lib.orc_pose_errors(self.h, _p(x), _p(target), x.shape[0], _p(e), _p(cur))
+        return e, cur
+
+    def lm_step(self, x, target, lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35, solver=0):
+        """Returns (x_new, J_scaled, e_scaled, n_failed_solves)."""
+        x, target = self._x(x), _d(target)
+        n = x.shape[0]
+        assert target.shape == (n, 7)
+        xn, J, e = np.empty_like(x), np.empty((n, 6, self.ndof)), np.empty((n, 6))
+        fails = self.lib.orc_lm_step(
+            self.h, _p(x), _p(target), n, lm_lambda, alpha_position, alpha_rotation, solver, _p(xn), _p(J), _p(e)
+        )
+        return xn, J, e, fails
+
+    def clamp(self, x):
+        x = self._x(x).copy()
+        self.lib.orc_clamp(self.h, _p(x), x.shape[0])
+        return x
+
+    def lm_steps(self, x, target, n_steps, lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35, solver=0):
+        x, target = self._x(x), _d(target)
+        n = x.shape[0]
+        assert target.shape == (n, 7)
+        out = np.empty_like(x)
+        self.lib.orc_lm_steps(
+            self.h, _p(x), _p(target), n, int(n_steps), lm_lambda, alpha_position, alpha_rotation, solver, _p(out)
+        )
+        return out
+
+    def pose_metrics(self, x, target):
+        x, target = self._x(x), _d(target)
+        n = x.shape[0]
+        pe, re = np.empty(n), np.empty(n)
+        self.lib.orc_pose_metrics(self.h, _p(x), _p(target), n, _p(pe), _p(re))
+        return pe, re
+
+    def self_dists(self, x):
+        x = self._x(x)
+        out = np.empty((x.shape[0], self.n_pairs))
+        self.lib.orc_self_dists(self.h, _p(x), x.shape[0], _p(out))
+        return out
+
+    def env_dists(self, x, box_lo, box_hi):
+        x, lo, hi = self._x(x), _d(box_lo), _d(box_hi)
+        out = np.empty((x.shape[0], self.n_caps))
+        self.lib.orc_env_dists(self.h, _p(x), x.shape[0], _p(lo), _p(hi), _p(out))
+        return out
+
+    def capsule_endpoints(self, x):
+        x = self._x(x)
+        out = np.empty((x.shape[0], self.n_caps, 6))
+        self.lib.orc_capsule_endpoints(self.h, _p(x), x.shape[0], _p(out))
+        return out
+
+    def masks(self, x, boxes_lo=None, boxes_hi=None, jl_lo=None, jl_hi=None):
+        """Returns dict(self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env) for rows x[n,d]."""
+        x = self._x(x)
+        n = x.shape[0]
+        lo = _d(boxes_lo).reshape(-1, 3) if boxes_lo is not None and len(boxes_lo) else np.zeros((0, 3))
+        hi = _d(boxes_hi).reshape(-1, 3) if boxes_hi is not None and len(boxes_hi) else np.zeros((0, 3))
+        nobs = lo.shape[0]
+        sm, em, jm = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+        cost, ms, me = np.empty(n), np.empty(n), np.empty(n)
+        jl = _d(jl_lo) if jl_lo is not None else None
+        jh = _d(jl_hi) if jl_hi is not None else None
+        null = ctypes.cast(None, _dp)
+        self.lib.orc_masks(
+            self.h, _p(x), n, nobs, _p(lo) if nobs else null, _p(hi) if nobs else null,
+            _p(jl) if jl is not None else null, _p(jh) if jh is not None else null,
+            sm.ctypes.data_as(_u8p), em.ctypes.data_as(_u8p), jm.ctypes.data_as(_u8p), _p(cost), _p(ms), _p(me),
+        )  # fmt: skip
+        return dict(self_mask=sm, env_mask=em, jlim_mask=jm, ext_cost=cost, min_self=ms, min_env=me)
+
+    def angular_changes(self, qpath):
+        q = _d(qpath)
+        T, c = q.shape
+        out = np.empty((T - 1, c))
+        self.lib.orc_angular_changes(_p(q), T, c, _p(out))
+        return out
+
+    def seed_validity(self, x, target, S, W):
+        x, target = self._x(x), _d(target)
+        assert x.shape[0] == S * W and target.shape == (S * W, 7)
+        out = np.empty((S, 4))
+        self.lib.orc_seed_validity(self.h, _p(x), _p(target), S, W, _p(out))
+        return out
