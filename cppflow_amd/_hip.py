@@ -1,0 +1,165 @@
+"""ctypes binding of libcppflow_hip.so (include/cppflow_hip.h).  There is no CPU fallback: if the shared library has
+not been built (`python -m cppflow_amd.build` or `__graft_entry__.build()`), importing a compute entry point raises.
+"""
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+from cppflow_amd.robot_model import MAX_CAPSULES, MAX_DOF, MAX_OBSTACLES, MAX_PAIRS, CanonicalChain
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcppflow_hip.so")
+
+CPPF_OK = 0
+CPPF_ERR_INVALID = -1
+CPPF_ERR_HIP = -2
+CPPF_ERR_UNSUPPORTED = -3
+
+_f = ctypes.c_float
+_i32 = ctypes.c_int32
+_vp = ctypes.c_void_p
+
+
+class RobotDesc(ctypes.Structure):
+    """struct cppf_robot_desc"""
+
+    _fields_ = [
+        ("ndof", _i32),
+        ("F", (_f * 12) * MAX_DOF),
+        ("F_ee", _f * 12),
+        ("jtype", _i32 * MAX_DOF),
+        ("lo", _f * MAX_DOF),
+        ("hi", _f * MAX_DOF),
+        ("n_capsules", _i32),
+        ("cap_link", _i32 * MAX_CAPSULES),
+        ("cap_p0", (_f * 3) * MAX_CAPSULES),
+        ("cap_p1", (_f * 3) * MAX_CAPSULES),
+        ("cap_r", _f * MAX_CAPSULES),
+        ("n_pairs", _i32),
+        ("pairs", (_i32 * 2) * MAX_PAIRS),
+    ]
+
+
+class LmParams(ctypes.Structure):
+    """struct cppf_lm_params"""
+
+    _fields_ = [
+        ("lm_lambda", _f),
+        ("alpha_position", _f),
+        ("alpha_rotation", _f),
+        ("n_steps", _i32),
+        ("clamp", _i32),
+    ]
+
+
+class LmOutputs(ctypes.Structure):
+    """struct cppf_lm_outputs (device pointers; 0 = not requested)"""
+
+    _fields_ = [
+        ("x_out", _vp),
+        ("J_out", _vp),
+        ("e_out", _vp),
+        ("pos_err_m", _vp),
+        ("rot_err_rad", _vp),
+        ("self_mask", _vp),
+        ("env_mask", _vp),
+        ("jlim_mask", _vp),
+        ("ext_cost", _vp),
+        ("min_self", _vp),
+        ("min_env", _vp),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "cppf_abi_version": (ctypes.c_int, []),
+    "cppf_last_error": (ctypes.c_char_p, []),
+    "cppf_robot_create": (ctypes.c_int, [ctypes.POINTER(RobotDesc), ctypes.c_int, ctypes.POINTER(_vp)]),
+    "cppf_robot_destroy": (None, [_vp]),
+    "cppf_robot_ndof": (ctypes.c_int, [_vp]),
+    "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
+    "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
+    "cppf_forward_kinematics": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cppf_jacobian": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cppf_pose_errors": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "cppf_clamp_to_joint_limits": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    "cppf_lm_pose_steps": (
+        ctypes.c_int,
+        [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LmParams), ctypes.POINTER(LmOutputs), _vp],
+    ),
+    "cppf_collision_masks": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cppf_self_collision_distances": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
+    "cppf_env_collision_distances": (
+        ctypes.c_int,
+        [_vp, _vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f), _vp, _vp],
+    ),
+    "cppf_pose_error_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
+    "cppf_seed_validity": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libcppflow_hip.so (once).  Raises RuntimeError if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP library first (python -m cppflow_amd.build). "
+                "cppflow_amd has no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    """0 -> ok; contract violations -> AssertionError (the reference asserts, e.g. cppflow/optimization.py:402-405);
+    runtime failures -> RuntimeError."""
+    if rc == CPPF_OK:
+        return
+    msg = lib().cppf_last_error().decode("utf-8", "replace")
+    if rc == CPPF_ERR_INVALID:
+        raise AssertionError(msg)
+    raise RuntimeError(msg)
+
+
+def chain_to_desc(chain: CanonicalChain) -> RobotDesc:
+    d = RobotDesc()
+    d.ndof = int(chain.ndof)
+    for j in range(chain.ndof):
+        for k in range(12):
+            d.F[j][k] = float(chain.F[j, k])
+        d.jtype[j] = int(chain.jtype[j])
+        d.lo[j] = float(chain.lo[j])
+        d.hi[j] = float(chain.hi[j])
+    for k in range(12):
+        d.F_ee[k] = float(chain.F_ee[k])
+    d.n_capsules = chain.n_capsules
+    for c in range(chain.n_capsules):
+        d.cap_link[c] = int(chain.cap_link[c])
+        for k in range(3):
+            d.cap_p0[c][k] = float(chain.cap_p0[c, k])
+            d.cap_p1[c][k] = float(chain.cap_p1[c, k])
+        d.cap_r[c] = float(chain.cap_r[c])
+    d.n_pairs = chain.n_pairs
+    for p in range(chain.n_pairs):
+        d.pairs[p][0] = int(chain.pairs[p, 0])
+        d.pairs[p][1] = int(chain.pairs[p, 1])
+    return d
+
+
+def fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(_f))
+
+
+assert MAX_OBSTACLES == 8 and MAX_PAIRS == 128

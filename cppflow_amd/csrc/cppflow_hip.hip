@@ -1,0 +1,875 @@
+// cppflow_hip.hip -- kernels + C ABI of libcppflow_hip.so (gfx950 only; see include/cppflow_hip.h for the contract).
+//
+// Layout of the work: one (seed, waypoint) row per lane, 256 rows per workgroup; rows are independent (no reduction
+// across rows anywhere in the reference's pose-only step, cppflow/optimization.py:61-92), so there is no inter-workgroup
+// communication and the blockIdx -> rows map needs no XCD awareness: every workgroup streams its own contiguous slab of
+// x, and the only shared data (the [W,7] target path, <= 14 KB) sits in every XCD's L2.
+//
+// The fused kernel keeps x in registers across K iterations of
+//     FK -> pose error -> geometric Jacobian -> row scaling -> damped solve -> x += delta -> clamp
+// and then evaluates the pose-error metrics and (optionally) the capsule collision masks / search cost of the result
+// in the same launch.  The damped normal equations are solved in their dual form
+//     delta = Js^T (Js Js^T + lambda I6)^-1 es        ( == (Js^T Js + lambda I)^-1 Js^T es exactly, push-through identity)
+// which is a 6x6 SPD system for every ndof, conditioned like Js Js^T instead of the rank-deficient Js^T Js the reference
+// hands to LU, and cheaper than the primal form for ndof >= 6.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "lmik_device.h"
+
+using namespace cppf;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- per-row chain evaluation ---------------------------------------------------------------------------------------------
+
+template <int D>
+__device__ __forceinline__ void load_x(const float* __restrict__ x, size_t row, float (&q)[D]) {
+    const float* p = x + row * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(p)[k];
+            q[4 * k] = v.x, q[4 * k + 1] = v.y, q[4 * k + 2] = v.z, q[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q[j] = p[j];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_x(float* __restrict__ x, size_t row, const float (&q)[D]) {
+    float* p = x + row * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k)
+            reinterpret_cast<float4*>(p)[k] = make_float4(q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) p[j] = q[j];
+    }
+}
+
+// FK to the end-effector frame only
+template <int D>
+__device__ __forceinline__ void fk_ee(const ChainK& ch, const float (&q)[D], float (&R)[9], float (&p)[3]) {
+    frame_identity(R, p);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed(R, p, ch.F[j]);
+        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+    }
+    fk_fixed(R, p, ch.Fee);
+}
+
+// FK keeping every joint's world axis and origin (for the Jacobian)
+template <int D>
+__device__ __forceinline__ void fk_ee_axes(const ChainK& ch, const float (&q)[D], float (&R)[9], float (&p)[3],
+                                           float (&ax)[D][3], float (&og)[D][3]) {
+    frame_identity(R, p);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed(R, p, ch.F[j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+    }
+    fk_fixed(R, p, ch.Fee);
+}
+
+// geometric Jacobian, rows 0:3 angular / 3:6 linear
+template <int D>
+__device__ __forceinline__ void jacobian_from_axes(const ChainK& ch, const float (&pe)[3], const float (&ax)[D][3],
+                                                   const float (&og)[D][3], float (&J)[6][D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float z0 = ax[j][0], z1 = ax[j][1], z2 = ax[j][2];
+        if (!((ch.pris_mask >> j) & 1u)) {
+            const float rx = pe[0] - og[j][0], ry = pe[1] - og[j][1], rz = pe[2] - og[j][2];
+            J[0][j] = z0, J[1][j] = z1, J[2][j] = z2;
+            J[3][j] = CPPF_FMA(z1, rz, -(z2 * ry));
+            J[4][j] = CPPF_FMA(z2, rx, -(z0 * rz));
+            J[5][j] = CPPF_FMA(z0, ry, -(z1 * rx));
+        } else {
+            J[0][j] = J[1][j] = J[2][j] = 0.f;
+            J[3][j] = z0, J[4][j] = z1, J[5][j] = z2;
+        }
+    }
+}
+
+// get_6d_pose_errors without the quaternion detour: the five terms quaternion_to_rpy reads from q_target * q_cur^-1 are
+// entries of R_err = R_target * R_cur^T  (cppflow/optimization_utils.py:813-819)
+__device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
+                                           const float (&p)[3], float (&e)[6]) {
+    const float e20 = dot3(Rt[6], Rt[7], Rt[8], R[0], R[1], R[2]);
+    const float e21 = dot3(Rt[6], Rt[7], Rt[8], R[3], R[4], R[5]);
+    const float e22 = dot3(Rt[6], Rt[7], Rt[8], R[6], R[7], R[8]);
+    const float e10 = dot3(Rt[3], Rt[4], Rt[5], R[0], R[1], R[2]);
+    const float e00 = dot3(Rt[0], Rt[1], Rt[2], R[0], R[1], R[2]);
+    float sp = -e20;
+    sp = sp > 1.f ? 1.f : (sp < -1.f ? -1.f : sp);
+    e[0] = atan2f(e21, e22);
+    e[1] = asinf(sp);
+    e[2] = atan2f(e10, e00);
+    e[3] = tt[0] - p[0];
+    e[4] = tt[1] - p[1];
+    e[5] = tt[2] - p[2];
+}
+
+// positional / geodesic rotational error (cppflow/evaluation_utils.py:134-141).  The reference evaluates
+// 2*acos(clamp(q_t . q_c, -1+1e-7, 1-1e-7)) folded to [0, pi]; that is the rotation angle theta of R_err, floored at
+// 2*acos(1 - 1e-7) = 8.944e-4 rad by the clamp.  theta is taken from atan2(|skew(R_err)|/2, (tr - 1)/2), which keeps
+// full relative accuracy for small angles (acos near 1 does not).
+__device__ __forceinline__ void pose_metrics(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
+                                             const float (&p)[3], float& pos_err, float& rot_err) {
+    const float dx = tt[0] - p[0], dy = tt[1] - p[1], dz = tt[2] - p[2];
+    pos_err = __builtin_sqrtf(CPPF_FMA(dz, dz, CPPF_FMA(dy, dy, dx * dx)));
+    float E[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            E[3 * i + j] = dot3(Rt[3 * i], Rt[3 * i + 1], Rt[3 * i + 2], R[3 * j], R[3 * j + 1], R[3 * j + 2]);
+    const float a0 = E[7] - E[5], a1 = E[2] - E[6], a2 = E[3] - E[1];
+    const float sn = 0.5f * __builtin_sqrtf(CPPF_FMA(a2, a2, CPPF_FMA(a1, a1, a0 * a0)));
+    const float cs = 0.5f * (E[0] + E[4] + E[8] - 1.f);
+    const float theta = atan2f(sn, cs);
+    rot_err = fmaxf(theta, 8.94427191e-4f);
+}
+
+// one damped Gauss-Newton update in dual form; J and e are scaled in place (optimization.py:77-80)
+template <int D>
+__device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], float lambda, float a_pos, float a_rot,
+                                              float (&delta)[D]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        e[i] *= a_rot;
+        e[3 + i] *= a_pos;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            J[i][j] *= a_rot;
+            J[3 + i][j] *= a_pos;
+        }
+    }
+    // A = J J^T + lambda I (upper triangle), Cholesky A = L L^T with reciprocal pivots, pivot floor lambda
+    // (every exact pivot of A is >= lambda_min(A) >= lambda, so the floor only acts on rounding noise)
+    float L[6][6], inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int i = j; i < 6; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
+            if (i == j) s += lambda;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
+            if (i == j) {
+                s = fmaxf(s, lambda);
+                inv[j] = __frsqrt_rn(s);
+            } else {
+                L[i][j] = s * inv[j];
+            }
+        }
+    }
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = e[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = CPPF_FMA(J[i][k], y[i], s);
+        delta[k] = s;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void clamp_row(const ChainK& ch, float (&q)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = fminf(fmaxf(q[j], ch.lo[j]), ch.hi[j]);
+}
+
+// ---- collision stage --------------------------------------------------------------------------------------------------------
+// Capsule end points are wave-private scratch indexed by a wave-uniform but run-time capsule id, which registers cannot
+// do without spilling; they go to LDS as [capsule*6 + k][lane] so that a wave's 64 lanes hit 64 consecutive banks.
+struct CollOut {
+    float min_self, min_env;
+    int self_hit, env_hit;
+};
+
+template <int D>
+__device__ __forceinline__ void fk_capsules_to_lds(const ChainK& ch, const CollK& co, const float (&q)[D],
+                                                   float* __restrict__ lds, int tid, float (&R)[9], float (&p)[3]) {
+    frame_identity(R, p);
+    for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed(R, p, ch.F[j]);
+        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+        for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
+            float w0[3], w1[3];
+            xform_point(R, p, co.cap_p0[c], w0);
+            xform_point(R, p, co.cap_p1[c], w1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lds[(c * 6 + k) * kBlock + tid] = w0[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int tid, int c, float (&w0)[3], float (&w1)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        w0[k] = lds[(c * 6 + k) * kBlock + tid];
+        w1[k] = lds[(c * 6 + 3 + k) * kBlock + tid];
+    }
+}
+
+__device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float* __restrict__ lds, int tid) {
+    CollOut r;
+    r.min_self = INFINITY;
+    for (int pi = 0; pi < co.npairs; ++pi) {
+        const int a = co.pair_a[pi], b = co.pair_b[pi];
+        float a0[3], a1[3], b0[3], b1[3];
+        lds_capsule(lds, tid, a, a0, a1);
+        lds_capsule(lds, tid, b, b0, b1);
+        const float v = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
+        r.min_self = v < r.min_self ? v : r.min_self;
+    }
+    r.self_hit = r.min_self < 0.f;  // collision_detection.py:66-68
+    r.min_env = INFINITY;
+    r.env_hit = 0;
+    for (int o = 0; o < co.nobs; ++o) {
+        float me = INFINITY;
+        for (int c = 0; c < co.ncaps; ++c) {
+            float w0[3], w1[3];
+            lds_capsule(lds, tid, c, w0, w1);
+            const float v = seg_box_dist(w0, w1, co.obs_lo[o], co.obs_hi[o]) - co.cap_r[c];
+            me = v < me ? v : me;
+        }
+        r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
+        r.min_env = me < r.min_env ? me : r.min_env;
+    }
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ int jlim_hit(const CollK& co, const float (&q)[D]) {
+    int jl = 0;
+    if (co.has_jl) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) jl |= (q[j] < co.jl_lo[j]) | (q[j] > co.jl_hi[j]);  // search.py:52
+    }
+    return jl;
+}
+
+__device__ __forceinline__ void write_coll_outputs(size_t row, const CollOut& c, int jl, uint8_t* self_mask,
+                                                   uint8_t* env_mask, uint8_t* jlim_mask, float* ext_cost,
+                                                   float* min_self, float* min_env) {
+    if (self_mask) self_mask[row] = (uint8_t)c.self_hit;
+    if (env_mask) env_mask[row] = (uint8_t)c.env_hit;
+    if (jlim_mask) jlim_mask[row] = (uint8_t)jl;
+    if (ext_cost) ext_cost[row] = 100.f * (float)jl + 1000.f * (float)c.env_hit + 1000.f * (float)c.self_hit;
+    if (min_self) min_self[row] = c.min_self;
+    if (min_env) min_env[row] = c.min_env;
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_target(const float* __restrict__ target, int w, float (&Rt)[9], float (&tt)[3]) {
+    const float* t = target + (size_t)w * 7;
+    tt[0] = t[0], tt[1] = t[1], tt[2] = t[2];
+    quat_to_mat(t[3], t[4], t[5], t[6], Rt);
+}
+
+template <int D, bool COLL>
+__global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+                                                          const float* __restrict__ x_in,
+                                                          const float* __restrict__ target, const cppf_lm_outputs out) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)prm.n) return;
+    float q[D], Rt[9], tt[3];
+    load_x<D>(x_in, row, q);
+    load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+
+    for (int it = 0; it < prm.n_steps; ++it) {
+        float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
+        fk_ee_axes<D>(ch, q, R, p, ax, og);
+        pose_error(Rt, tt, R, p, e);
+        jacobian_from_axes<D>(ch, p, ax, og, J);
+        lm_dual_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+        if (it == prm.n_steps - 1) {
+            if (out.J_out) {
+                float* Jo = out.J_out + row * 6 * D;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j];
+            }
+            if (out.e_out) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) q[j] += delta[j];
+        if (prm.clamp) clamp_row<D>(ch, q);
+    }
+    if (out.x_out) store_x<D>(out.x_out, row, q);
+
+    if constexpr (COLL) {
+        float R[9], p[3];
+        fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
+        fk_fixed(R, p, ch.Fee);
+        if (out.pos_err_m || out.rot_err_rad) {
+            float pe, re;
+            pose_metrics(Rt, tt, R, p, pe, re);
+            if (out.pos_err_m) out.pos_err_m[row] = pe;
+            if (out.rot_err_rad) out.rot_err_rad[row] = re;
+        }
+        const CollOut c = collide_from_lds(co, lds, tid);
+        write_coll_outputs(row, c, jlim_hit<D>(co, q), out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost,
+                           out.min_self, out.min_env);
+    } else {
+        if (out.pos_err_m || out.rot_err_rad) {
+            float R[9], p[3], pe, re;
+            fk_ee<D>(ch, q, R, p);
+            pose_metrics(Rt, tt, R, p, pe, re);
+            if (out.pos_err_m) out.pos_err_m[row] = pe;
+            if (out.rot_err_rad) out.rot_err_rad[row] = re;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void collision_kernel(const ChainK ch, const CollK co, int n,
+                                                           const float* __restrict__ x, uint8_t* self_mask,
+                                                           uint8_t* env_mask, uint8_t* jlim_mask, float* ext_cost,
+                                                           float* min_self, float* min_env) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3];
+    load_x<D>(x, row, q);
+    fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
+    const CollOut c = collide_from_lds(co, lds, tid);
+    write_coll_outputs(row, c, jlim_hit<D>(co, q), self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env);
+}
+
+// full distance matrices (Robot.self_collision_distances / env_collision_distances); box = the single cuboid, co.nobs unused
+template <int D, bool ENV>
+__global__ __launch_bounds__(kBlock) void distances_kernel(const ChainK ch, const CollK co, int n,
+                                                           const float* __restrict__ x, float blo0, float blo1,
+                                                           float blo2, float bhi0, float bhi1, float bhi2,
+                                                           float* __restrict__ dists) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3];
+    load_x<D>(x, row, q);
+    fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
+    if constexpr (ENV) {
+        const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
+        for (int c = 0; c < co.ncaps; ++c) {
+            float w0[3], w1[3];
+            lds_capsule(lds, tid, c, w0, w1);
+            dists[row * co.ncaps + c] = seg_box_dist(w0, w1, lo, hi) - co.cap_r[c];
+        }
+    } else {
+        for (int pi = 0; pi < co.npairs; ++pi) {
+            const int a = co.pair_a[pi], b = co.pair_b[pi];
+            float a0[3], a1[3], b0[3], b1[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            dists[row * co.npairs + pi] = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void fk_kernel(const ChainK ch, int n, const float* __restrict__ x,
+                                                    float* __restrict__ poses) {
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], qt[4];
+    load_x<D>(x, row, q);
+    fk_ee<D>(ch, q, R, p);
+    mat_to_quat(R, qt);
+    float* o = poses + row * 7;
+    o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = qt[0], o[4] = qt[1], o[5] = qt[2], o[6] = qt[3];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void jacobian_kernel(const ChainK ch, int n, const float* __restrict__ x,
+                                                          float* __restrict__ Jout) {
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3], J[6][D];
+    load_x<D>(x, row, q);
+    fk_ee_axes<D>(ch, q, R, p, ax, og);
+    jacobian_from_axes<D>(ch, p, ax, og, J);
+    float* Jo = Jout + row * 6 * D;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pose_errors_kernel(const ChainK ch, int n, int W, const float* __restrict__ x,
+                                                             const float* __restrict__ target, float* __restrict__ e_out,
+                                                             float* __restrict__ cur_out) {
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], Rt[9], tt[3], e[6];
+    load_x<D>(x, row, q);
+    load_target(target, (int)(row % (size_t)W), Rt, tt);
+    fk_ee<D>(ch, q, R, p);
+    pose_error(Rt, tt, R, p, e);
+    if (e_out) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e_out[row * 6 + i] = e[i];
+    }
+    if (cur_out) {
+        float qt[4];
+        mat_to_quat(R, qt);
+        float* o = cur_out + row * 7;
+        o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = qt[0], o[4] = qt[1], o[5] = qt[2], o[6] = qt[3];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pose_metrics_kernel(const ChainK ch, int n, int W, const float* __restrict__ x,
+                                                              const float* __restrict__ target,
+                                                              float* __restrict__ pos_err, float* __restrict__ rot_err) {
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
+    load_x<D>(x, row, q);
+    load_target(target, (int)(row % (size_t)W), Rt, tt);
+    fk_ee<D>(ch, q, R, p);
+    pose_metrics(Rt, tt, R, p, pe, re);
+    if (pos_err) pos_err[row] = pe;
+    if (rot_err) rot_err[row] = re;
+}
+
+__global__ __launch_bounds__(kBlock) void clamp_kernel(const ChainK ch, size_t total, float* __restrict__ x) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % (size_t)ch.ndof);
+    x[i] = fminf(fmaxf(x[i], ch.lo[j]), ch.hi[j]);
+}
+
+// one wavefront per seed: lanes stride over the seed's W waypoints, then a 64-lane butterfly max
+template <int D>
+__global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, int S, int W, const float* __restrict__ x,
+                                                           const float* __restrict__ target, float* __restrict__ out) {
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    const float rad2deg = 57.29577951308232087680f;
+    float mp = 0.f, mr = 0.f, mrev = 0.f, mpri = 0.f;
+    for (int w = threadIdx.x; w < W; w += 64) {
+        const size_t row = (size_t)s * W + w;
+        float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
+        load_x<D>(x, row, q);
+        load_target(target, w, Rt, tt);
+        fk_ee<D>(ch, q, R, p);
+        pose_metrics(Rt, tt, R, p, pe, re);
+        mp = fmaxf(mp, 100.f * pe);
+        mr = fmaxf(mr, rad2deg * re);
+        if (w + 1 < W) {
+            float qn[D];
+            load_x<D>(x, row + 1, qn);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float dq = qn[j] - q[j];
+                if ((ch.pris_mask >> j) & 1u)
+                    mpri = fmaxf(mpri, fabsf(100.f * dq));
+                else
+                    mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mp = fmaxf(mp, __shfl_xor(mp, off, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, off, 64));
+        mrev = fmaxf(mrev, __shfl_xor(mrev, off, 64));
+        mpri = fmaxf(mpri, __shfl_xor(mpri, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        out[s * 4 + 0] = mp, out[s * 4 + 1] = mr, out[s * 4 + 2] = mrev, out[s * 4 + 3] = mpri;
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define CPPF_REQUIRE(cond, msg) \
+    do {                        \
+        if (!(cond)) return fail(CPPF_ERR_INVALID, std::string("cppflow_hip: ") + (msg)); \
+    } while (0)
+
+#define CPPF_HIP(call)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e__ = (call);                                                                             \
+        if (e__ != hipSuccess)                                                                               \
+            return fail(CPPF_ERR_HIP, std::string("cppflow_hip: " #call " failed: ") + hipGetErrorString(e__)); \
+    } while (0)
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+struct cppf_robot {
+    cppf_robot_desc desc;
+    ChainK chain;
+    CollK coll;
+    int device;
+    size_t lds_bytes;  // capsule end points: 6 floats per capsule per lane
+};
+
+namespace {
+
+// dispatch on ndof: the kernels are instantiated for the degrees of freedom of the shipped robots
+#define CPPF_DISPATCH_D(d, ...)                                                                               \
+    switch (d) {                                                                                              \
+        case 6: { constexpr int D = 6; __VA_ARGS__; } break;                                                  \
+        case 7: { constexpr int D = 7; __VA_ARGS__; } break;                                                  \
+        case 8: { constexpr int D = 8; __VA_ARGS__; } break;                                                  \
+        case 12: { constexpr int D = 12; __VA_ARGS__; } break;                                                \
+        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {6, 7, 8, 12}"); \
+    }
+
+int check_launch(const cppf_robot* rb) {
+    CPPF_HIP(hipGetLastError());
+    (void)rb;
+    return CPPF_OK;
+}
+
+int enter(const cppf_robot* rb) {
+    CPPF_REQUIRE(rb != nullptr, "robot handle is NULL");
+    CPPF_HIP(hipSetDevice(rb->device));
+    return CPPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cppf_abi_version(void) { return CPPF_ABI_VERSION; }
+
+const char* cppf_last_error(void) { return g_err.c_str(); }
+
+int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out) {
+    CPPF_REQUIRE(desc && out, "desc / out is NULL");
+    *out = nullptr;
+    const int d = desc->ndof;
+    CPPF_REQUIRE(d >= 1 && d <= CPPF_MAX_DOF, "ndof out of range");
+    CPPF_REQUIRE(desc->n_capsules >= 0 && desc->n_capsules <= CPPF_MAX_CAPSULES, "n_capsules out of range");
+    CPPF_REQUIRE(desc->n_pairs >= 0 && desc->n_pairs <= CPPF_MAX_PAIRS, "n_pairs out of range");
+    for (int j = 0; j < d; ++j) {
+        CPPF_REQUIRE(desc->jtype[j] == CPPF_JOINT_REVOLUTE || desc->jtype[j] == CPPF_JOINT_PRISMATIC, "bad joint type");
+        CPPF_REQUIRE(desc->lo[j] <= desc->hi[j], "joint limits: lo > hi");
+        for (int k = 0; k < 12; ++k) CPPF_REQUIRE(std::isfinite(desc->F[j][k]), "non-finite chain constant");
+    }
+    int prev = -1;
+    for (int c = 0; c < desc->n_capsules; ++c) {
+        const int l = desc->cap_link[c];
+        CPPF_REQUIRE(l >= -1 && l < d, "capsule link index out of range");
+        CPPF_REQUIRE(l >= prev, "capsules must be ordered by link (base first)");
+        prev = l;
+        float len2 = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const float dd = desc->cap_p1[c][k] - desc->cap_p0[c][k];
+            len2 += dd * dd;
+        }
+        CPPF_REQUIRE(len2 > 1e-12f, "degenerate capsule (p0 == p1)");
+        CPPF_REQUIRE(desc->cap_r[c] >= 0.f, "negative capsule radius");
+    }
+    for (int p = 0; p < desc->n_pairs; ++p) {
+        const int a = desc->pairs[p][0], b = desc->pairs[p][1];
+        CPPF_REQUIRE(a >= 0 && a < desc->n_capsules && b >= 0 && b < desc->n_capsules && a != b, "bad capsule pair");
+    }
+    int ndev = 0;
+    CPPF_HIP(hipGetDeviceCount(&ndev));
+    CPPF_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+
+    cppf_robot* rb = new (std::nothrow) cppf_robot();
+    if (!rb) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
+    rb->desc = *desc;
+    rb->device = device;
+    std::memset(&rb->chain, 0, sizeof(ChainK));
+    std::memset(&rb->coll, 0, sizeof(CollK));
+    rb->chain.ndof = d;
+    for (int j = 0; j < d; ++j) {
+        std::memcpy(rb->chain.F[j], desc->F[j], sizeof(float) * 12);
+        rb->chain.lo[j] = desc->lo[j];
+        rb->chain.hi[j] = desc->hi[j];
+        if (desc->jtype[j] == CPPF_JOINT_PRISMATIC) rb->chain.pris_mask |= (1u << j);
+    }
+    std::memcpy(rb->chain.Fee, desc->F_ee, sizeof(float) * 12);
+    CollK& co = rb->coll;
+    co.ncaps = desc->n_capsules;
+    co.npairs = desc->n_pairs;
+    for (int c = 0; c < co.ncaps; ++c) {
+        for (int k = 0; k < 3; ++k) {
+            co.cap_p0[c][k] = desc->cap_p0[c][k];
+            co.cap_p1[c][k] = desc->cap_p1[c][k];
+        }
+        co.cap_r[c] = desc->cap_r[c];
+    }
+    // cap_begin[l+1] = first capsule whose link >= l
+    for (int l = -1; l <= d; ++l) {
+        int first = co.ncaps;
+        for (int c = co.ncaps - 1; c >= 0; --c)
+            if (desc->cap_link[c] >= l) first = c;
+        co.cap_begin[l + 1] = first;
+    }
+    for (int p = 0; p < co.npairs; ++p) {
+        co.pair_a[p] = (uint8_t)desc->pairs[p][0];
+        co.pair_b[p] = (uint8_t)desc->pairs[p][1];
+    }
+    rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
+    *out = rb;
+    return CPPF_OK;
+}
+
+void cppf_robot_destroy(cppf_robot* robot) { delete robot; }
+
+int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
+
+int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
+    CPPF_REQUIRE(robot, "robot handle is NULL");
+    CPPF_REQUIRE(n_obs >= 0 && n_obs <= CPPF_MAX_OBSTACLES, "n_obs out of range");
+    CPPF_REQUIRE(n_obs == 0 || (cuboids && Rt), "cuboids / Rt is NULL");
+    for (int o = 0; o < n_obs; ++o) {
+        const float* R = Rt + o * 12;
+        const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k)
+            CPPF_REQUIRE(std::fabs(R[k] - I[k]) < 1e-8f, "only axis-aligned cuboids are supported (R must be I)");
+        for (int k = 0; k < 3; ++k) {
+            CPPF_REQUIRE(cuboids[o * 6 + k] <= cuboids[o * 6 + 3 + k], "cuboid min corner > max corner");
+            robot->coll.obs_lo[o][k] = R[9 + k] + cuboids[o * 6 + k];
+            robot->coll.obs_hi[o][k] = R[9 + k] + cuboids[o * 6 + 3 + k];
+        }
+    }
+    robot->coll.nobs = n_obs;
+    return CPPF_OK;
+}
+
+int cppf_set_joint_limit_padding(cppf_robot* robot, const float* lo_padded, const float* hi_padded) {
+    CPPF_REQUIRE(robot, "robot handle is NULL");
+    if (!lo_padded || !hi_padded) {
+        robot->coll.has_jl = 0;
+        return CPPF_OK;
+    }
+    for (int j = 0; j < robot->desc.ndof; ++j) {
+        robot->coll.jl_lo[j] = lo_padded[j];
+        robot->coll.jl_hi[j] = hi_padded[j];
+    }
+    robot->coll.has_jl = 1;
+    return CPPF_OK;
+}
+
+int cppf_forward_kinematics(const cppf_robot* robot, const float* x, int n, float* poses, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && poses, "x / poses is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((fk_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                                        robot->chain, n, x, poses));
+    return check_launch(robot);
+}
+
+int cppf_jacobian(const cppf_robot* robot, const float* x, int n, float* J, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && J, "x / J is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((jacobian_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                                        robot->chain, n, x, J));
+    return check_launch(robot);
+}
+
+int cppf_pose_errors(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* e,
+                     float* current_poses, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+    const size_t n = (size_t)S * W;
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    CPPF_REQUIRE(x && target, "x / target is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((pose_errors_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                                        robot->chain, (int)n, W, x, target, e, current_poses));
+    return check_launch(robot);
+}
+
+int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(x, "x is NULL");
+    const size_t total = (size_t)n * robot->desc.ndof;
+    hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, robot->chain, total, x);
+    return check_launch(robot);
+}
+
+int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
+                       const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(params && out, "params / out is NULL");
+    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+    CPPF_REQUIRE(params->n_steps >= 1, "n_steps must be >= 1");
+    CPPF_REQUIRE(params->clamp == 1 || params->n_steps == 1, "clamp = 0 is only defined for a single step");
+    CPPF_REQUIRE(params->lm_lambda > 0.f, "lm_lambda must be > 0");
+    const size_t n = (size_t)S * W;
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    CPPF_REQUIRE(x_in && target, "x_in / target is NULL");
+    LmK prm;
+    prm.lm_lambda = params->lm_lambda;
+    prm.a_pos = params->alpha_position;
+    prm.a_rot = params->alpha_rotation;
+    prm.n_steps = params->n_steps;
+    prm.clamp = params->clamp;
+    prm.n = (int)n;
+    prm.W = W;
+    const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self || out->min_env;
+    hipStream_t st = (hipStream_t)stream;
+    if (coll) {
+        CPPF_DISPATCH_D(robot->desc.ndof,
+                        hipLaunchKernelGGL((lm_fused_kernel<D, true>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
+                                           st, robot->chain, robot->coll, prm, x_in, target, *out));
+    } else {
+        CPPF_DISPATCH_D(robot->desc.ndof,
+                        hipLaunchKernelGGL((lm_fused_kernel<D, false>), dim3(grid_for(n)), dim3(kBlock), 0, st,
+                                           robot->chain, robot->coll, prm, x_in, target, *out));
+    }
+    return check_launch(robot);
+}
+
+int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,
+                         uint8_t* jlim_mask, float* ext_cost, float* min_self, float* min_env, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+    const size_t n = (size_t)S * W;
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    CPPF_REQUIRE(q, "q is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((collision_kernel<D>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st,
+                                       robot->chain, robot->coll, (int)n, q, self_mask, env_mask, jlim_mask, ext_cost,
+                                       min_self, min_env));
+    return check_launch(robot);
+}
+
+int cppf_self_collision_distances(const cppf_robot* robot, const float* x, int n, float* dists, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0 || robot->coll.npairs == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && dists, "x / dists is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((distances_kernel<D, false>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
+                                       st, robot->chain, robot->coll, n, x, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, dists));
+    return check_launch(robot);
+}
+
+int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n, const float* cuboid, const float* Rt,
+                                 float* dists, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    CPPF_REQUIRE(cuboid && Rt, "cuboid / Rt is NULL");
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k)
+        CPPF_REQUIRE(std::fabs(Rt[k] - I[k]) < 1e-8f, "only axis-aligned cuboids are supported (R must be I)");
+    if (n == 0 || robot->coll.ncaps == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && dists, "x / dists is NULL");
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = Rt[9 + k] + cuboid[k];
+        hi[k] = Rt[9 + k] + cuboid[3 + k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((distances_kernel<D, true>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
+                                       st, robot->chain, robot->coll, n, x, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2],
+                                       dists));
+    return check_launch(robot);
+}
+
+int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* pos_err_m,
+                            float* rot_err_rad, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+    const size_t n = (size_t)S * W;
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    CPPF_REQUIRE(x && target, "x / target is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((pose_metrics_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain,
+                                       (int)n, W, x, target, pos_err_m, rot_err_rad));
+    return check_launch(robot);
+}
+
+int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
+                       void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
+    if (S == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && target && out, "x / target / out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((seed_validity_kernel<D>), dim3(S), dim3(64), 0, st,
+                                                        robot->chain, S, W, x, target, out));
+    return check_launch(robot);
+}
+
+}  // extern "C"

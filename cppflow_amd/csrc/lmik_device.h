@@ -1,0 +1,264 @@
+// lmik_device.h -- device-side building blocks of the fused LM-IK kernels (gfx950 / CDNA4 only).
+//
+// Everything a wavefront shares (the canonical chain, joint limits, capsules, pair list, obstacles) arrives in the
+// kernel-argument segment (structs passed by value): every lane reads the same constant, so the compiler turns each
+// access into a scalar load (s_load_dword*) and the constants live in SGPRs -- no VGPRs, no LDS traffic, no bank
+// conflicts.  Per-row state (x, frames, Jacobian, the 6x6 dual system) lives in VGPRs, one row per lane.
+//
+// Canonical operation order.  FK, capsule end points and the two distance functions are written with explicit fmaf in
+// a fixed order so that they can be compared bit for bit with the fp32 build of the CPU oracle (tests only).  This file
+// is compiled with -ffp-contract=off; the only fused multiply-adds are the ones spelled out below.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cppflow_hip.h"
+
+#define CPPF_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+namespace cppf {
+
+// ---- kernel-argument structs (wave-uniform constants) -----------------------------------------------------------------
+struct ChainK {
+    float F[CPPF_MAX_DOF][12];
+    float Fee[12];
+    float lo[CPPF_MAX_DOF];
+    float hi[CPPF_MAX_DOF];
+    uint32_t pris_mask;  // bit j set: joint j is prismatic
+    int32_t ndof;
+};
+
+struct CollK {
+    float cap_p0[CPPF_MAX_CAPSULES][3];
+    float cap_p1[CPPF_MAX_CAPSULES][3];
+    float cap_r[CPPF_MAX_CAPSULES];
+    int32_t cap_begin[CPPF_MAX_DOF + 2];  // capsules of link l (-1..d-1) are [cap_begin[l+1], cap_begin[l+2])
+    uint8_t pair_a[CPPF_MAX_PAIRS];
+    uint8_t pair_b[CPPF_MAX_PAIRS];
+    float obs_lo[CPPF_MAX_OBSTACLES][3];  // world-frame box corners
+    float obs_hi[CPPF_MAX_OBSTACLES][3];
+    float jl_lo[CPPF_MAX_DOF];  // padded limits of search.py:46-51
+    float jl_hi[CPPF_MAX_DOF];
+    int32_t ncaps, npairs, nobs, has_jl;
+};
+
+struct LmK {
+    float lm_lambda, a_pos, a_rot;
+    int32_t n_steps, clamp;
+    int32_t n, W;
+};
+
+// ---- sin / cos ------------------------------------------------------------------------------------------------------------
+// Cody-Waite reduction by pi/2 in three exact pieces + Cephes single-precision minimax polynomials on [-pi/4, pi/4].
+// ~22 VALU instructions, no slow path: joint angles are bounded by the joint limits (|q| < 2^10 is ample).
+// The fp32 oracle build uses the identical formula, so FK agrees bit for bit.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+    const float k = __builtin_rintf(x * 0.63661977236758134f);
+    float r = CPPF_FMA(-k, 1.5703125f, x);
+    r = CPPF_FMA(-k, 4.837512969970703125e-4f, r);
+    r = CPPF_FMA(-k, 7.54978995489188e-8f, r);
+    const float z = r * r;
+    const float ps = CPPF_FMA(CPPF_FMA(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float sn = CPPF_FMA(r * z, ps, r);
+    const float pc = CPPF_FMA(CPPF_FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float cs = CPPF_FMA(z * z, pc, CPPF_FMA(-0.5f, z, 1.0f));
+    const int q = ((int)k) & 3;
+    float so = (q & 1) ? cs : sn;
+    float co = (q & 1) ? sn : cs;
+    if (q == 1 || q == 2) co = -co;
+    if (q >= 2) so = -so;
+    s = so;
+    c = co;
+}
+
+// ---- canonical FK steps ---------------------------------------------------------------------------------------------------
+// frame <- frame * F      (F = 12 wave-uniform floats: R row-major, t)
+__device__ __forceinline__ void fk_fixed(float (&R)[9], float (&p)[3], const float* __restrict__ F) {
+    float A[9], np[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float r0 = R[3 * i], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
+        np[i] = CPPF_FMA(r2, F[11], CPPF_FMA(r1, F[10], CPPF_FMA(r0, F[9], p[i])));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[3 * i + c] = CPPF_FMA(r2, F[6 + c], CPPF_FMA(r1, F[3 + c], r0 * F[c]));
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = A[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = np[k];
+}
+
+// frame <- frame * M_z(q): rotation about (revolute) or translation along (prismatic) the local z axis
+__device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool prismatic, float q) {
+    if (!prismatic) {
+        float s, c;
+        sincos_cw(q, s, c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a0 = R[3 * i], a1 = R[3 * i + 1];
+            R[3 * i] = CPPF_FMA(s, a1, c * a0);
+            R[3 * i + 1] = CPPF_FMA(c, a1, -(s * a0));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] = CPPF_FMA(R[3 * i + 2], q, p[i]);
+    }
+}
+
+__device__ __forceinline__ void frame_identity(float (&R)[9], float (&p)[3]) {
+    R[0] = 1.f, R[1] = 0.f, R[2] = 0.f, R[3] = 0.f, R[4] = 1.f, R[5] = 0.f, R[6] = 0.f, R[7] = 0.f, R[8] = 1.f;
+    p[0] = p[1] = p[2] = 0.f;
+}
+
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    return CPPF_FMA(a2, b2, CPPF_FMA(a1, b1, a0 * b0));
+}
+
+__device__ __forceinline__ float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+
+// world point of a link-frame constant point (canonical order shared with the oracle)
+__device__ __forceinline__ void xform_point(const float (&R)[9], const float (&p)[3], const float* __restrict__ c,
+                                            float (&w)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        w[i] = CPPF_FMA(R[3 * i + 2], c[2], CPPF_FMA(R[3 * i + 1], c[1], CPPF_FMA(R[3 * i], c[0], p[i])));
+}
+
+// ---- rotation matrix -> quaternion (w first; branch on the largest of w,x,y,z so the divisor is >= 1) -----------------------
+__device__ __forceinline__ void mat_to_quat(const float (&R)[9], float (&q)[4]) {
+    const float m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7], m22 = R[8];
+    const float q0 = 1.f + m00 + m11 + m22, q1 = 1.f + m00 - m11 - m22, q2 = 1.f - m00 + m11 - m22,
+                q3 = 1.f - m00 - m11 + m22;
+    int best = 0;
+    float bv = q0;
+    if (q1 > bv) best = 1, bv = q1;
+    if (q2 > bv) best = 2, bv = q2;
+    if (q3 > bv) best = 3, bv = q3;
+    const float d = __builtin_sqrtf(bv > 0.f ? bv : 0.f);
+    const float inv = 0.5f / d;
+    if (best == 0) {
+        q[0] = 0.5f * d, q[1] = (m21 - m12) * inv, q[2] = (m02 - m20) * inv, q[3] = (m10 - m01) * inv;
+    } else if (best == 1) {
+        q[0] = (m21 - m12) * inv, q[1] = 0.5f * d, q[2] = (m10 + m01) * inv, q[3] = (m02 + m20) * inv;
+    } else if (best == 2) {
+        q[0] = (m02 - m20) * inv, q[1] = (m10 + m01) * inv, q[2] = 0.5f * d, q[3] = (m12 + m21) * inv;
+    } else {
+        q[0] = (m10 - m01) * inv, q[1] = (m20 + m02) * inv, q[2] = (m21 + m12) * inv, q[3] = 0.5f * d;
+    }
+}
+
+// target quaternion (w,x,y,z) -> the matrix whose entries are the terms quaternion_to_rpy reads (unit quaternion assumed)
+__device__ __forceinline__ void quat_to_mat(float w, float x, float y, float z, float (&R)[9]) {
+    R[0] = 1.f - 2.f * (y * y + z * z);
+    R[1] = 2.f * (x * y - w * z);
+    R[2] = 2.f * (x * z + w * y);
+    R[3] = 2.f * (x * y + w * z);
+    R[4] = 1.f - 2.f * (x * x + z * z);
+    R[5] = 2.f * (y * z - w * x);
+    R[6] = 2.f * (x * z - w * y);
+    R[7] = 2.f * (y * z + w * x);
+    R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// ---- distances (canonical order) ------------------------------------------------------------------------------------------
+// closest distance between two non-degenerate segments (Ericson, Real-Time Collision Detection 5.1.9)
+__device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
+                                              const float (&Q2)[3]) {
+    float d1[3], d2[3], rr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d1[i] = Q1[i] - P1[i];
+        d2[i] = Q2[i] - P2[i];
+        rr[i] = P1[i] - P2[i];
+    }
+    const float a = dot3(d1[0], d1[1], d1[2], d1[0], d1[1], d1[2]);
+    const float e = dot3(d2[0], d2[1], d2[2], d2[0], d2[1], d2[2]);
+    const float f = dot3(d2[0], d2[1], d2[2], rr[0], rr[1], rr[2]);
+    const float c = dot3(d1[0], d1[1], d1[2], rr[0], rr[1], rr[2]);
+    const float b = dot3(d1[0], d1[1], d1[2], d2[0], d2[1], d2[2]);
+    const float denom = CPPF_FMA(a, e, -(b * b));
+    float s = denom > 0.f ? clamp01(CPPF_FMA(b, f, -(c * e)) / denom) : 0.f;
+    float t = CPPF_FMA(b, s, f) / e;
+    if (t < 0.f) {
+        t = 0.f;
+        s = clamp01(-c / a);
+    } else if (t > 1.f) {
+        t = 1.f;
+        s = clamp01((b - c) / a);
+    }
+    float df[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) df[i] = CPPF_FMA(d1[i], s, P1[i]) - CPPF_FMA(d2[i], t, P2[i]);
+    return __builtin_sqrtf(dot3(df[0], df[1], df[2], df[0], df[1], df[2]));
+}
+
+__device__ __forceinline__ float seg_box_g(const float (&P)[3], const float (&D)[3], const float* __restrict__ lo,
+                                           const float* __restrict__ hi, float t) {
+    float ex[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float x = CPPF_FMA(D[i], t, P[i]);
+        const float cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+        ex[i] = x - cl;
+    }
+    return dot3(D[0], D[1], D[2], ex[0], ex[1], ex[2]);
+}
+
+// exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 when they intersect): root of the nondecreasing,
+// piecewise-linear half-derivative g of dist^2, bracketed among t = 0, 1 and the six (clamped) face-crossing parameters.
+__device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+                                              const float* __restrict__ hi) {
+    float D[3], cand[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
+    cand[0] = 0.f;
+    cand[1] = 1.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float inv = D[i] != 0.f ? 1.f / D[i] : 0.f;
+        cand[2 + 2 * i] = clamp01((lo[i] - P0[i]) * inv);
+        cand[3 + 2 * i] = clamp01((hi[i] - P0[i]) * inv);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gv[k] = seg_box_g(P0, D, lo, hi, cand[k]);
+    float t;
+    if (gv[0] >= 0.f) {
+        t = 0.f;
+    } else if (gv[1] <= 0.f) {
+        t = 1.f;
+    } else {
+        float tl = 0.f, gl = gv[0], tr = 1.f, gr = gv[1];
+#pragma unroll
+        for (int k = 2; k < 8; ++k) {
+            if (gv[k] <= 0.f && cand[k] >= tl) {
+                tl = cand[k];
+                gl = gv[k];
+            }
+            if (gv[k] >= 0.f && cand[k] <= tr) {
+                tr = cand[k];
+                gr = gv[k];
+            }
+        }
+        const float dg = gr - gl;
+        t = dg > 0.f ? CPPF_FMA(tr - tl, (-gl) / dg, tl) : tl;
+    }
+    float ex[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float x = CPPF_FMA(D[i], t, P0[i]);
+        const float cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+        ex[i] = x - cl;
+    }
+    return __builtin_sqrtf(dot3(ex[0], ex[1], ex[2], ex[0], ex[1], ex[2]));
+}
+
+// torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153)
+__device__ __forceinline__ float wrap_pi(float dq) {
+    const float pi = 3.14159265358979323846f;
+    float m = __builtin_fmodf(dq + pi, 2.f * pi);
+    if (m < 0.f) m += 2.f * pi;
+    return m - pi;
+}
+
+}  // namespace cppf

@@ -1,0 +1,358 @@
+"""`Robot`: the duck type the reference's hot path reads off `jrl.robot.Robot`, backed by the HIP library.
+
+Attributes / methods mirrored (reference call sites):
+  ndof, name, formal_robot_name, actuated_joints_limits, revolute_joint_idxs, prismatic_joint_idxs,
+  has_prismatic_joints, split_configs_to_revolute_and_prismatic        cppflow/optimization_utils.py:228-234, 825-832;
+                                                                       cppflow/search.py:46-51, 119-121
+  forward_kinematics(x, out_device=, dtype=)                           cppflow/optimization_utils.py:811
+  jacobian(x)                                                          cppflow/optimization.py:74
+  self_collision_distances(x)                                          cppflow/collision_detection.py:65
+  env_collision_distances(x, cuboid, Tcuboid)                          cppflow/collision_detection.py:40
+  clamp_to_joint_limits(x), sample_joint_angles(n)                     tests/optimization_test.py:82, 135
+
+Every compute method takes CUDA (ROCm) float32 tensors and launches a hand-written gfx950 kernel through the C ABI on
+torch's current stream.  CPU tensors are rejected: this package has no CPU path.
+"""
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from cppflow_amd import _hip
+from cppflow_amd.robot_model import CanonicalChain, RobotSpec, canonicalize, urdf_forward_kinematics
+from cppflow_amd.robot_zoo import ROBOT_SPECS
+
+
+def _require_device_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on '{t.device}': cppflow_amd runs on MI355X only (no CPU fallback); move the tensor to cuda"
+        )
+    assert t.dtype == dtype, f"{name} must be {dtype}, is {t.dtype}"
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Robot:
+    def __init__(self, spec: RobotSpec):
+        self.spec: RobotSpec = spec
+        self.chain: CanonicalChain = canonicalize(spec)
+        self.name: str = spec.name
+        self.formal_robot_name: str = spec.formal_name
+        self.ndof: int = self.chain.ndof
+        self.actuated_joints_limits: List[Tuple[float, float]] = [
+            (float(l), float(u)) for l, u in zip(self.chain.lo, self.chain.hi)
+        ]
+        self.revolute_joint_idxs: List[int] = [j for j in range(self.ndof) if self.chain.jtype[j] == 0]
+        self.prismatic_joint_idxs: List[int] = [j for j in range(self.ndof) if self.chain.jtype[j] == 1]
+        self.n_capsules: int = self.chain.n_capsules
+        self.n_collision_pairs: int = self.chain.n_pairs
+        self.collision_capsule_names: List[str] = list(self.chain.cap_names)
+        self._desc = _hip.chain_to_desc(self.chain)
+        self._handles: Dict[int, ctypes.c_void_p] = {}
+        self._obstacles: Optional[Tuple[np.ndarray, np.ndarray]] = None
+        self._jl_padding: Optional[Tuple[np.ndarray, np.ndarray]] = None
+
+    # ---- static properties ------------------------------------------------------------------------------------------
+    @property
+    def has_prismatic_joints(self) -> bool:
+        return len(self.prismatic_joint_idxs) > 0
+
+    def __str__(self) -> str:
+        return f"<Robot[{self.name}] ndof={self.ndof} capsules={self.n_capsules} pairs={self.n_collision_pairs}>"
+
+    def split_configs_to_revolute_and_prismatic(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return x[:, self.revolute_joint_idxs], x[:, self.prismatic_joint_idxs]
+
+    def sample_joint_angles(self, n: int) -> np.ndarray:
+        lo, hi = self.chain.lo, self.chain.hi
+        return np.random.uniform(lo, hi, size=(n, self.ndof))
+
+    def link_frame_at_zero(self, link_name: str) -> np.ndarray:
+        """4x4 world transform of a named link at q = 0 (host, fp64).  Used for `path_offset_frame`
+        (reference cppflow/data_type_utils.py:65-73, there via klampt)."""
+        return urdf_forward_kinematics(self.spec, np.zeros(self.ndof), link=link_name)
+
+    # ---- handle management ---------------------------------------------------------------------------------------------
+    def _handle(self, device: torch.device) -> ctypes.c_void_p:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            out = ctypes.c_void_p()
+            _hip.check(_hip.lib().cppf_robot_create(ctypes.byref(self._desc), idx, ctypes.byref(out)))
+            h = out
+            self._handles[idx] = h
+            self._apply_obstacles(h)
+            self._apply_jl_padding(h)
+        return h
+
+    def __del__(self):
+        try:
+            for h in self._handles.values():
+                _hip.lib().cppf_robot_destroy(h)
+            self._handles = {}
+        except Exception:
+            pass
+
+    def _apply_obstacles(self, h) -> None:
+        if self._obstacles is None:
+            _hip.check(_hip.lib().cppf_set_obstacles(h, 0, None, None))
+        else:
+            cub, rt = self._obstacles
+            _hip.check(_hip.lib().cppf_set_obstacles(h, cub.shape[0], _hip.fptr(cub), _hip.fptr(rt)))
+
+    def _apply_jl_padding(self, h) -> None:
+        if self._jl_padding is None:
+            _hip.check(_hip.lib().cppf_set_joint_limit_padding(h, None, None))
+        else:
+            lo, hi = self._jl_padding
+            _hip.check(_hip.lib().cppf_set_joint_limit_padding(h, _hip.fptr(lo), _hip.fptr(hi)))
+
+    @staticmethod
+    def _pack_obstacles(cuboids: Sequence, Tcuboids: Sequence) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        """Problem.obstacles_cuboids ([6] each) and obstacles_Tcuboids (4x4 each; only R and t are read -- element
+        [3,3] is left 0 by the reference loader, cppflow/data_type_utils.py:120-124)."""
+        if cuboids is None or len(cuboids) == 0:
+            return None
+        assert len(cuboids) == len(Tcuboids)
+        cub = np.zeros((len(cuboids), 6), dtype=np.float32)
+        rt = np.zeros((len(cuboids), 12), dtype=np.float32)
+        for i, (c, T) in enumerate(zip(cuboids, Tcuboids)):
+            c = c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else np.asarray(c)
+            T = T.detach().cpu().numpy() if isinstance(T, torch.Tensor) else np.asarray(T)
+            cub[i] = c.astype(np.float32).reshape(6)
+            rt[i, :9] = T[:3, :3].astype(np.float32).reshape(9)
+            rt[i, 9:] = T[:3, 3].astype(np.float32)
+        return cub, rt
+
+    def set_obstacles(self, cuboids: Sequence, Tcuboids: Sequence) -> None:
+        self._obstacles = self._pack_obstacles(cuboids, Tcuboids)
+        for h in self._handles.values():
+            self._apply_obstacles(h)
+
+    def set_joint_limit_padding(self, eps_revolute: Optional[float], eps_prismatic: Optional[float]) -> None:
+        """Padded limits exactly as cppflow/search.py:46-51 forms them: fp32 tensors, in-place += / -= of the scalar."""
+        if eps_revolute is None:
+            self._jl_padding = None
+        else:
+            lo = np.array([l for l, _ in self.actuated_joints_limits], dtype=np.float32)
+            hi = np.array([u for _, u in self.actuated_joints_limits], dtype=np.float32)
+            er, ep = np.float32(eps_revolute), np.float32(eps_prismatic)
+            lo[self.prismatic_joint_idxs] += ep
+            lo[self.revolute_joint_idxs] += er
+            hi[self.prismatic_joint_idxs] -= ep
+            hi[self.revolute_joint_idxs] -= er
+            self._jl_padding = (lo, hi)
+        for h in self._handles.values():
+            self._apply_jl_padding(h)
+
+    def padded_joint_limits(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+        return self._jl_padding
+
+    # ---- jrl-compatible compute methods --------------------------------------------------------------------------------
+    def _x2d(self, x: torch.Tensor, name: str = "x") -> torch.Tensor:
+        x = _require_device_tensor(x, name)
+        assert x.dim() == 2 and x.shape[1] == self.ndof, f"{name} must be [n, {self.ndof}], is {tuple(x.shape)}"
+        return x
+
+    def forward_kinematics(self, x: torch.Tensor, out_device=None, dtype=None) -> torch.Tensor:
+        x = self._x2d(x)
+        poses = torch.empty((x.shape[0], 7), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_forward_kinematics(
+                self._handle(x.device), x.data_ptr(), x.shape[0], poses.data_ptr(), _stream_ptr(x.device)
+            )
+        )
+        if dtype is not None and dtype != torch.float32:
+            poses = poses.to(dtype)
+        if out_device is not None and torch.device(out_device) != poses.device:
+            poses = poses.to(out_device)
+        return poses
+
+    def jacobian(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._x2d(x)
+        J = torch.empty((x.shape[0], 6, self.ndof), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_jacobian(self._handle(x.device), x.data_ptr(), x.shape[0], J.data_ptr(), _stream_ptr(x.device))
+        )
+        return J
+
+    def self_collision_distances(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._x2d(x)
+        d = torch.empty((x.shape[0], self.n_collision_pairs), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_self_collision_distances(
+                self._handle(x.device), x.data_ptr(), x.shape[0], d.data_ptr(), _stream_ptr(x.device)
+            )
+        )
+        return d
+
+    def env_collision_distances(self, x: torch.Tensor, cuboid, Tcuboid) -> torch.Tensor:
+        x = self._x2d(x)
+        cub, rt = self._pack_obstacles([cuboid], [Tcuboid])
+        d = torch.empty((x.shape[0], self.n_capsules), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_env_collision_distances(
+                self._handle(x.device), x.data_ptr(), x.shape[0], _hip.fptr(cub[0]), _hip.fptr(rt[0]), d.data_ptr(),
+                _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return d
+
+    def clamp_to_joint_limits(self, x: torch.Tensor) -> torch.Tensor:
+        """In place (and returned), like cppflow/optimization_utils.py:831-833."""
+        x_c = self._x2d(x)
+        assert x_c.data_ptr() == x.data_ptr(), "clamp_to_joint_limits mutates its argument: x must be contiguous"
+        _hip.check(
+            _hip.lib().cppf_clamp_to_joint_limits(self._handle(x.device), x.data_ptr(), x.shape[0], _stream_ptr(x.device))
+        )
+        return x
+
+    # ---- fused entry points ----------------------------------------------------------------------------------------------
+    def pose_errors(self, x: torch.Tensor, target: torch.Tensor, want_current_poses: bool = True):
+        """get_6d_pose_errors: returns (e [n,6,1], current_poses [n,7]).  `target` is [W,7] with n % W == 0."""
+        x = self._x2d(x)
+        target = _require_device_tensor(target, "target_poses")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0, (tuple(target.shape), n)
+        e = torch.empty((n, 6, 1), dtype=torch.float32, device=x.device)
+        cur = torch.empty((n, 7), dtype=torch.float32, device=x.device) if want_current_poses else None
+        _hip.check(
+            _hip.lib().cppf_pose_errors(
+                self._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, e.data_ptr(),
+                cur.data_ptr() if cur is not None else None, _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return e, cur
+
+    def lm_pose_steps(
+        self,
+        x: torch.Tensor,
+        target: torch.Tensor,
+        lm_lambda: float,
+        alpha_position: float,
+        alpha_rotation: float,
+        n_steps: int = 1,
+        clamp: bool = True,
+        return_residual: bool = False,
+        want_errors: bool = False,
+        want_collisions: bool = False,
+        want_min_dists: bool = False,
+    ) -> Dict[str, torch.Tensor]:
+        """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
+        (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7]."""
+        x = self._x2d(x)
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7, tuple(target.shape)
+        assert W > 0 and n % W == 0, f"x has {n} rows, not a multiple of the {W} target waypoints"
+        dev = x.device
+        res: Dict[str, torch.Tensor] = {"x": torch.empty_like(x)}
+        out = _hip.LmOutputs()
+        out.x_out = res["x"].data_ptr()
+        if return_residual:
+            res["J"] = torch.empty((n, 6, self.ndof), dtype=torch.float32, device=dev)
+            res["e"] = torch.empty((n, 6, 1), dtype=torch.float32, device=dev)
+            out.J_out, out.e_out = res["J"].data_ptr(), res["e"].data_ptr()
+        if want_errors:
+            res["pos_err_m"] = torch.empty(n, dtype=torch.float32, device=dev)
+            res["rot_err_rad"] = torch.empty(n, dtype=torch.float32, device=dev)
+            out.pos_err_m, out.rot_err_rad = res["pos_err_m"].data_ptr(), res["rot_err_rad"].data_ptr()
+        if want_collisions:
+            for k in ("self_mask", "env_mask", "jlim_mask"):
+                res[k] = torch.empty(n, dtype=torch.uint8, device=dev)
+            res["ext_cost"] = torch.empty(n, dtype=torch.float32, device=dev)
+            out.self_mask, out.env_mask, out.jlim_mask = (res[k].data_ptr() for k in ("self_mask", "env_mask", "jlim_mask"))
+            out.ext_cost = res["ext_cost"].data_ptr()
+            if want_min_dists:
+                res["min_self"] = torch.empty(n, dtype=torch.float32, device=dev)
+                res["min_env"] = torch.empty(n, dtype=torch.float32, device=dev)
+                out.min_self, out.min_env = res["min_self"].data_ptr(), res["min_env"].data_ptr()
+        prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
+        _hip.check(
+            _hip.lib().cppf_lm_pose_steps(
+                self._handle(dev), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(prm), ctypes.byref(out),
+                _stream_ptr(dev),
+            )  # fmt: skip
+        )
+        return res
+
+    def collision_masks(self, q: torch.Tensor, want_min_dists: bool = False) -> Dict[str, torch.Tensor]:
+        """q [S, W, d] -> self_mask / env_mask / jlim_mask (bool [S,W]) and ext_cost (float [S,W]) in one launch, against
+        the obstacles / limit padding last given to set_obstacles / set_joint_limit_padding."""
+        q = _require_device_tensor(q, "q")
+        assert q.dim() == 3 and q.shape[2] == self.ndof, f"q must be [k, ntimesteps, {self.ndof}], is {tuple(q.shape)}"
+        S, W, _ = q.shape
+        dev = q.device
+        res = {k: torch.empty((S, W), dtype=torch.uint8, device=dev) for k in ("self_mask", "env_mask", "jlim_mask")}
+        res["ext_cost"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+        ms = me = None
+        if want_min_dists:
+            ms = res["min_self"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+            me = res["min_env"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+        _hip.check(
+            _hip.lib().cppf_collision_masks(
+                self._handle(dev), q.data_ptr(), S, W, res["self_mask"].data_ptr(), res["env_mask"].data_ptr(),
+                res["jlim_mask"].data_ptr(), res["ext_cost"].data_ptr(), ms.data_ptr() if ms is not None else None,
+                me.data_ptr() if me is not None else None, _stream_ptr(dev),
+            )  # fmt: skip
+        )
+        for k in ("self_mask", "env_mask", "jlim_mask"):
+            res[k] = res[k].view(torch.bool)
+        return res
+
+    def pose_error_metrics(self, x: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(positional error [n] in metres, rotational error [n] in radians); target [W,7], n % W == 0."""
+        x = self._x2d(x)
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0
+        pe = torch.empty(n, dtype=torch.float32, device=x.device)
+        re = torch.empty(n, dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_pose_error_metrics(
+                self._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, pe.data_ptr(), re.data_ptr(),
+                _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return pe, re
+
+    def seed_validity(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """[S,4]: per seed max position error (cm), max rotation error (deg), mjac revolute (deg), mjac prismatic (cm)."""
+        x = self._x2d(x)
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0
+        out = torch.empty((n // W, 4), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_seed_validity(
+                self._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, out.data_ptr(), _stream_ptr(x.device)
+            )
+        )
+        return out
+
+
+def get_robot(name: str) -> Robot:
+    """Stands in for jrl.robots.get_robot (cppflow/data_type_utils.py:197)."""
+    if name not in ROBOT_SPECS:
+        raise ValueError(f"unknown robot '{name}' (have {sorted(ROBOT_SPECS)})")
+    return Robot(ROBOT_SPECS[name]())
+
+
+def Panda() -> Robot:
+    return get_robot("panda")
+
+
+def Fetch() -> Robot:
+    return get_robot("fetch")
+
+
+def FetchArm() -> Robot:
+    return get_robot("fetch_arm")

@@ -1,0 +1,151 @@
+/*
+ * cppflow_hip.h -- C ABI of libcppflow_hip.so: the MI355X (gfx950) implementation of jstmn/cppflow's batched LM-IK
+ * refinement hot path (pose-only Levenberg-Marquardt step + batched self / environment collision masks).
+ *
+ * The reference has no FFI for this path (it is pure Python over torch + the un-vendored `jrl` package); the drop-in
+ * boundary is therefore a set of Python call signatures, mirrored by cppflow_amd/*.py, each of which lands on exactly
+ * one entry point below.  Every entry point cites the reference interface it replaces (paths under /root/reference).
+ *
+ * Conventions
+ *   - plain C, no torch types; all `x`, `target`, output pointers are DEVICE pointers to contiguous row-major fp32
+ *     (masks: uint8) on the robot's device; robot / obstacle descriptions are HOST pointers, copied at call time.
+ *   - the library never allocates or frees caller buffers; every launch is asynchronous on `stream` (a hipStream_t
+ *     passed as void*, NULL = the default stream); no host synchronisation inside any compute entry point.
+ *   - rows are (seed, waypoint) pairs: row r = s * W + w; `target` is [W, 7] and is indexed by r % W, which replaces the
+ *     reference's `torch.vstack([target_path] * parallel_count)` (cppflow/optimization.py:399-401).  Pass W = n for an
+ *     already-stacked [n, 7] target.
+ *   - return value 0 on success; CPPF_ERR_INVALID (contract / shape violation -> the Python shim raises AssertionError,
+ *     mirroring the reference's asserts), CPPF_ERR_HIP (runtime failure -> RuntimeError), CPPF_ERR_UNSUPPORTED.
+ *     cppf_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef CPPFLOW_HIP_H
+#define CPPFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPPF_ABI_VERSION 1
+
+#define CPPF_MAX_DOF 16
+#define CPPF_MAX_CAPSULES 24
+#define CPPF_MAX_PAIRS 128
+#define CPPF_MAX_OBSTACLES 8
+
+#define CPPF_OK 0
+#define CPPF_ERR_INVALID (-1)
+#define CPPF_ERR_HIP (-2)
+#define CPPF_ERR_UNSUPPORTED (-3)
+
+#define CPPF_JOINT_REVOLUTE 0
+#define CPPF_JOINT_PRISMATIC 1
+
+/* Canonical serial chain (cppflow_amd/robot_model.py): world_T_link_j = prod_{i<=j} F_i * M_z(q_i), ee = link_{d-1} * F_ee.
+ * Stands in for the `jrl.robot.Robot` object the reference passes around (cppflow/data_types.py:383). */
+typedef struct cppf_robot_desc {
+    int32_t ndof;
+    float F[CPPF_MAX_DOF][12]; /* per joint: rotation row-major (9) then translation (3) */
+    float F_ee[12];
+    int32_t jtype[CPPF_MAX_DOF]; /* CPPF_JOINT_* : motion about / along the local z axis */
+    float lo[CPPF_MAX_DOF];     /* robot.actuated_joints_limits (cppflow/optimization_utils.py:825-832) */
+    float hi[CPPF_MAX_DOF];
+    int32_t n_capsules;
+    int32_t cap_link[CPPF_MAX_CAPSULES]; /* moving link the capsule rides on, -1 = base; must be non-decreasing */
+    float cap_p0[CPPF_MAX_CAPSULES][3];
+    float cap_p1[CPPF_MAX_CAPSULES][3]; /* |p1 - p0| must be > 0 */
+    float cap_r[CPPF_MAX_CAPSULES];
+    int32_t n_pairs;
+    int32_t pairs[CPPF_MAX_PAIRS][2]; /* capsule index pairs checked by self_collision_distances */
+} cppf_robot_desc;
+
+/* cppflow/lm_hyper_parameters.py:14-81 (fields the pose-only step reads) + fused-loop controls */
+typedef struct cppf_lm_params {
+    float lm_lambda;      /* OptimizationParameters.lm_lambda      (ALT_LOSS_V2_1_POSE: 1e-6, :123) */
+    float alpha_position; /* OptimizationParameters.alpha_position (3.5,  :125) */
+    float alpha_rotation; /* OptimizationParameters.alpha_rotation (0.35, :126) */
+    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration) */
+    int32_t clamp;        /* 1: clamp_to_joint_limits after every step (the reference loop); 0: bare step (K must be 1) */
+} cppf_lm_params;
+
+/* Optional outputs of the fused launch; any pointer may be NULL. */
+typedef struct cppf_lm_outputs {
+    float* x_out;         /* [n, d]    x after K steps (may alias x_in) */
+    float* J_out;         /* [n, 6, d] SCALED Jacobian at the last linearisation point (optimization.py:77-80, 90-92) */
+    float* e_out;         /* [n, 6]    SCALED pose error there, rows [roll pitch yaw x y z] (optimization_utils.py:806) */
+    float* pos_err_m;     /* [n]  ||t_target - t(x_out)||_2            (evaluation_utils.py:134-136) */
+    float* rot_err_rad;   /* [n]  geodesic quaternion distance at x_out (evaluation_utils.py:139-141) */
+    uint8_t* self_mask;   /* [n]  min self distance < 0 at x_out        (collision_detection.py:52-69) */
+    uint8_t* env_mask;    /* [n]  OR over obstacles of min dist < 0     (collision_detection.py:27-49) */
+    uint8_t* jlim_mask;   /* [n]  joint within padding of a limit       (search.py:25-52) */
+    float* ext_cost;      /* [n]  100*jlim + 1000*env + 1000*self        (search.py:14-15, 146-150) */
+    float* min_self;      /* [n]  min over pairs of the signed distance (+inf when no pairs) */
+    float* min_env;       /* [n]  min over obstacles and capsules       (+inf when no obstacles) */
+} cppf_lm_outputs;
+
+typedef struct cppf_robot cppf_robot; /* opaque: host copy of the description + launch state for one device */
+
+int cppf_abi_version(void);
+const char* cppf_last_error(void);
+
+/* Replaces jrl.robots.get_robot(name) (cppflow/data_type_utils.py:197): validates and binds a description to `device`. */
+int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out);
+void cppf_robot_destroy(cppf_robot* robot);
+int cppf_robot_ndof(const cppf_robot* robot);
+
+/* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
+ * cuboids [O,6] = (-sx/2,-sy/2,-sz/2, sx/2,sy/2,sz/2); Rt [O,12] = rotation row-major (9) then translation (3), HOST
+ * pointers.  Only axis-aligned cuboids are accepted (R = I), as the reference asserts at data_type_utils.py:108. */
+int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt);
+
+/* Padded joint limits l + eps / u - eps of joint_limit_almost_violations_3d (cppflow/search.py:46-51), HOST [d] each. */
+int cppf_set_joint_limit_padding(cppf_robot* robot, const float* lo_padded, const float* hi_padded);
+
+/* Robot.forward_kinematics(x) -> [n,7] = [x y z qw qx qy qz] (call sites cppflow/optimization_utils.py:811,
+ * cppflow/evaluation_utils.py:115) */
+int cppf_forward_kinematics(const cppf_robot* robot, const float* x, int n, float* poses, void* stream);
+
+/* Robot.jacobian(x) -> [n,6,d], rows 0:3 angular, 3:6 linear, world frame (call site cppflow/optimization.py:74) */
+int cppf_jacobian(const cppf_robot* robot, const float* x, int n, float* J, void* stream);
+
+/* get_6d_pose_errors(robot, x, target_poses) -> (e [n,6], current_poses [n,7]); cppflow/optimization_utils.py:802-820 */
+int cppf_pose_errors(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* e,
+                     float* current_poses, void* stream);
+
+/* clamp_to_joint_limits(robot, x): in place; cppflow/optimization_utils.py:823-833 */
+int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* stream);
+
+/* levenberg_marquardt_only_pose (cppflow/optimization.py:61-92) followed by clamp_to_joint_limits (:259), K times in one
+ * launch, with the pose-error metrics of x_is_valid (cppflow/optimization_utils.py:847) and the collision masks / search
+ * cost (cppflow/collision_detection.py:27-69, cppflow/search.py:146-150) of the result evaluated in the same launch. */
+int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
+                       const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream);
+
+/* qpaths_batched_self_collisions / qpaths_batched_env_collisions (cppflow/collision_detection.py:27-69) +
+ * joint_limit_almost_violations_3d + q_costs_external (cppflow/search.py:25-52, 146-150) for q [S,W,d]. Outputs [S*W]. */
+int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,
+                         uint8_t* jlim_mask, float* ext_cost, float* min_self, float* min_env, void* stream);
+
+/* Robot.self_collision_distances(x) -> [n, n_pairs] (call site cppflow/collision_detection.py:65) */
+int cppf_self_collision_distances(const cppf_robot* robot, const float* x, int n, float* dists, void* stream);
+
+/* Robot.env_collision_distances(x, cuboid, Tcuboid) -> [n, n_capsules] for ONE cuboid (HOST cuboid[6], Rt[12]);
+ * call site cppflow/collision_detection.py:40 */
+int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n, const float* cuboid, const float* Rt,
+                                 float* dists, void* stream);
+
+/* calculate_pose_error_cm_deg's two per-row terms (cppflow/evaluation_utils.py:113-116) in metres / radians */
+int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* pos_err_m,
+                            float* rot_err_rad, void* stream);
+
+/* Validity half of x_is_valid for every seed (cppflow/optimization_utils.py:845-884, evaluation_utils.py:29-75):
+ * out [S,4] = max position error (cm), max rotation error (deg), max |revolute joint change| (deg),
+ * max |prismatic joint change| (cm) over the seed's W waypoints. */
+int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPPFLOW_HIP_H */

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is test infrastructure: build its two shared objects once per session (gcc, < 2 s)."""
+    from oracle import oracle
+
+    oracle.build()
+    yield
