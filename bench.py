@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- LM-IK iterations/s of the fused MI355X hot path (BASELINE.json metric), one process per GPU.
+
+A "step" is ONE pass of the hot path over one batch of synthetic seeds: a single launch of the fused kernel
+(cppf_lm_pose_steps) doing `--lm-steps` K iterations of { pose-only LM step ; clamp to joint limits } on every
+(seed, waypoint) row, then the pose-error metrics, self / environment collision masks, joint-limit mask and search cost of
+the result -- and, for N > 1, the one RCCL all-gather of the packed per-row costs / masks / errors that dp_search
+consumes.  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S seeds:
+weak scaling, seeds sharded, no data-path collective other than that all-gather).
+
+Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two
+cuboids of panda__2cubes -- the configuration the metric is quoted on ("1024 seeds x 256 waypoints x 7-DoF at 1 MI355X").
+Inputs are synthetic and already resident in HBM when the timed region starts: per waypoint q* ~ U(limits),
+target = FK(q*), seeds x0 = clamp(q* + 0.1 randn)  (the construction of the reference's tests/optimization_test.py:82,136-137).
+
+Prints ONE JSON line (rank 0).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak
+
+
+def algorithmic_flops_per_row_iter(d: int) -> float:
+    """FK 130*(d + n_fixed) + Jacobian 12d + pose error ~100 + scaling 6(d+1) + J^T J upper triangle
+    12*d(d+1)/2 + J^T e 12d + Cholesky d^3/3 + 2d^2 + update/clamp 3d   (d=7: ~1.9 kFLOP; the figure the survey states)."""
+    n_fixed = 1
+    return (
+        130.0 * (d + n_fixed) + 12 * d + 100 + 6 * (d + 1) + 12 * d * (d + 1) / 2 + 12 * d + d**3 / 3 + 2 * d * d + 3 * d
+    )
+
+
+def algorithmic_flops_collision(L: int, P: int, O: int) -> float:
+    """capsule end points 36 L + pairs 90 P_s + capsule-cuboid 150 L O."""
+    return 36.0 * L + 90.0 * P + 150.0 * L * O
+
+
+def algorithmic_bytes_per_row(d: int, collide: bool) -> float:
+    """read x 4d + read target 28 + write x 4d (+2 mask bytes + 4 cost bytes when collision is fused)."""
+    return 8.0 * d + 28.0 + (6.0 if collide else 0.0)
+
+
+def make_inputs(robot, S, W, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lo = torch.tensor([l for l, _ in robot.actuated_joints_limits], dtype=torch.float32)
+    hi = torch.tensor([u for _, u in robot.actuated_joints_limits], dtype=torch.float32)
+    q_star = lo + (hi - lo) * torch.rand((W, robot.ndof), generator=g)
+    target = robot.forward_kinematics(q_star.to(device))  # [W,7]
+    g2 = torch.Generator(device="cpu").manual_seed(1000 + seed)
+    x0 = q_star[None] + 0.1 * torch.randn((S, W, robot.ndof), generator=g2)
+    x0 = torch.minimum(torch.maximum(x0, lo), hi).reshape(S * W, robot.ndof).contiguous()
+    return x0.to(device), target.contiguous()
+
+
+def cpu_baseline(robot_name, obstacles, d, W, K, budget_s=15.0):
+    """Oracle (the CPU restatement of the reference path, oracle/lmik_oracle.c, fp32 canonical build, OpenMP over rows)
+    timed on this host on a bounded sample of the same workload: S_cpu seeds x W waypoints, K iterations + masks."""
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robot_zoo import ROBOT_SPECS
+    from oracle import oracle as orc
+
+    orc.build()
+    cores = os.cpu_count() or 1
+    chain = canonicalize(ROBOT_SPECS[robot_name]())
+    o = orc.Oracle(chain, f32=True, threads=cores)
+    rng = np.random.RandomState(0)
+    q_star = rng.uniform(chain.lo, chain.hi, size=(W, d)).astype(np.float32).astype(np.float64)
+    target = o.fk(q_star)
+    lo_b = np.array([np.float32(T[:3, 3]) + np.float32(c[:3]) for c, T in obstacles], dtype=np.float64).reshape(-1, 3)
+    hi_b = np.array([np.float32(T[:3, 3]) + np.float32(c[3:]) for c, T in obstacles], dtype=np.float64).reshape(-1, 3)
+
+    def run(S_cpu):
+        x0 = np.clip(np.tile(q_star[None], (S_cpu, 1, 1)) + 0.1 * rng.randn(S_cpu, W, d), chain.lo, chain.hi)
+        x0 = x0.reshape(S_cpu * W, d).astype(np.float32).astype(np.float64)
+        tgt = np.tile(target, (S_cpu, 1))
+        t0 = time.perf_counter()
+        x = o.lm_steps(x0, tgt, K, 1e-6, 3.5, 0.35, solver=0)
+        o.pose_metrics(x, tgt)
+        o.masks(x, lo_b, hi_b, chain.lo, chain.hi)
+        return time.perf_counter() - t0
+
+    t_probe = run(8)
+    S_cpu = int(max(8, min(1024, 8 * budget_s / max(t_probe, 1e-6))))
+    t = run(S_cpu)
+    return {
+        "value": S_cpu * W * K / t,
+        "unit": "LM-IK iterations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{S_cpu} seeds x {W} waypoints x {K} LM iterations + collision masks, fp32 C restatement "
+        f"(oracle/lmik_oracle.c, LU solve in reference order), OpenMP {cores} threads, {t:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--robot", default="panda")
+    ap.add_argument("--seeds", type=int, default=1024, help="seeds per GPU")
+    ap.add_argument("--waypoints", type=int, default=256)
+    ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
+    ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
+    from cppflow_amd.robots import get_robot
+    from cppflow_amd.search import DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC, DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE
+
+    robot = get_robot(args.robot)
+    d, S, W, K = robot.ndof, args.seeds, args.waypoints, args.lm_steps
+    n = S * W
+    collide = not args.no_collide
+    obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if collide else []
+    robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
+    robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
+
+    x0, target = make_inputs(robot, S, W, device, seed=rank)
+    x_out = torch.empty_like(x0)
+    packed = torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
+    gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device=device) if (world > 1 and collide) else None
+    prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
+
+    def step():
+        res = robot.lm_pose_steps(
+            x0, target, n_steps=K, clamp=True, x_out=x_out, packed_out=packed, want_errors=not collide, **prm
+        )
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, packed)
+        return res
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()  # torch's current stream == the stream the kernel is launched on
+        res = step()
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # kernel duration: a second pass with events bracketing the launch only (no collective inside the bracket)
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for i in range(args.steps):
+        kev[i][0].record()
+        robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=x_out, packed_out=packed, want_errors=not collide, **prm)
+        kev[i][1].record()
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    step_ms_events = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # sanity on the result of the last step (not timed): most rows converged, masks are plausible
+    pos_err = res["pos_err_m"]
+    conv_frac = float((pos_err < 1e-4).float().mean().item())
+
+    if rank == 0:
+        iters = float(n) * K * args.steps * world
+        flops_launch = n * (K * algorithmic_flops_per_row_iter(d)
+                            + (algorithmic_flops_collision(robot.n_capsules, robot.n_collision_pairs, len(obstacles)) if collide else 0.0))
+        bytes_launch = n * algorithmic_bytes_per_row(d, collide)
+        ach_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+        ach_gbps = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "LM-IK iterations/sec (seeds x waypoints)",
+            "value": iters / elapsed,
+            "unit": "LM-IK iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.robot}__2cubes geometry, {S} seeds/GPU x {W} waypoints x {d}-DoF, K={K} fused LM "
+                f"iterations per launch" + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
+                "robot": args.robot,
+                "seeds_per_gpu": S,
+                "waypoints": W,
+                "ndof": d,
+                "lm_iterations_per_step": K,
+                "collision_fused": collide,
+                "obstacles": len(obstacles),
+                "allgather_bytes_per_rank": int(packed.numel()) if gathered is not None else 0,
+                "converged_frac_pos_err_lt_1e-4": conv_frac,
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": ach_tflops,
+                "peak": F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach_tflops / F32_PEAK_TFLOPS,
+                "traffic": None,
+                "kernel": "lm_fused_kernel",
+                "kernel_ms": kernel_ms,
+                "note": "binding resource is the fp32 FMA rate (157.3 TFLOP/s: vector peak == f32-input MFMA peak); the "
+                "kernel issues VALU FMAs, no MFMA instructions.  achieved = algorithmic flops (SURVEY 8d) / kernel time",
+                "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
+            },
+            "step_ms_hip_events": step_ms_events,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.robot, obstacles, d, W, K)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -257,30 +257,35 @@ __device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int t
     }
 }
 
-__device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float* __restrict__ lds, int tid) {
+__device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float* __restrict__ lds, int tid,
+                                                    bool do_self, bool do_env) {
     CollOut r;
     r.min_self = INFINITY;
-    for (int pi = 0; pi < co.npairs; ++pi) {
-        const int a = co.pair_a[pi], b = co.pair_b[pi];
-        float a0[3], a1[3], b0[3], b1[3];
-        lds_capsule(lds, tid, a, a0, a1);
-        lds_capsule(lds, tid, b, b0, b1);
-        const float v = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
-        r.min_self = v < r.min_self ? v : r.min_self;
+    if (do_self) {
+        for (int pi = 0; pi < co.npairs; ++pi) {
+            const int a = co.pair_a[pi], b = co.pair_b[pi];
+            float a0[3], a1[3], b0[3], b1[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            const float v = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
+            r.min_self = v < r.min_self ? v : r.min_self;
+        }
     }
     r.self_hit = r.min_self < 0.f;  // collision_detection.py:66-68
     r.min_env = INFINITY;
     r.env_hit = 0;
-    for (int o = 0; o < co.nobs; ++o) {
-        float me = INFINITY;
-        for (int c = 0; c < co.ncaps; ++c) {
-            float w0[3], w1[3];
-            lds_capsule(lds, tid, c, w0, w1);
-            const float v = seg_box_dist(w0, w1, co.obs_lo[o], co.obs_hi[o]) - co.cap_r[c];
-            me = v < me ? v : me;
+    if (do_env) {
+        for (int o = 0; o < co.nobs; ++o) {
+            float me = INFINITY;
+            for (int c = 0; c < co.ncaps; ++c) {
+                float w0[3], w1[3];
+                lds_capsule(lds, tid, c, w0, w1);
+                const float v = seg_box_dist(w0, w1, co.obs_lo[o], co.obs_hi[o]) - co.cap_r[c];
+                me = v < me ? v : me;
+            }
+            r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
+            r.min_env = me < r.min_env ? me : r.min_env;
         }
-        r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
-        r.min_env = me < r.min_env ? me : r.min_env;
     }
     return r;
 }
@@ -361,7 +366,9 @@ __global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const
             if (out.pos_err_m) out.pos_err_m[row] = pe;
             if (out.rot_err_rad) out.rot_err_rad[row] = re;
         }
-        const CollOut c = collide_from_lds(co, lds, tid);
+        const bool do_self = out.self_mask || out.min_self || out.ext_cost;
+        const bool do_env = out.env_mask || out.min_env || out.ext_cost;
+        const CollOut c = collide_from_lds(co, lds, tid, do_self, do_env);
         write_coll_outputs(row, c, jlim_hit<D>(co, q), out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost,
                            out.min_self, out.min_env);
     } else {
@@ -386,8 +393,11 @@ __global__ __launch_bounds__(kBlock) void collision_kernel(const ChainK ch, cons
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3];
     load_x<D>(x, row, q);
-    fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
-    const CollOut c = collide_from_lds(co, lds, tid);
+    // wave-uniform: which halves of the work the caller asked for (jlim-only calls skip FK altogether)
+    const bool do_self = self_mask || min_self || ext_cost;
+    const bool do_env = env_mask || min_env || ext_cost;
+    if (do_self || do_env) fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
+    const CollOut c = collide_from_lds(co, lds, tid, do_self, do_env);
     write_coll_outputs(row, c, jlim_hit<D>(co, q), self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env);
 }
 

@@ -41,6 +41,8 @@ def _stream_ptr(device: torch.device) -> int:
 
 
 class Robot:
+    PACKED_BYTES_PER_ROW = 15  # 3 x fp32 (ext_cost, pos_err_m, rot_err_rad) + 3 x u8 (self, env, jlim masks)
+
     def __init__(self, spec: RobotSpec):
         self.spec: RobotSpec = spec
         self.chain: CanonicalChain = canonicalize(spec)
@@ -245,18 +247,38 @@ class Robot:
         want_errors: bool = False,
         want_collisions: bool = False,
         want_min_dists: bool = False,
+        x_out: Optional[torch.Tensor] = None,
+        packed_out: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
         """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
-        (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7]."""
+        (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7].
+
+        `x_out` (may be `x` itself) and `packed_out` let a caller reuse buffers: `packed_out` is a uint8 tensor of
+        `PACKED_BYTES_PER_ROW * n` bytes that receives ext_cost | pos_err_m | rot_err_rad (fp32 [n] each) then
+        self_mask | env_mask | jlim_mask (u8 [n] each) back to back -- the single buffer one RCCL all-gather ships to
+        every rank; it implies want_errors and want_collisions."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
         assert target.dim() == 2 and target.shape[1] == 7, tuple(target.shape)
         assert W > 0 and n % W == 0, f"x has {n} rows, not a multiple of the {W} target waypoints"
         dev = x.device
-        res: Dict[str, torch.Tensor] = {"x": torch.empty_like(x)}
+        if x_out is not None:
+            x_out = self._x2d(x_out, "x_out")
+            assert x_out.shape == x.shape and x_out.device == dev
+        res: Dict[str, torch.Tensor] = {"x": x_out if x_out is not None else torch.empty_like(x)}
         out = _hip.LmOutputs()
         out.x_out = res["x"].data_ptr()
+        if packed_out is not None:
+            assert packed_out.dtype == torch.uint8 and packed_out.is_cuda and packed_out.is_contiguous()
+            assert packed_out.numel() == self.PACKED_BYTES_PER_ROW * n and packed_out.data_ptr() % 4 == 0
+            f = packed_out[: 12 * n].view(torch.float32)
+            res["ext_cost"], res["pos_err_m"], res["rot_err_rad"] = f[:n], f[n : 2 * n], f[2 * n :]
+            m = packed_out[12 * n :]
+            res["self_mask"], res["env_mask"], res["jlim_mask"] = m[:n], m[n : 2 * n], m[2 * n :]
+            for k in ("ext_cost", "pos_err_m", "rot_err_rad", "self_mask", "env_mask", "jlim_mask"):
+                setattr(out, k, res[k].data_ptr())
+            want_errors = want_collisions = False
         if return_residual:
             res["J"] = torch.empty((n, 6, self.ndof), dtype=torch.float32, device=dev)
             res["e"] = torch.empty((n, 6, 1), dtype=torch.float32, device=dev)
@@ -284,28 +306,41 @@ class Robot:
         )
         return res
 
-    def collision_masks(self, q: torch.Tensor, want_min_dists: bool = False) -> Dict[str, torch.Tensor]:
+    def collision_masks(
+        self, q: torch.Tensor, want_min_dists: bool = False, only: Optional[Sequence[str]] = None
+    ) -> Dict[str, torch.Tensor]:
         """q [S, W, d] -> self_mask / env_mask / jlim_mask (bool [S,W]) and ext_cost (float [S,W]) in one launch, against
-        the obstacles / limit padding last given to set_obstacles / set_joint_limit_padding."""
+        the obstacles / limit padding last given to set_obstacles / set_joint_limit_padding.  `only` (subset of
+        "self", "env", "jlim") restricts the work: the kernel skips what no requested output needs."""
         q = _require_device_tensor(q, "q")
         assert q.dim() == 3 and q.shape[2] == self.ndof, f"q must be [k, ntimesteps, {self.ndof}], is {tuple(q.shape)}"
         S, W, _ = q.shape
         dev = q.device
-        res = {k: torch.empty((S, W), dtype=torch.uint8, device=dev) for k in ("self_mask", "env_mask", "jlim_mask")}
-        res["ext_cost"] = torch.empty((S, W), dtype=torch.float32, device=dev)
-        ms = me = None
+        parts = ("self", "env", "jlim") if only is None else tuple(only)
+        assert set(parts) <= {"self", "env", "jlim"} and len(parts) > 0, parts
+        res: Dict[str, torch.Tensor] = {}
+        for part in parts:
+            res[part + "_mask"] = torch.empty((S, W), dtype=torch.uint8, device=dev)
+        if only is None:
+            res["ext_cost"] = torch.empty((S, W), dtype=torch.float32, device=dev)
         if want_min_dists:
-            ms = res["min_self"] = torch.empty((S, W), dtype=torch.float32, device=dev)
-            me = res["min_env"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+            if "self" in parts:
+                res["min_self"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+            if "env" in parts:
+                res["min_env"] = torch.empty((S, W), dtype=torch.float32, device=dev)
+
+        def ptr(k):
+            return res[k].data_ptr() if k in res else None
+
         _hip.check(
             _hip.lib().cppf_collision_masks(
-                self._handle(dev), q.data_ptr(), S, W, res["self_mask"].data_ptr(), res["env_mask"].data_ptr(),
-                res["jlim_mask"].data_ptr(), res["ext_cost"].data_ptr(), ms.data_ptr() if ms is not None else None,
-                me.data_ptr() if me is not None else None, _stream_ptr(dev),
+                self._handle(dev), q.data_ptr(), S, W, ptr("self_mask"), ptr("env_mask"), ptr("jlim_mask"),
+                ptr("ext_cost"), ptr("min_self"), ptr("min_env"), _stream_ptr(dev),
             )  # fmt: skip
         )
         for k in ("self_mask", "env_mask", "jlim_mask"):
-            res[k] = res[k].view(torch.bool)
+            if k in res:
+                res[k] = res[k].view(torch.bool)
         return res
 
     def pose_error_metrics(self, x: torch.Tensor, target: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -595,6 +595,39 @@ void orc_pose_metrics(const void* h, const double* x, const double* target, int 
     }
 }
 
+/* The same two metrics with the geodesic term evaluated the numerically careful way: both quaternions normalised,
+ * angle = 2*atan2(|vec(q_t * q_c^-1)|, |w(q_t * q_c^-1)|), floored at the reference's clamp value 2*acos(1 - 1e-7).
+ * Mathematically identical to orc_pose_metrics; numerically it removes that formula's sensitivity to the quaternion
+ * norm (d(2 acos)/d(dot) = -2/sin(theta/2): a 1e-7 norm error of an fp32-stored target moves the result by 1e-4 rad at
+ * theta = 2e-3).  This is the quantity the HIP kernels report (DESIGN.md "rotation error"). */
+void orc_pose_metrics_exact(const void* h, const double* x, const double* target, int n, double* pos_err_m,
+                            double* rot_err_rad) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], cur[7], tgt[7], inv[4], qe[4];
+        frame_t ee;
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        for (int k = 0; k < 7; ++k) tgt[k] = (REAL)target[(size_t)r * 7 + k];
+        fk_chain(rb, q, NULL, NULL, NULL, &ee);
+        frame_to_pose(&ee, cur);
+        const REAL dx = tgt[0] - cur[0], dy = tgt[1] - cur[1], dz = tgt[2] - cur[2];
+        pos_err_m[r] = SQRT(dx * dx + dy * dy + dz * dz);
+        REAL nt = SQRT(tgt[3] * tgt[3] + tgt[4] * tgt[4] + tgt[5] * tgt[5] + tgt[6] * tgt[6]);
+        REAL nc = SQRT(cur[3] * cur[3] + cur[4] * cur[4] + cur[5] * cur[5] + cur[6] * cur[6]);
+        for (int k = 3; k < 7; ++k) {
+            tgt[k] /= nt;
+            cur[k] /= nc;
+        }
+        quat_conj(cur + 3, inv);
+        quat_mul(tgt + 3, inv, qe);
+        const REAL vn = SQRT(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]);
+        REAL th = 2 * ATAN2(vn, FABS(qe[0]));
+        const REAL floor_v = 2 * ACOS((REAL)1 - RC(1e-7));
+        rot_err_rad[r] = th > floor_v ? th : floor_v;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------------------- */
 /* collision distances (canonical order)                                                                            */
 

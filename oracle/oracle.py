@@ -56,6 +56,7 @@ def _lib(f32: bool):
             ctypes.c_int, _dp,
         ]  # fmt: skip
         lib.orc_pose_metrics.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, _dp, _dp]
+        lib.orc_pose_metrics_exact.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, _dp, _dp]
         lib.orc_self_dists.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
         lib.orc_env_dists.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp, _dp]
         lib.orc_capsule_endpoints.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp]
@@ -171,6 +172,14 @@ class Oracle:
         n = x.shape[0]
         pe, re = np.empty(n), np.empty(n)
         self.lib.orc_pose_metrics(self.h, _p(x), _p(target), n, _p(pe), _p(re))
+        return pe, re
+
+    def pose_metrics_exact(self, x, target):
+        """positional error and the norm-insensitive evaluation of the geodesic rotation error (see the C source)."""
+        x, target = self._x(x), _d(target)
+        n = x.shape[0]
+        pe, re = np.empty(n), np.empty(n)
+        self.lib.orc_pose_metrics_exact(self.h, _p(x), _p(target), n, _p(pe), _p(re))
         return pe, re
 
     def self_dists(self, x):
