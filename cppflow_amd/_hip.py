@@ -112,6 +112,11 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build the HIP library first (python -m cppflow_amd.build). "
                 "cppflow_amd has no CPU fallback."
             )
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be resident BEFORE this library is
+        # loaded so that our DT_NEEDED libamdhip64.so.7 binds to that same in-process runtime: the kernels are launched
+        # on torch's streams, and two HIP runtimes in one process do not share devices or streams.
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
