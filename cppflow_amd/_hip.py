@@ -11,7 +11,7 @@ import numpy as np
 from cppflow_amd.robot_model import MAX_CAPSULES, MAX_DOF, MAX_OBSTACLES, MAX_PAIRS, CanonicalChain
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcppflow_hip.so")
+LIB_PATH = os.environ.get("CPPFLOW_HIP_LIB", os.path.join(_HERE, "csrc", "libcppflow_hip.so"))
 
 CPPF_OK = 0
 CPPF_ERR_INVALID = -1
@@ -80,6 +80,8 @@ SIGNATURES = {
     "cppf_robot_create": (ctypes.c_int, [ctypes.POINTER(RobotDesc), ctypes.c_int, ctypes.POINTER(_vp)]),
     "cppf_robot_destroy": (None, [_vp]),
     "cppf_robot_ndof": (ctypes.c_int, [_vp]),
+    "cppf_robot_specialization": (ctypes.c_int, [_vp]),
+    "cppf_debug_force_generic": (None, [ctypes.c_int]),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_forward_kinematics": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),

@@ -7,7 +7,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["cppflow_hip.hip"]
-HEADERS = ["lmik_device.h", os.path.join("..", "..", "include", "cppflow_hip.h")]
+HEADERS = ["lmik_device.h", "robots_gen.h", os.path.join("..", "..", "include", "cppflow_hip.h")]
 OUT = os.path.join(CSRC, "libcppflow_hip.so")
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() of the canonical operation order, so FK and the
@@ -20,6 +20,9 @@ HIPCC_FLAGS = [
     "-shared",
     "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
+    # no SLP vectorisation: v_pk_fma_f32 / v_pk_mul_f32 issue no faster than two scalar ops on gfx950 for this code and
+    # cost register-pair shuffles (v_mov); measured -13 % kernel time on the fused launch
+    "-fno-slp-vectorize",
     "-Wno-comment",
 ]
 
@@ -33,6 +36,10 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    from cppflow_amd import gen_robots
+
+    if gen_robots.write() and verbose:
+        print("regenerated", gen_robots.OUT)
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "hipcc")

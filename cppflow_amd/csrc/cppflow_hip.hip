@@ -21,12 +21,21 @@
 #include <string>
 
 #include "lmik_device.h"
+#include "robots_gen.h"
 
 using namespace cppf;
 
 namespace {
 
 constexpr int kBlock = 256;
+
+// minimum resident waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef CPPF_WAVES_LM
+#define CPPF_WAVES_LM 2
+#endif
+#ifndef CPPF_WAVES_COLL
+#define CPPF_WAVES_COLL 2
+#endif
 
 // ---- per-row chain evaluation ---------------------------------------------------------------------------------------------
 
@@ -59,43 +68,43 @@ __device__ __forceinline__ void store_x(float* __restrict__ x, size_t row, const
 }
 
 // FK to the end-effector frame only
-template <int D>
-__device__ __forceinline__ void fk_ee(const ChainK& ch, const float (&q)[D], float (&R)[9], float (&p)[3]) {
+template <class RB>
+__device__ __forceinline__ void fk_ee(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3]) {
     frame_identity(R, p);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        fk_fixed(R, p, ch.F[j]);
-        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+        fk_joint(R, p, rb.pris(j), q[j]);
     }
-    fk_fixed(R, p, ch.Fee);
+    fk_fixed_ee(rb, R, p);
 }
 
 // FK keeping every joint's world axis and origin (for the Jacobian)
-template <int D>
-__device__ __forceinline__ void fk_ee_axes(const ChainK& ch, const float (&q)[D], float (&R)[9], float (&p)[3],
-                                           float (&ax)[D][3], float (&og)[D][3]) {
+template <class RB>
+__device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
+                                           float (&ax)[RB::D][3], float (&og)[RB::D][3]) {
     frame_identity(R, p);
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        fk_fixed(R, p, ch.F[j]);
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             ax[j][i] = R[3 * i + 2];
             og[j][i] = p[i];
         }
-        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+        fk_joint(R, p, rb.pris(j), q[j]);
     }
-    fk_fixed(R, p, ch.Fee);
+    fk_fixed_ee(rb, R, p);
 }
 
 // geometric Jacobian, rows 0:3 angular / 3:6 linear
-template <int D>
-__device__ __forceinline__ void jacobian_from_axes(const ChainK& ch, const float (&pe)[3], const float (&ax)[D][3],
-                                                   const float (&og)[D][3], float (&J)[6][D]) {
+template <class RB>
+__device__ __forceinline__ void jacobian_from_axes(const RB& rb, const float (&pe)[3], const float (&ax)[RB::D][3],
+                                                   const float (&og)[RB::D][3], float (&J)[6][RB::D]) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
+    for (int j = 0; j < RB::D; ++j) {
         const float z0 = ax[j][0], z1 = ax[j][1], z2 = ax[j][2];
-        if (!((ch.pris_mask >> j) & 1u)) {
+        if (!rb.pris(j)) {
             const float rx = pe[0] - og[j][0], ry = pe[1] - og[j][1], rz = pe[2] - og[j][2];
             J[0][j] = z0, J[1][j] = z1, J[2][j] = z2;
             J[3][j] = CPPF_FMA(z1, rz, -(z2 * ry));
@@ -207,10 +216,10 @@ __device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], f
     }
 }
 
-template <int D>
-__device__ __forceinline__ void clamp_row(const ChainK& ch, float (&q)[D]) {
+template <class RB>
+__device__ __forceinline__ void clamp_row(const RB& rb, float (&q)[RB::D]) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) q[j] = fminf(fmaxf(q[j], ch.lo[j]), ch.hi[j]);
+    for (int j = 0; j < RB::D; ++j) q[j] = fminf(fmaxf(q[j], rb.lo(j)), rb.hi(j));
 }
 
 // ---- collision stage --------------------------------------------------------------------------------------------------------
@@ -221,8 +230,8 @@ struct CollOut {
     int self_hit, env_hit;
 };
 
-template <int D>
-__device__ __forceinline__ void fk_capsules_to_lds(const ChainK& ch, const CollK& co, const float (&q)[D],
+template <class RB>
+__device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co, const float (&q)[RB::D],
                                                    float* __restrict__ lds, int tid, float (&R)[9], float (&p)[3]) {
     frame_identity(R, p);
     for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
@@ -233,13 +242,13 @@ __device__ __forceinline__ void fk_capsules_to_lds(const ChainK& ch, const CollK
         }
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        fk_fixed(R, p, ch.F[j]);
-        fk_joint(R, p, (ch.pris_mask >> j) & 1u, q[j]);
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+        fk_joint(R, p, rb.pris(j), q[j]);
         for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
             float w0[3], w1[3];
-            xform_point(R, p, co.cap_p0[c], w0);
-            xform_point(R, p, co.cap_p1[c], w1);
+            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
+            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 lds[(c * 6 + k) * kBlock + tid] = w0[k];
@@ -247,6 +256,65 @@ __device__ __forceinline__ void fk_capsules_to_lds(const ChainK& ch, const CollK
             }
         }
     }
+}
+
+// Robot-specialised variant: capsule ids, link ids and the pair list are compile-time, so the end points live in VGPRs
+// (static indices after unrolling) and no LDS is touched.  Same canonical operation order as the LDS variant.
+template <class RB>
+__device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co, const float (&q)[RB::D], float (&R)[9],
+                                                  float (&p)[3], bool do_self, bool do_env) {
+    using T = typename RB::Table;
+    constexpr int L = T::L > 0 ? T::L : 1;
+    float w0[L][3], w1[L][3];
+    frame_identity(R, p);
+#pragma unroll
+    for (int c = 0; c < T::L; ++c) {
+        if (T::cap_link[c] < 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                w0[c][k] = T::cap_p0[c][k];
+                w1[c][k] = T::cap_p1[c][k];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+        fk_joint(R, p, rb.pris(j), q[j]);
+#pragma unroll
+        for (int c = 0; c < T::L; ++c) {
+            if (T::cap_link[c] == j) {
+                xform_point(R, p, T::cap_p0[c][0], T::cap_p0[c][1], T::cap_p0[c][2], w0[c]);
+                xform_point(R, p, T::cap_p1[c][0], T::cap_p1[c][1], T::cap_p1[c][2], w1[c]);
+            }
+        }
+    }
+    CollOut r;
+    r.min_self = INFINITY;
+    if (do_self) {
+#pragma unroll
+        for (int pi = 0; pi < T::P; ++pi) {
+            const int a = T::pair_a[pi], b = T::pair_b[pi];
+            const float v = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]) - (T::cap_r[a] + T::cap_r[b]);
+            r.min_self = v < r.min_self ? v : r.min_self;
+        }
+    }
+    r.self_hit = r.min_self < 0.f;
+    r.min_env = INFINITY;
+    r.env_hit = 0;
+    if (do_env) {
+        for (int o = 0; o < co.nobs; ++o) {
+            float me = INFINITY;
+#pragma unroll
+            for (int c = 0; c < T::L; ++c) {
+                const float v = seg_box_dist(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]) - T::cap_r[c];
+                me = v < me ? v : me;
+            }
+            r.env_hit |= (me < 0.f);
+            r.min_env = me < r.min_env ? me : r.min_env;
+        }
+    }
+    return r;
 }
 
 __device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int tid, int c, float (&w0)[3], float (&w1)[3]) {
@@ -290,6 +358,18 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
     return r;
 }
 
+// capsule FK + distances for one row; leaves the LAST LINK frame in R, p (the caller applies F_ee for the metrics)
+template <class RB>
+__device__ __forceinline__ CollOut collide_row(const RB& rb, const CollK& co, const float (&q)[RB::D], float* lds, int tid,
+                                               float (&R)[9], float (&p)[3], bool do_self, bool do_env) {
+    if constexpr (RB::kStatic) {
+        return collide_static<RB>(rb, co, q, R, p, do_self, do_env);
+    } else {
+        fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
+        return collide_from_lds(co, lds, tid, do_self, do_env);
+    }
+}
+
 template <int D>
 __device__ __forceinline__ int jlim_hit(const CollK& co, const float (&q)[D]) {
     int jl = 0;
@@ -319,11 +399,13 @@ __device__ __forceinline__ void load_target(const float* __restrict__ target, in
     quat_to_mat(t[3], t[4], t[5], t[6], Rt);
 }
 
-template <int D, bool COLL>
-__global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+template <class RB, bool COLL>
+__global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
     extern __shared__ float lds[];
+    constexpr int D = RB::D;
+    const RB rb{ch, co};
     const int tid = threadIdx.x;
     const size_t row = (size_t)blockIdx.x * kBlock + tid;
     if (row >= (size_t)prm.n) return;
@@ -333,9 +415,9 @@ __global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const
 
     for (int it = 0; it < prm.n_steps; ++it) {
         float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
-        fk_ee_axes<D>(ch, q, R, p, ax, og);
+        fk_ee_axes<RB>(rb, q, R, p, ax, og);
         pose_error(Rt, tt, R, p, e);
-        jacobian_from_axes<D>(ch, p, ax, og, J);
+        jacobian_from_axes<RB>(rb, p, ax, og, J);
         lm_dual_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
         if (it == prm.n_steps - 1) {
             if (out.J_out) {
@@ -352,29 +434,28 @@ __global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) q[j] += delta[j];
-        if (prm.clamp) clamp_row<D>(ch, q);
+        if (prm.clamp) clamp_row<RB>(rb, q);
     }
     if (out.x_out) store_x<D>(out.x_out, row, q);
 
     if constexpr (COLL) {
         float R[9], p[3];
-        fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
-        fk_fixed(R, p, ch.Fee);
+        const bool do_self = out.self_mask || out.min_self || out.ext_cost;
+        const bool do_env = out.env_mask || out.min_env || out.ext_cost;
+        const CollOut c = collide_row<RB>(rb, co, q, lds, tid, R, p, do_self, do_env);
         if (out.pos_err_m || out.rot_err_rad) {
             float pe, re;
+            fk_fixed_ee(rb, R, p);
             pose_metrics(Rt, tt, R, p, pe, re);
             if (out.pos_err_m) out.pos_err_m[row] = pe;
             if (out.rot_err_rad) out.rot_err_rad[row] = re;
         }
-        const bool do_self = out.self_mask || out.min_self || out.ext_cost;
-        const bool do_env = out.env_mask || out.min_env || out.ext_cost;
-        const CollOut c = collide_from_lds(co, lds, tid, do_self, do_env);
         write_coll_outputs(row, c, jlim_hit<D>(co, q), out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost,
                            out.min_self, out.min_env);
     } else {
         if (out.pos_err_m || out.rot_err_rad) {
             float R[9], p[3], pe, re;
-            fk_ee<D>(ch, q, R, p);
+            fk_ee<RB>(rb, q, R, p);
             pose_metrics(Rt, tt, R, p, pe, re);
             if (out.pos_err_m) out.pos_err_m[row] = pe;
             if (out.rot_err_rad) out.rot_err_rad[row] = re;
@@ -382,12 +463,14 @@ __global__ __launch_bounds__(kBlock) void lm_fused_kernel(const ChainK ch, const
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void collision_kernel(const ChainK ch, const CollK co, int n,
+template <class RB>
+__global__ __launch_bounds__(kBlock, CPPF_WAVES_COLL) void collision_kernel(const ChainK ch, const CollK co, int n,
                                                            const float* __restrict__ x, uint8_t* self_mask,
                                                            uint8_t* env_mask, uint8_t* jlim_mask, float* ext_cost,
                                                            float* min_self, float* min_env) {
     extern __shared__ float lds[];
+    constexpr int D = RB::D;
+    const RB rb{ch, co};
     const int tid = threadIdx.x;
     const size_t row = (size_t)blockIdx.x * kBlock + tid;
     if (row >= (size_t)n) return;
@@ -396,8 +479,10 @@ __global__ __launch_bounds__(kBlock) void collision_kernel(const ChainK ch, cons
     // wave-uniform: which halves of the work the caller asked for (jlim-only calls skip FK altogether)
     const bool do_self = self_mask || min_self || ext_cost;
     const bool do_env = env_mask || min_env || ext_cost;
-    if (do_self || do_env) fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
-    const CollOut c = collide_from_lds(co, lds, tid, do_self, do_env);
+    CollOut c;
+    c.min_self = c.min_env = INFINITY;
+    c.self_hit = c.env_hit = 0;
+    if (do_self || do_env) c = collide_row<RB>(rb, co, q, lds, tid, R, p, do_self, do_env);
     write_coll_outputs(row, c, jlim_hit<D>(co, q), self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env);
 }
 
@@ -408,12 +493,14 @@ __global__ __launch_bounds__(kBlock) void distances_kernel(const ChainK ch, cons
                                                            float blo2, float bhi0, float bhi1, float bhi2,
                                                            float* __restrict__ dists) {
     extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const int tid = threadIdx.x;
     const size_t row = (size_t)blockIdx.x * kBlock + tid;
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3];
     load_x<D>(x, row, q);
-    fk_capsules_to_lds<D>(ch, co, q, lds, tid, R, p);
+    fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
     if constexpr (ENV) {
         const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
         for (int c = 0; c < co.ncaps; ++c) {
@@ -433,27 +520,31 @@ __global__ __launch_bounds__(kBlock) void distances_kernel(const ChainK ch, cons
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void fk_kernel(const ChainK ch, int n, const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock) void fk_kernel(const ChainK ch, const CollK co, int n, const float* __restrict__ x,
                                                     float* __restrict__ poses) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3], qt[4];
     load_x<D>(x, row, q);
-    fk_ee<D>(ch, q, R, p);
+    fk_ee<RB>(rb, q, R, p);
     mat_to_quat(R, qt);
     float* o = poses + row * 7;
     o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = qt[0], o[4] = qt[1], o[5] = qt[2], o[6] = qt[3];
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void jacobian_kernel(const ChainK ch, int n, const float* __restrict__ x,
-                                                          float* __restrict__ Jout) {
+__global__ __launch_bounds__(kBlock) void jacobian_kernel(const ChainK ch, const CollK co, int n,
+                                                          const float* __restrict__ x, float* __restrict__ Jout) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3], ax[D][3], og[D][3], J[6][D];
     load_x<D>(x, row, q);
-    fk_ee_axes<D>(ch, q, R, p, ax, og);
-    jacobian_from_axes<D>(ch, p, ax, og, J);
+    fk_ee_axes<RB>(rb, q, R, p, ax, og);
+    jacobian_from_axes<RB>(rb, p, ax, og, J);
     float* Jo = Jout + row * 6 * D;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -462,15 +553,18 @@ __global__ __launch_bounds__(kBlock) void jacobian_kernel(const ChainK ch, int n
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void pose_errors_kernel(const ChainK ch, int n, int W, const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock) void pose_errors_kernel(const ChainK ch, const CollK co, int n, int W,
+                                                             const float* __restrict__ x,
                                                              const float* __restrict__ target, float* __restrict__ e_out,
                                                              float* __restrict__ cur_out) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3], Rt[9], tt[3], e[6];
     load_x<D>(x, row, q);
     load_target(target, (int)(row % (size_t)W), Rt, tt);
-    fk_ee<D>(ch, q, R, p);
+    fk_ee<RB>(rb, q, R, p);
     pose_error(Rt, tt, R, p, e);
     if (e_out) {
 #pragma unroll
@@ -485,15 +579,18 @@ __global__ __launch_bounds__(kBlock) void pose_errors_kernel(const ChainK ch, in
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void pose_metrics_kernel(const ChainK ch, int n, int W, const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock) void pose_metrics_kernel(const ChainK ch, const CollK co, int n, int W,
+                                                              const float* __restrict__ x,
                                                               const float* __restrict__ target,
                                                               float* __restrict__ pos_err, float* __restrict__ rot_err) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (size_t)n) return;
     float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
     load_x<D>(x, row, q);
     load_target(target, (int)(row % (size_t)W), Rt, tt);
-    fk_ee<D>(ch, q, R, p);
+    fk_ee<RB>(rb, q, R, p);
     pose_metrics(Rt, tt, R, p, pe, re);
     if (pos_err) pos_err[row] = pe;
     if (rot_err) rot_err[row] = re;
@@ -508,8 +605,11 @@ __global__ __launch_bounds__(kBlock) void clamp_kernel(const ChainK ch, size_t t
 
 // one wavefront per seed: lanes stride over the seed's W waypoints, then a 64-lane butterfly max
 template <int D>
-__global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, int S, int W, const float* __restrict__ x,
+__global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, const CollK co, int S, int W,
+                                                           const float* __restrict__ x,
                                                            const float* __restrict__ target, float* __restrict__ out) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
     const int s = blockIdx.x;
     if (s >= S) return;
     const float rad2deg = 57.29577951308232087680f;
@@ -519,7 +619,7 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, int 
         float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
         load_x<D>(x, row, q);
         load_target(target, w, Rt, tt);
-        fk_ee<D>(ch, q, R, p);
+        fk_ee<RB>(rb, q, R, p);
         pose_metrics(Rt, tt, R, p, pe, re);
         mp = fmaxf(mp, 100.f * pe);
         mr = fmaxf(mr, rad2deg * re);
@@ -529,7 +629,7 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, int 
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const float dq = qn[j] - q[j];
-                if ((ch.pris_mask >> j) & 1u)
+                if (rb.pris(j))
                     mpri = fmaxf(mpri, fabsf(100.f * dq));
                 else
                     mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
@@ -578,12 +678,68 @@ struct cppf_robot {
     ChainK chain;
     CollK coll;
     int device;
-    size_t lds_bytes;  // capsule end points: 6 floats per capsule per lane
+    int static_id;     // index into robots_gen.h when the description equals a generated table, else -1
+    size_t lds_bytes;  // generic path only: capsule end points, 6 floats per capsule per lane
 };
 
 namespace {
 
-// dispatch on ndof: the kernels are instantiated for the degrees of freedom of the shipped robots
+// does a description equal a generated compile-time table exactly?
+template <class T>
+bool desc_matches(const cppf_robot_desc& d) {
+    if (d.ndof != T::D || d.n_capsules != T::L || d.n_pairs != T::P) return false;
+    uint32_t pm = 0;
+    for (int j = 0; j < T::D; ++j) {
+        if (d.jtype[j] == CPPF_JOINT_PRISMATIC) pm |= 1u << j;
+        for (int k = 0; k < 12; ++k)
+            if (d.F[j][k] != T::F[j][k]) return false;
+        if (d.lo[j] != T::lo[j] || d.hi[j] != T::hi[j]) return false;
+    }
+    if (pm != T::pris_mask) return false;
+    for (int k = 0; k < 12; ++k)
+        if (d.F_ee[k] != T::Fee[k]) return false;
+    for (int c = 0; c < T::L; ++c) {
+        if (d.cap_link[c] != T::cap_link[c] || d.cap_r[c] != T::cap_r[c]) return false;
+        for (int k = 0; k < 3; ++k)
+            if (d.cap_p0[c][k] != T::cap_p0[c][k] || d.cap_p1[c][k] != T::cap_p1[c][k]) return false;
+    }
+    for (int p = 0; p < T::P; ++p)
+        if (d.pairs[p][0] != T::pair_a[p] || d.pairs[p][1] != T::pair_b[p]) return false;
+    return true;
+}
+
+int find_static_robot(const cppf_robot_desc& d) {
+#define CPPF_MATCH(idx, Type) \
+    if (desc_matches<Type>(d)) return idx;
+    CPPF_FOR_EACH_STATIC_ROBOT(CPPF_MATCH)
+#undef CPPF_MATCH
+    return -1;
+}
+
+// dispatch of the heavy kernels on the robot: a generated table if the description matched one, else the generic
+// instantiation for its ndof.  Inside __VA_ARGS__ the accessor type is `RB`.
+#define CPPF_STATIC_CASE(idx, Type)       \
+    case idx: {                           \
+        using RB = StaRobot<Type>;        \
+        CPPF_BODY;                        \
+    } break;
+
+#define CPPF_DISPATCH_RB(robot)                                                                                       \
+    if ((robot)->static_id >= 0 && !g_force_generic) {                                                                \
+        switch ((robot)->static_id) { CPPF_FOR_EACH_STATIC_ROBOT(CPPF_STATIC_CASE) default: break; }                  \
+    } else {                                                                                                          \
+        switch ((robot)->desc.ndof) {                                                                                 \
+            case 6: { using RB = DynRobot<6>; CPPF_BODY; } break;                                                     \
+            case 7: { using RB = DynRobot<7>; CPPF_BODY; } break;                                                     \
+            case 8: { using RB = DynRobot<8>; CPPF_BODY; } break;                                                     \
+            case 12: { using RB = DynRobot<12>; CPPF_BODY; } break;                                                   \
+            default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {6, 7, 8, 12}");  \
+        }                                                                                                             \
+    }
+
+bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
+
+// dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
     switch (d) {                                                                                              \
         case 6: { constexpr int D = 6; __VA_ARGS__; } break;                                                  \
@@ -683,6 +839,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.pair_b[p] = (uint8_t)desc->pairs[p][1];
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
+    rb->static_id = find_static_robot(*desc);
     *out = rb;
     return CPPF_OK;
 }
@@ -690,6 +847,10 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
 void cppf_robot_destroy(cppf_robot* robot) { delete robot; }
 
 int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
+
+int cppf_robot_specialization(const cppf_robot* robot) { return robot ? robot->static_id : CPPF_ERR_INVALID; }
+
+void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 
 int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
     CPPF_REQUIRE(robot, "robot handle is NULL");
@@ -731,7 +892,7 @@ int cppf_forward_kinematics(const cppf_robot* robot, const float* x, int n, floa
     CPPF_REQUIRE(x && poses, "x / poses is NULL");
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((fk_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                                        robot->chain, n, x, poses));
+                                                        robot->chain, robot->coll, n, x, poses));
     return check_launch(robot);
 }
 
@@ -742,7 +903,7 @@ int cppf_jacobian(const cppf_robot* robot, const float* x, int n, float* J, void
     CPPF_REQUIRE(x && J, "x / J is NULL");
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((jacobian_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                                        robot->chain, n, x, J));
+                                                        robot->chain, robot->coll, n, x, J));
     return check_launch(robot);
 }
 
@@ -756,7 +917,7 @@ int cppf_pose_errors(const cppf_robot* robot, const float* x, const float* targe
     CPPF_REQUIRE(x && target, "x / target is NULL");
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((pose_errors_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                                        robot->chain, (int)n, W, x, target, e, current_poses));
+                                                        robot->chain, robot->coll, (int)n, W, x, target, e, current_poses));
     return check_launch(robot);
 }
 
@@ -792,14 +953,19 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     prm.W = W;
     const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self || out->min_env;
     hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
     if (coll) {
-        CPPF_DISPATCH_D(robot->desc.ndof,
-                        hipLaunchKernelGGL((lm_fused_kernel<D, true>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
-                                           st, robot->chain, robot->coll, prm, x_in, target, *out));
+#define CPPF_BODY                                                                                                    \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+                       prm, x_in, target, *out)
+        CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
     } else {
-        CPPF_DISPATCH_D(robot->desc.ndof,
-                        hipLaunchKernelGGL((lm_fused_kernel<D, false>), dim3(grid_for(n)), dim3(kBlock), 0, st,
-                                           robot->chain, robot->coll, prm, x_in, target, *out));
+#define CPPF_BODY                                                                                                    \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
+                       prm, x_in, target, *out)
+        CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
     }
     return check_launch(robot);
 }
@@ -813,10 +979,12 @@ int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, 
     CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
     CPPF_REQUIRE(q, "q is NULL");
     hipStream_t st = (hipStream_t)stream;
-    CPPF_DISPATCH_D(robot->desc.ndof,
-                    hipLaunchKernelGGL((collision_kernel<D>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st,
-                                       robot->chain, robot->coll, (int)n, q, self_mask, env_mask, jlim_mask, ext_cost,
-                                       min_self, min_env));
+    const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
+#define CPPF_BODY                                                                                                     \
+    hipLaunchKernelGGL((collision_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, (int)n, \
+                       q, self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env)
+    CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
     return check_launch(robot);
 }
 
@@ -866,7 +1034,7 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof,
                     hipLaunchKernelGGL((pose_metrics_kernel<D>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain,
-                                       (int)n, W, x, target, pos_err_m, rot_err_rad));
+                                       robot->coll, (int)n, W, x, target, pos_err_m, rot_err_rad));
     return check_launch(robot);
 }
 
@@ -878,7 +1046,7 @@ int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* tar
     CPPF_REQUIRE(x && target && out, "x / target / out is NULL");
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((seed_validity_kernel<D>), dim3(S), dim3(64), 0, st,
-                                                        robot->chain, S, W, x, target, out));
+                                                        robot->chain, robot->coll, S, W, x, target, out));
     return check_launch(robot);
 }
 

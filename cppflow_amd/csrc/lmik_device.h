@@ -49,6 +49,59 @@ struct LmK {
     int32_t n, W;
 };
 
+// ---- multiply / fma by a chain constant --------------------------------------------------------------------------------------
+// In the robot-specialised instantiations every chain constant is a literal after unrolling; 0 and +-1 are peeled off
+// here.  Each shortcut returns exactly what the general fmaf would (x*1 and acc + x*1 round once either way; x*0 and
+// acc + x*0 are exact for finite x), so the specialised and the generic kernels agree bit for bit (up to the sign of a zero).
+__device__ __forceinline__ float cmul(float x, float c) {
+    if (__builtin_constant_p(c)) {
+        if (c == 0.f) return 0.f;
+        if (c == 1.f) return x;
+        if (c == -1.f) return -x;
+    }
+    return x * c;
+}
+
+__device__ __forceinline__ float cfma(float x, float c, float acc) {
+    if (__builtin_constant_p(c)) {
+        if (c == 0.f) return acc;
+        if (__builtin_constant_p(acc) && acc == 0.f) return cmul(x, c);
+        if (c == 1.f) return acc + x;
+        if (c == -1.f) return acc - x;
+    }
+    return CPPF_FMA(x, c, acc);
+}
+
+// ---- robot accessors ------------------------------------------------------------------------------------------------------------
+// DynRobot<D>: constants come from the kernel-argument structs (scalar loads).  StaRobot<T>: constants are the
+// generated compile-time tables of robots_gen.h; obstacles and the joint-limit padding stay run-time (CollK) in both.
+template <int D_>
+struct DynRobot {
+    static constexpr int D = D_;
+    static constexpr bool kStatic = false;
+    const ChainK& ch;
+    const CollK& co;
+    __device__ __forceinline__ float F(int j, int k) const { return ch.F[j][k]; }
+    __device__ __forceinline__ float Fee(int k) const { return ch.Fee[k]; }
+    __device__ __forceinline__ bool pris(int j) const { return (ch.pris_mask >> j) & 1u; }
+    __device__ __forceinline__ float lo(int j) const { return ch.lo[j]; }
+    __device__ __forceinline__ float hi(int j) const { return ch.hi[j]; }
+};
+
+template <class T>
+struct StaRobot {
+    using Table = T;
+    static constexpr int D = T::D;
+    static constexpr bool kStatic = true;
+    const ChainK& ch;
+    const CollK& co;
+    __device__ __forceinline__ float F(int j, int k) const { return T::F[j][k]; }
+    __device__ __forceinline__ float Fee(int k) const { return T::Fee[k]; }
+    __device__ __forceinline__ bool pris(int j) const { return (T::pris_mask >> j) & 1u; }
+    __device__ __forceinline__ float lo(int j) const { return T::lo[j]; }
+    __device__ __forceinline__ float hi(int j) const { return T::hi[j]; }
+};
+
 // ---- sin / cos ------------------------------------------------------------------------------------------------------------
 // Cody-Waite reduction by pi/2 in three exact pieces + Cephes single-precision minimax polynomials on [-pi/4, pi/4].
 // ~22 VALU instructions, no slow path: joint angles are bounded by the joint limits (|q| < 2^10 is ample).
@@ -74,19 +127,35 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
 
 // ---- canonical FK steps ---------------------------------------------------------------------------------------------------
 // frame <- frame * F      (F = 12 wave-uniform floats: R row-major, t)
-__device__ __forceinline__ void fk_fixed(float (&R)[9], float (&p)[3], const float* __restrict__ F) {
+__device__ __forceinline__ void fk_fixed(float (&R)[9], float (&p)[3], const float (&F)[12]) {
     float A[9], np[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float r0 = R[3 * i], r1 = R[3 * i + 1], r2 = R[3 * i + 2];
-        np[i] = CPPF_FMA(r2, F[11], CPPF_FMA(r1, F[10], CPPF_FMA(r0, F[9], p[i])));
+        np[i] = cfma(r2, F[11], cfma(r1, F[10], cfma(r0, F[9], p[i])));
 #pragma unroll
-        for (int c = 0; c < 3; ++c) A[3 * i + c] = CPPF_FMA(r2, F[6 + c], CPPF_FMA(r1, F[3 + c], r0 * F[c]));
+        for (int c = 0; c < 3; ++c) A[3 * i + c] = cfma(r2, F[6 + c], cfma(r1, F[3 + c], cmul(r0, F[c])));
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = A[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) p[k] = np[k];
+}
+
+template <class RB>
+__device__ __forceinline__ void fk_fixed_joint(const RB& rb, int j, float (&R)[9], float (&p)[3]) {
+    float F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) F[k] = rb.F(j, k);
+    fk_fixed(R, p, F);
+}
+
+template <class RB>
+__device__ __forceinline__ void fk_fixed_ee(const RB& rb, float (&R)[9], float (&p)[3]) {
+    float F[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) F[k] = rb.Fee(k);
+    fk_fixed(R, p, F);
 }
 
 // frame <- frame * M_z(q): rotation about (revolute) or translation along (prismatic) the local z axis
@@ -115,14 +184,15 @@ __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, fl
     return CPPF_FMA(a2, b2, CPPF_FMA(a1, b1, a0 * b0));
 }
 
-__device__ __forceinline__ float clamp01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+// clamps as one v_med3_f32: for lo <= hi and a non-NaN x the median of (x, lo, hi) IS the clamp, value for value
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1.f); }
 
 // world point of a link-frame constant point (canonical order shared with the oracle)
-__device__ __forceinline__ void xform_point(const float (&R)[9], const float (&p)[3], const float* __restrict__ c,
+__device__ __forceinline__ void xform_point(const float (&R)[9], const float (&p)[3], float c0, float c1, float c2,
                                             float (&w)[3]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        w[i] = CPPF_FMA(R[3 * i + 2], c[2], CPPF_FMA(R[3 * i + 1], c[1], CPPF_FMA(R[3 * i], c[0], p[i])));
+    for (int i = 0; i < 3; ++i) w[i] = cfma(R[3 * i + 2], c2, cfma(R[3 * i + 1], c1, cfma(R[3 * i], c0, p[i])));
 }
 
 // ---- rotation matrix -> quaternion (w first; branch on the largest of w,x,y,z so the divisor is >= 1) -----------------------
@@ -178,14 +248,15 @@ __device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float 
     const float c = dot3(d1[0], d1[1], d1[2], rr[0], rr[1], rr[2]);
     const float b = dot3(d1[0], d1[1], d1[2], d2[0], d2[1], d2[2]);
     const float denom = CPPF_FMA(a, e, -(b * b));
+    const float inv_a = 1.f / a, inv_e = 1.f / e;  // one IEEE division per capsule: shared by every pair it is in
     float s = denom > 0.f ? clamp01(CPPF_FMA(b, f, -(c * e)) / denom) : 0.f;
-    float t = CPPF_FMA(b, s, f) / e;
+    float t = CPPF_FMA(b, s, f) * inv_e;
     if (t < 0.f) {
         t = 0.f;
-        s = clamp01(-c / a);
+        s = clamp01(-c * inv_a);
     } else if (t > 1.f) {
         t = 1.f;
-        s = clamp01((b - c) / a);
+        s = clamp01((b - c) * inv_a);
     }
     float df[3];
 #pragma unroll
@@ -199,8 +270,7 @@ __device__ __forceinline__ float seg_box_g(const float (&P)[3], const float (&D)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float x = CPPF_FMA(D[i], t, P[i]);
-        const float cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
-        ex[i] = x - cl;
+        ex[i] = x - clampf(x, lo[i], hi[i]);
     }
     return dot3(D[0], D[1], D[2], ex[0], ex[1], ex[2]);
 }
@@ -247,8 +317,7 @@ __device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float 
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float x = CPPF_FMA(D[i], t, P0[i]);
-        const float cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
-        ex[i] = x - cl;
+        ex[i] = x - clampf(x, lo[i], hi[i]);
     }
     return __builtin_sqrtf(dot3(ex[0], ex[1], ex[2], ex[0], ex[1], ex[2]));
 }

@@ -93,6 +93,11 @@ const char* cppf_last_error(void);
 int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out);
 void cppf_robot_destroy(cppf_robot* robot);
 int cppf_robot_ndof(const cppf_robot* robot);
+/* >= 0: index of the robot-specialised kernel set (generated tables, csrc/robots_gen.h) this handle runs; -1: the generic
+ * kernels, driven by the description in the kernel-argument segment. */
+int cppf_robot_specialization(const cppf_robot* robot);
+/* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
+void cppf_debug_force_generic(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
  * cuboids [O,6] = (-sx/2,-sy/2,-sz/2, sx/2,sy/2,sz/2); Rt [O,12] = rotation row-major (9) then translation (3), HOST

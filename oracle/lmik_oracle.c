@@ -644,14 +644,15 @@ static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const R
     }
     const REAL a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, rr), c = dot3(d1, rr), b = dot3(d1, d2);
     const REAL denom = FMA(a, e, -(b * b));
+    const REAL inv_a = (REAL)1 / a, inv_e = (REAL)1 / e; /* one division per capsule (shared by all its pairs) */
     REAL s = denom > 0 ? clamp01(FMA(b, f, -(c * e)) / denom) : (REAL)0;
-    REAL t = FMA(b, s, f) / e;
+    REAL t = FMA(b, s, f) * inv_e;
     if (t < 0) {
         t = 0;
-        s = clamp01(-c / a);
+        s = clamp01(-c * inv_a);
     } else if (t > 1) {
         t = 1;
-        s = clamp01((b - c) / a);
+        s = clamp01((b - c) * inv_a);
     }
     REAL df[3];
     for (int i = 0; i < 3; ++i) df[i] = FMA(d1[i], s, P1[i]) - FMA(d2[i], t, P2[i]);

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on one MI355X (developer tool): times the fused launch for a grid of (robot, K, collide)
+with HIP events, interleaved rounds in one process (cdna guide rule 24).  Usage: python scripts/kbench.py [--rounds 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_inputs  # noqa: E402
+from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays  # noqa: E402
+from cppflow_amd.robots import get_robot  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--robots", default="panda,fetch,chain12")
+    ap.add_argument("--seeds", type=int, default=1024)
+    ap.add_argument("--waypoints", type=int, default=256)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cases = []
+    for name in args.robots.split(","):
+        rb = get_robot(name)
+        obs = obstacle_arrays(PANDA_2CUBES_OBSTACLES)
+        rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+        rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+        x0, target = make_inputs(rb, args.seeds, args.waypoints, dev, 0)
+        xo = torch.empty_like(x0)
+        packed = torch.empty(rb.PACKED_BYTES_PER_ROW * x0.shape[0], dtype=torch.uint8, device=dev)
+        q3 = x0.reshape(args.seeds, args.waypoints, -1)
+        for K in (1, 10, 20):
+            for coll in (False, True):
+                cases.append((f"{name} lm K={K} coll={int(coll)}", (lambda rb=rb, x0=x0, t=target, xo=xo, pk=packed, K=K, coll=coll:
+                              rb.lm_pose_steps(x0, t, 1e-6, 3.5, 0.35, n_steps=K, x_out=xo, packed_out=pk if coll else None, want_errors=not coll)), K))
+        cases.append((f"{name} collision_masks", (lambda rb=rb, q3=q3: rb.collision_masks(q3)), 0))
+        cases.append((f"{name} fk", (lambda rb=rb, x0=x0: rb.forward_kinematics(x0)), 0))
+    times = {c[0]: [] for c in cases}
+    for fn in [c[1] for c in cases]:
+        fn()
+    torch.cuda.synchronize()
+    for _ in range(args.rounds):
+        for name, fn, _K in cases:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            times[name].append(a.elapsed_time(b) / args.reps * 1e3)
+    n = args.seeds * args.waypoints
+    for name, _fn, K in cases:
+        t = np.array(times[name])
+        extra = f"  {n * K / np.median(t) * 1e6 / 1e9:8.2f} G row-iter/s" if K else ""
+        print(f"{name:34s} median {np.median(t):9.1f} us  min {t.min():9.1f} us{extra}")
+
+
+if __name__ == "__main__":
+    main()

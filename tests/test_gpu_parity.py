@@ -221,3 +221,33 @@ def test_contract_violations_raise(robots):
     with pytest.raises(AssertionError):
         rb.set_obstacles([cuboid], [T])
     rb.set_obstacles([], [])
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_specialised_kernels_equal_generic_kernels(robots, name):
+    """The robot-specialised instantiations (compile-time chain tables, capsules in registers) and the generic ones
+    (kernel-argument constants, capsules in LDS) follow the same canonical operation order: identical outputs."""
+    from cppflow_amd import _hip
+
+    rb = robots[name]
+    assert _hip.lib().cppf_robot_specialization(rb._handle(torch.device("cuda:0"))) >= 0
+    obs = _obstacles_for(name)
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    S, W = 8, 64
+    x0, target = H.lm_problem(name, S, W, seed=11)
+    kw = dict(n_steps=4, want_errors=True, want_collisions=True, want_min_dists=True, return_residual=True, **LM)
+    a = rb.lm_pose_steps(dev(x0), dev(target), **kw)
+    ca = rb.collision_masks(dev(x0).reshape(S, W, -1), want_min_dists=True)
+    try:
+        _hip.lib().cppf_debug_force_generic(1)
+        b = rb.lm_pose_steps(dev(x0), dev(target), **kw)
+        cb = rb.collision_masks(dev(x0).reshape(S, W, -1), want_min_dists=True)
+    finally:
+        _hip.lib().cppf_debug_force_generic(0)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k in ca:
+        assert torch.equal(ca[k], cb[k]), k
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
