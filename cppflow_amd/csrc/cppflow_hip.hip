@@ -27,7 +27,10 @@ using namespace cppf;
 
 namespace {
 
-constexpr int kBlock = 256;
+#ifndef CPPF_BLOCK
+#define CPPF_BLOCK 256
+#endif
+constexpr int kBlock = CPPF_BLOCK;
 
 // minimum resident waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
 #ifndef CPPF_WAVES_LM
@@ -157,22 +160,16 @@ __device__ __forceinline__ void pose_metrics(const float (&Rt)[9], const float (
     rot_err = fmaxf(theta, 8.94427191e-4f);
 }
 
-// one damped Gauss-Newton update in dual form; J and e are scaled in place (optimization.py:77-80)
+// One damped Gauss-Newton update in dual form.  With S = diag(a_rot x3, a_pos x3) the reference scales J and e in place
+// (optimization.py:77-80) and solves (Js^T Js + lambda I) delta = Js^T es; here the scaling is folded into the 6x6 system:
+//     A = S (J J^T) S + lambda I,   A y = S e,   delta = J^T (S y)
+// (21 + 6 + 6 multiplies instead of 6 d + 6), identical in exact arithmetic.  J and e are left UNscaled.
 template <int D>
-__device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], float lambda, float a_pos, float a_rot,
-                                              float (&delta)[D]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        e[i] *= a_rot;
-        e[3 + i] *= a_pos;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            J[i][j] *= a_rot;
-            J[3 + i][j] *= a_pos;
-        }
-    }
-    // A = J J^T + lambda I (upper triangle), Cholesky A = L L^T with reciprocal pivots, pivot floor lambda
-    // (every exact pivot of A is >= lambda_min(A) >= lambda, so the floor only acts on rounding noise)
+__device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
+                                              float a_rot, float (&delta)[D]) {
+    const float srr = a_rot * a_rot, srp = a_rot * a_pos, spp = a_pos * a_pos;
+    // Cholesky A = L L^T with reciprocal pivots and pivot floor lambda (every exact pivot of A is >= lambda_min(A) >=
+    // lambda, so the floor only acts on rounding noise)
     float L[6][6], inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -181,6 +178,7 @@ __device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], f
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
+            s *= (i < 3 ? (j < 3 ? srr : srp) : (j < 3 ? srp : spp));
             if (i == j) s += lambda;
 #pragma unroll
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
@@ -195,7 +193,7 @@ __device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], f
     float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float s = e[i];
+        float s = e[i] * (i < 3 ? a_rot : a_pos);
 #pragma unroll
         for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
         y[i] = s * inv[i];
@@ -207,6 +205,8 @@ __device__ __forceinline__ void lm_dual_solve(float (&J)[6][D], float (&e)[6], f
         for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
         y[i] = s * inv[i];
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] *= (i < 3 ? a_rot : a_pos);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         float s = 0.f;
@@ -420,16 +420,17 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
         jacobian_from_axes<RB>(rb, p, ax, og, J);
         lm_dual_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
         if (it == prm.n_steps - 1) {
+            // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
             if (out.J_out) {
                 float* Jo = out.J_out + row * 6 * D;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j];
+                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
             }
             if (out.e_out) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i];
+                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
             }
         }
 #pragma unroll

@@ -165,9 +165,10 @@ __device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool pris
         sincos_cw(q, s, c);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+            // a0, a1 are literals for the first joint of a specialised chain (R = F_0): cmul / cfma fold the 0 / +-1 cases
             const float a0 = R[3 * i], a1 = R[3 * i + 1];
-            R[3 * i] = CPPF_FMA(s, a1, c * a0);
-            R[3 * i + 1] = CPPF_FMA(c, a1, -(s * a0));
+            R[3 * i] = cfma(s, a1, cmul(c, a0));
+            R[3 * i + 1] = cfma(c, a1, -cmul(s, a0));
         }
     } else {
 #pragma unroll

@@ -1,0 +1,66 @@
+"""Seed sharding across the GPUs of one node: one process per GPU, rank g owns a contiguous slab of
+seeds, the robot / target path / obstacles are replicated, and ONE all-gather of the packed per-row outputs
+(`Robot.PACKED_BYTES_PER_ROW` bytes per (seed, waypoint): search cost, pose errors, the three masks) gives every rank
+the `[S_total, W]` cost and mask matrices `dp_search` consumes (cppflow/search.py:146-151).
+
+The collective is `torch.distributed.all_gather_into_tensor` -- RCCL over xGMI with the "nccl" backend on MI355X, gloo
+on CPU in the unit tests.  Messages are small (15 B per row: 3.9 MB per rank at 1024 x 256), so the collective is
+latency-bound: it is issued once per planning call, after the last fused step, on one contiguous buffer.
+"""
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+PACKED_BYTES_PER_ROW = 15
+
+
+def seed_shard(n_seeds_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[begin, end) of the seeds rank owns: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_seeds_total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+@dataclass
+class GatheredSeedOutputs:
+    ext_cost: torch.Tensor  # float32 [S_total, W]
+    pos_err_m: torch.Tensor  # float32 [S_total, W]
+    rot_err_rad: torch.Tensor  # float32 [S_total, W]
+    self_mask: torch.Tensor  # bool [S_total, W]
+    env_mask: torch.Tensor  # bool [S_total, W]
+    jlim_mask: torch.Tensor  # bool [S_total, W]
+
+
+def unpack_rows(packed: torch.Tensor, n: int):
+    """Views into one rank's packed buffer: (ext_cost, pos_err_m, rot_err_rad) float32 [n], 3 x uint8 [n]."""
+    assert packed.dtype == torch.uint8 and packed.numel() == PACKED_BYTES_PER_ROW * n
+    f = packed[: 12 * n].view(torch.float32)
+    m = packed[12 * n :]
+    return f[:n], f[n : 2 * n], f[2 * n :], m[:n], m[n : 2 * n], m[2 * n :]
+
+
+def allgather_seed_outputs(
+    packed: torch.Tensor, seeds_per_rank: int, W: int, group: Optional[dist.ProcessGroup] = None,
+    out: Optional[torch.Tensor] = None,
+) -> GatheredSeedOutputs:  # fmt: skip
+    """One all-gather of every rank's packed buffer (equal shard sizes) -> the per-seed matrices over ALL seeds."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n = seeds_per_rank * W
+    assert packed.numel() == PACKED_BYTES_PER_ROW * n
+    if world == 1:
+        gathered = packed.view(1, -1)
+    else:
+        if out is None:
+            out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
+        dist.all_gather_into_tensor(out, packed, group=group)
+        gathered = out.view(world, -1)
+    parts = [unpack_rows(gathered[r], n) for r in range(world)]
+
+    def cat(i, as_bool=False):
+        t = torch.cat([p[i].reshape(seeds_per_rank, W) for p in parts], dim=0)
+        return t.view(torch.bool) if as_bool else t
+
+    return GatheredSeedOutputs(cat(0), cat(1), cat(2), cat(3, True), cat(4, True), cat(5, True))

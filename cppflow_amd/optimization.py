@@ -1,0 +1,249 @@
+"""The LM optimiser surface of the reference (`cppflow/optimization.py`): dataclasses (`:26-57`), the batched pose-only
+step (`:61-92`), the loop (`:147-373`) and the entry point (`:376-426`).
+
+What runs where
+  * `levenberg_marquardt_only_pose` = ONE launch of the fused kernel with K = 1 and no clamp (x_new, and J / e scaled
+    exactly as the reference returns them when `return_residual=True`).
+  * `run_lm_alternating_loss` keeps the reference's Python control flow (termination rules, TL bookkeeping) around
+    launches of the fused kernel; the coupled "differencing" step (`levenberg_marquardt_full`, `:95-144`) is SURVEY.md
+    8(f) item 1 ("next") and is not built: where the reference would take it, `on_pose_valid` decides (default "stop").
+  * `run_lm_pose_refinement` is the batched form the MI355X path is built for: all S seeds x W waypoints, K fused
+    iterations, per-seed validity and collision masks / search cost in the same launch.
+"""
+
+import warnings
+from dataclasses import dataclass
+from time import time
+from typing import Dict, Optional
+
+import torch
+
+from cppflow_amd.config import ENV_COLLISIONS_IGNORED, SELF_COLLISIONS_IGNORED
+from cppflow_amd.data_types import Constraints, Problem
+from cppflow_amd.evaluation_utils import angular_changes
+from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, OptimizationParameters
+from cppflow_amd.optimization_utils import clamp_to_joint_limits, x_is_valid
+from cppflow_amd.utils import make_text_green_or_red
+
+
+@dataclass
+class OptimizationProblem:
+    problem: Problem
+    constraints: Constraints
+    seed: torch.Tensor
+    target_path: torch.Tensor
+    verbosity: int
+    parallel_count: int
+    results_df: Optional[Dict]
+
+    @property
+    def robot(self):
+        return self.problem.robot
+
+    @property
+    def n_timesteps(self) -> int:
+        return self.problem.n_timesteps
+
+
+@dataclass
+class OptimizationState:
+    x: torch.Tensor
+    n_steps: int
+    t0: float
+
+
+@dataclass
+class OptimizationResult:
+    x_opt: torch.Tensor
+    n_steps_taken: int
+    is_valid: bool
+    parallel_seed_idx: int
+
+
+def _unstacked_target(opt_problem: OptimizationProblem) -> torch.Tensor:
+    """The kernels index target[row % W]; the reference's stacked [k*W, 7] tensor is just W rows repeated."""
+    W = opt_problem.n_timesteps
+    t = opt_problem.target_path
+    return t if t.shape[0] == W else t[:W]
+
+
+def levenberg_marquardt_only_pose(
+    opt_problem: OptimizationProblem,
+    opt_state: OptimizationState,
+    opt_params: OptimizationParameters,
+    return_residual: bool = False,
+):
+    """One batched pose-only LM step: `x + (J^T J + lambda I)^-1 J^T e` with rows of J / e scaled by alpha_rotation
+    (rows 0:3) and alpha_position (rows 3:6).  Returns x_new, or (x_new, J [n,6,d], e [n,6,1]) -- J and e scaled, as the
+    reference returns them (cppflow/optimization.py:77-80, 90-92)."""
+    n, ndof = opt_state.x.shape
+    assert ndof == opt_problem.robot.ndof
+    assert opt_problem.target_path.shape[0] in (n, opt_problem.n_timesteps), "target_path must be [n,7] or [W,7]"
+    res = opt_problem.robot.lm_pose_steps(
+        opt_state.x,
+        _unstacked_target(opt_problem),
+        lm_lambda=opt_params.lm_lambda,
+        alpha_position=opt_params.alpha_position,
+        alpha_rotation=opt_params.alpha_rotation,
+        n_steps=1,
+        clamp=False,
+        return_residual=return_residual,
+    )
+    if return_residual:
+        return res["x"], res["J"], res["e"]
+    return res["x"]
+
+
+def levenberg_marquardt_full(*_args, **_kwargs):
+    raise NotImplementedError(
+        "the coupled differencing step (cppflow/optimization.py:95-144) is SURVEY.md 8(f) item 1 and is not built yet"
+    )
+
+
+def run_lm_alternating_loss(
+    opt_problem: OptimizationProblem,
+    opt_state: OptimizationState,
+    params_diff: OptimizationParameters,
+    params_pose: OptimizationParameters,
+    return_residuals: bool,
+    tmax_sec: Optional[float],
+    max_n_steps: Optional[int],
+    return_if_valid_after_n_steps: Optional[int],
+    convergence_threshold: float,
+    verbosity: int = 0,
+    save_images: bool = False,
+    results_df: Optional[Dict] = None,
+    on_pose_valid: str = "stop",
+    fused_steps: int = 1,
+):
+    """The reference's loop (cppflow/optimization.py:147-373) with its termination rules, driving fused launches.
+
+    Every iteration: { pose-only step ; clamp } (`fused_steps` of them per launch, 1 = the reference's cadence), then
+    `x_is_valid`.  When both pose flags are valid the reference switches to the differencing step; that step is not
+    built, so `on_pose_valid` = "stop" ends the loop there and "continue" keeps taking pose steps."""
+    assert not return_residuals and not save_images and results_df is None, "debug outputs are not supported"
+    assert on_pose_valid in ("stop", "continue")
+    if tmax_sec is None:
+        assert (max_n_steps is not None) and (return_if_valid_after_n_steps is not None)
+        assert return_if_valid_after_n_steps <= max_n_steps
+    if max_n_steps is None:
+        assert tmax_sec is not None
+        max_n_steps = 10**6
+    del params_diff
+    robot = opt_problem.robot
+    target = _unstacked_target(opt_problem)
+    printc = print if verbosity > 1 else (lambda *a, **k: None)
+
+    def calc_TL(qpath):
+        rev, _ = robot.split_configs_to_revolute_and_prismatic(qpath)
+        return angular_changes(rev).abs().sum().item()
+
+    last_valid, last_valid_idx, valid_seed_idx = None, -1, 0
+    pose_pos_valid, pose_rot_valid = True, False  # the reference's initial values (:218-219): lead with a pose step
+    t0 = time()
+    i = -1
+    for i in range(max_n_steps):
+        if pose_pos_valid and pose_rot_valid and on_pose_valid == "stop":
+            printc("  pose is valid; the differencing step is not built -- stopping")
+            break
+        printc(f"i: {i}  --> only pose")
+        res = robot.lm_pose_steps(
+            opt_state.x, target, params_pose.lm_lambda, params_pose.alpha_position, params_pose.alpha_rotation,
+            n_steps=fused_steps, clamp=True,
+        )  # fmt: skip
+        opt_state.x = res["x"]
+        opt_state.n_steps += fused_steps
+        printc(f"  tl: {calc_TL(opt_state.x)}")
+        x_sol, seed_idx, flags = x_is_valid(
+            opt_problem.problem, opt_problem.constraints, target, opt_state.x, opt_problem.parallel_count, verbosity=verbosity
+        )
+        pose_pos_valid, pose_rot_valid = flags[0], flags[1]
+        if x_sol is not None:
+            last_valid_idx, last_valid, valid_seed_idx = i, opt_state.x.clone(), seed_idx
+            printc(make_text_green_or_red("  x is valid, continuing", True))
+        if tmax_sec is not None and time() - t0 > tmax_sec:
+            if last_valid is not None:
+                opt_state.x = last_valid.clone()
+            break
+        if last_valid is not None and return_if_valid_after_n_steps is not None and i > return_if_valid_after_n_steps:
+            break
+    x_return = last_valid if last_valid is not None else opt_state.x
+    return OptimizationResult(
+        x_opt=x_return, n_steps_taken=max(i, 0), is_valid=last_valid is not None, parallel_seed_idx=valid_seed_idx
+    )
+
+
+def run_lm_optimization(
+    problem: Problem,
+    x_seed: torch.Tensor,
+    tmax_sec: Optional[float],
+    max_n_steps: int,
+    return_if_valid_after_n_steps: int,
+    convergence_threshold: float,
+    parallel_count: int = 1,
+    results_df: Optional[Dict] = None,
+    verbosity: int = 1,
+    on_pose_valid: str = "stop",
+) -> OptimizationResult:
+    """Optimise a trajectory (or `parallel_count` seeds at once): x_seed is [parallel_count * W, ndof]
+    (cppflow/optimization.py:376-426).  The target path is NOT stacked: rows index it modulo W."""
+    if SELF_COLLISIONS_IGNORED:
+        warnings.warn("robot-robot are collisions will be ignored during LM optimization")
+    if ENV_COLLISIONS_IGNORED:
+        warnings.warn("environment-robot collisions will be ignored during LM optimization")
+    assert problem.target_path.shape == (problem.n_timesteps, 7)
+    assert problem.n_timesteps * parallel_count == x_seed.shape[0]
+    assert x_seed.shape[1] == problem.robot.ndof
+    assert isinstance(max_n_steps, int), f"error: max_n_steps must be int, is {type(max_n_steps)}"
+    opt_problem = OptimizationProblem(
+        problem, problem.constraints, x_seed, problem.target_path, verbosity, parallel_count, results_df
+    )
+    opt_state = OptimizationState(x_seed.clone(), 0, time())
+    return run_lm_alternating_loss(
+        opt_problem, opt_state, ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, return_residuals=False, verbosity=verbosity,
+        tmax_sec=tmax_sec, max_n_steps=max_n_steps, return_if_valid_after_n_steps=return_if_valid_after_n_steps,
+        convergence_threshold=convergence_threshold, save_images=False, results_df=results_df, on_pose_valid=on_pose_valid,
+    )  # fmt: skip
+
+
+@dataclass
+class PoseRefinementResult:
+    x: torch.Tensor  # [S*W, d]
+    pos_err_m: torch.Tensor  # [S, W]
+    rot_err_rad: torch.Tensor  # [S, W]
+    self_mask: torch.Tensor  # bool [S, W]
+    env_mask: torch.Tensor  # bool [S, W]
+    jlim_mask: torch.Tensor  # bool [S, W]
+    ext_cost: torch.Tensor  # float [S, W]: 100*jlim + 1000*env + 1000*self (cppflow/search.py:146-150)
+    packed: torch.Tensor  # the uint8 buffer the six per-row outputs live in (what the all-gather ships)
+
+
+def run_lm_pose_refinement(
+    problem: Problem,
+    x_seeds: torch.Tensor,
+    n_steps: int,
+    params_pose: OptimizationParameters = ALT_LOSS_V2_1_POSE,
+    x_out: Optional[torch.Tensor] = None,
+    packed_out: Optional[torch.Tensor] = None,
+) -> PoseRefinementResult:
+    """All seeds x waypoints through `n_steps` fused { pose step ; clamp } iterations in ONE launch, with pose errors,
+    collision / joint-limit masks and the search cost of the result written to one packed buffer."""
+    from cppflow_amd.search import DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC, DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE
+
+    W = problem.n_timesteps
+    assert x_seeds.dim() == 2 and x_seeds.shape[0] % W == 0, tuple(x_seeds.shape)
+    S, n = x_seeds.shape[0] // W, x_seeds.shape[0]
+    robot = problem.robot
+    problem.bind_obstacles()
+    robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
+    if packed_out is None:
+        packed_out = torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=x_seeds.device)
+    r = robot.lm_pose_steps(
+        x_seeds, problem.target_path, params_pose.lm_lambda, params_pose.alpha_position, params_pose.alpha_rotation,
+        n_steps=n_steps, clamp=True, x_out=x_out, packed_out=packed_out,
+    )  # fmt: skip
+    return PoseRefinementResult(
+        x=r["x"], pos_err_m=r["pos_err_m"].view(S, W), rot_err_rad=r["rot_err_rad"].view(S, W),
+        self_mask=r["self_mask"].view(S, W).view(torch.bool), env_mask=r["env_mask"].view(S, W).view(torch.bool),
+        jlim_mask=r["jlim_mask"].view(S, W).view(torch.bool), ext_cost=r["ext_cost"].view(S, W), packed=packed_out,
+    )  # fmt: skip

@@ -1,0 +1,67 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard the seeds, each fills its packed per-row buffer (with the
+oracle standing in for the kernel, there being no GPU here) and ONE all-gather gives every rank all seeds' costs / masks /
+errors -- identical to the single-process result (sharding invariance: rows are independent)."""
+
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cppflow_amd.distributed import PACKED_BYTES_PER_ROW, allgather_seed_outputs, seed_shard, unpack_rows
+from tests import helpers as H
+
+S_TOTAL, W, K = 6, 16, 3
+
+
+def _fill_packed(name, x0, target, S):
+    """What cppf_lm_pose_steps writes into the packed buffer, computed by the oracle."""
+    o64, o32 = H.oracle64(name), H.oracle32(name)
+    tgt = H.stacked(target, S)
+    x = H.f32(o64.lm_steps(x0, tgt, K))
+    pe, re = o64.pose_metrics_exact(x, tgt)
+    lo, hi = H.box_corners([c for c, _ in H.PANDA_2CUBES], [T for _, T in H.PANDA_2CUBES])
+    ch = H.chain(name)
+    m = o32.masks(x, lo, hi, ch.lo, ch.hi)
+    n = S * W
+    packed = torch.zeros(PACKED_BYTES_PER_ROW * n, dtype=torch.uint8)
+    cost, p, r, sm, em, jm = unpack_rows(packed, n)
+    cost.copy_(torch.tensor(m["ext_cost"], dtype=torch.float32))
+    p.copy_(torch.tensor(pe, dtype=torch.float32))
+    r.copy_(torch.tensor(re, dtype=torch.float32))
+    sm.copy_(torch.tensor(m["self_mask"]))
+    em.copy_(torch.tensor(m["env_mask"]))
+    jm.copy_(torch.tensor(m["jlim_mask"]))
+    return packed
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x0, target = H.lm_problem("panda", S_TOTAL, W, seed=21)
+        b, e = seed_shard(S_TOTAL, rank, world)
+        packed = _fill_packed("panda", x0[b * W : e * W], target, e - b)
+        g = allgather_seed_outputs(packed, e - b, W)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cost=g.ext_cost.numpy(), pe=g.pos_err_m.numpy(),
+                 re=g.rot_err_rad.numpy(), sm=g.self_mask.numpy(), em=g.env_mask.numpy(), jm=g.jlim_mask.numpy())  # fmt: skip
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_allgather_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    x0, target = H.lm_problem("panda", S_TOTAL, W, seed=21)
+    full = _fill_packed("panda", x0, target, S_TOTAL)
+    cost, pe, re, sm, em, jm = (t.numpy().reshape(S_TOTAL, W) for t in unpack_rows(full, S_TOTAL * W))
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert np.array_equal(z["cost"], cost) and np.array_equal(z["pe"], pe) and np.array_equal(z["re"], re)
+        assert np.array_equal(z["sm"], sm.astype(bool)) and np.array_equal(z["em"], em.astype(bool))
+        assert np.array_equal(z["jm"], jm.astype(bool))
+    assert cost.max() >= 1000.0  # the case does contain collisions

@@ -1,0 +1,237 @@
+"""GPU tests of the reference-named Python surface (each call lands on the C ABI) and of the committed golden fixtures."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def robots():
+    from cppflow_amd.robots import get_robot
+
+    return {n: get_robot(n) for n in ("panda", "fetch", "fetch_arm", "chain12")}
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch", "fetch_arm", "chain12"])
+def test_golden_vectors(robots, name):
+    """tests/golden/lm_golden_<robot>.npz (fp64 oracle, reference operation order; made by tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, f"lm_golden_{name}.npz"))
+    rb = robots[name]
+    S, W, K = int(z["S"]), int(z["W"]), int(z["K"])
+    x0, target = dev(z["x0"]), dev(z["target"])
+    assert np.abs(host(rb.forward_kinematics(x0))[:, :3] - z["fk"][:, :3]).max() < 2e-6
+    e, _ = rb.pose_errors(x0, target)
+    assert np.abs(host(e)[:, :, 0] - z["e"]).max() < 1e-5
+    r1 = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=1, clamp=False, return_residual=True)
+    assert np.abs(host(r1["J"]) - z["J_scaled"]).max() < 1e-5
+    assert np.abs(host(r1["e"])[:, :, 0] - z["e_scaled"]).max() < 1e-5
+    ok = np.linalg.svd(z["J_scaled"], compute_uv=False)[:, -1] >= 1e-2
+    assert np.abs(host(r1["x"]) - z["x_step1"])[ok].max() < 5e-3
+    rK = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=K, want_errors=True)
+    conv = (z["pos_err_K"] < 1e-4) & (z["rot_err_K"] < 1.2e-3)
+    assert conv.mean() > 0.85
+    assert np.abs(host(rK["pos_err_m"]) - z["pos_err_K"])[conv].max() < 1e-5
+    assert np.abs(host(rK["rot_err_rad"]) - z["rot_err_K"])[conv].max() < 1e-5
+    # collision: distances within fp32 rounding of the fp64 golden values, masks bit-exact with the fp32 golden masks
+    q = dev(z["q_coll"])
+    assert np.abs(host(rb.self_collision_distances(q)) - z["self_dists"]).max() < 5e-6
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    ch = H.chain(name)
+    rb._jl_padding = (ch.lo.astype(np.float32), ch.hi.astype(np.float32))
+    for h in rb._handles.values():
+        rb._apply_jl_padding(h)
+    m = rb.collision_masks(q.reshape(1, -1, rb.ndof), want_min_dists=True)
+    assert np.array_equal(m["self_mask"].cpu().numpy().reshape(-1).astype(np.uint8), z["self_mask"])
+    assert np.array_equal(m["env_mask"].cpu().numpy().reshape(-1).astype(np.uint8), z["env_mask"])
+    assert np.array_equal(host(m["min_self"]).reshape(-1), z["min_self_f32"])
+    assert np.array_equal(host(m["min_env"]).reshape(-1), z["min_env_f32"])
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
+
+
+def test_joint_limit_margin_mask_kat_on_gpu(robots):
+    """tests/search_test.py:22-57 of the reference, through joint_limit_almost_violations_3d."""
+    from cppflow_amd.search import joint_limit_almost_violations_3d
+
+    pi = np.pi
+    qs = torch.zeros((2, 3, 8), device=DEV)
+    qs[0, 0] = torch.tensor([0.051, 0, 0, 0, 0, 0, 0, 0])
+    qs[0, 1] = torch.tensor([0.38615 - 0.001, 0, 0, 0, 0, 0, 0, 0])
+    qs[0, 2] = torch.tensor([0.38615 - 0.051, 0, 0, 0, 0, 0, 0, 0])
+    qs[1, 0] = torch.tensor([0.38615 - 0.051, 0, 0, -pi, 0, 0, 0, 0])
+    qs[1, 1] = torch.tensor([0.38615 - 0.051, 0, 0, -pi + 0.11, 0, 0, 0, 0])
+    qs[1, 2] = torch.tensor([0.38615 - 0.051, 0, 0, -pi + 0.11, 0, 0, 0, pi - 0.25])
+    got = joint_limit_almost_violations_3d(robots["fetch"], qs, eps_revolute=0.1, eps_prismatic=0.05)
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(got.cpu(), torch.tensor([[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]))
+
+
+def test_pose_residual_kat_on_gpu(robots):
+    """tests/optimization_utils_test.py:344-402 of the reference through levenberg_marquardt_only_pose."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_POSE, OptimizationParameters
+    from cppflow_amd.optimization import OptimizationProblem, OptimizationState, levenberg_marquardt_only_pose
+    from cppflow_amd.optimization_utils import get_6d_pose_errors
+
+    fetch = robots["fetch"]
+    qs = dev([[-0.05, 0, 0, 0, 0, 0, 0, 0], [0.25, 0, 0, 0, 0, 0, 0, 0], [0.1, 0, 0, 0, 0, 0, 0, 0]])
+    target = fetch.forward_kinematics(dev([[0.05, 0, 0, 0, 0, 0, 0, 0], [0.2, 0, 0, 0, 0, 0, 0, 0], [0.1, 0, 0, 0, 0, 0, 0, 0]]))
+    params = OptimizationParameters(**{**ALT_LOSS_V2_1_POSE.__dict__, "alpha_position": 0.25, "alpha_rotation": 1.5})
+    problem = problem_from_arrays(fetch, target.cpu().numpy(), device=DEV)
+    op = OptimizationProblem(problem, problem.constraints, qs, problem.target_path, 0, 1, None)
+    x_new, J, r = levenberg_marquardt_only_pose(op, OptimizationState(qs.clone(), 0, 0.0), params, return_residual=True)
+    expected = torch.tensor([[0, 0, 0, 0, 0, 0.1 * 0.25], [0, 0, 0, 0, 0, -0.05 * 0.25], [0, 0, 0, 0, 0, 0.0]])
+    torch.testing.assert_close(r[:, :, 0].cpu(), expected, atol=1e-6, rtol=0)
+    assert J.shape == (3, 6, 8) and x_new.shape == (3, 8)
+    torch.testing.assert_close(J[:, :, 0].cpu(), torch.tensor([0, 0, 0, 0, 0, 0.25]).repeat(3, 1), atol=1e-6, rtol=0)
+    # the step moves the prismatic joint toward the target height
+    assert abs(float(x_new[0, 0]) - 0.05) < 1e-3 and abs(float(x_new[1, 0]) - 0.2) < 1e-3
+    e, cur = get_6d_pose_errors(fetch, qs, target)
+    assert e.shape == (3, 6, 1) and cur.shape == (3, 7)
+    torch.testing.assert_close(e[:, 5, 0].cpu(), torch.tensor([0.1, -0.05, 0.0]), atol=1e-6, rtol=0)
+
+
+def test_batched_masks_equal_per_path_masks(robots):
+    """Property P3: tests/collision_checking_test.py:27-56 of the reference (Panda, 1 cube, 50 paths x 5 waypoints)."""
+    from cppflow_amd.collision_detection import (env_colliding_configs_capsule, get_only_non_colliding_qpaths,
+                                                 qpaths_batched_collisions, qpaths_batched_env_collisions,
+                                                 qpaths_batched_self_collisions, self_colliding_configs_capsule)  # fmt: skip
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.problems_synthetic import PANDA_1CUBE_OBSTACLES
+
+    rb = robots["panda"]
+    n, k = 5, 50
+    target = H.oracle64("panda").fk(H.random_configs("panda", n, seed=1))
+    problem = problem_from_arrays(rb, target, PANDA_1CUBE_OBSTACLES, device=DEV)
+    np.random.seed(0)
+    qpaths = [dev(rb.sample_joint_angles(n)) for _ in range(k)]
+    safe_gt = [qp for qp in qpaths if not self_colliding_configs_capsule(problem, qp).any()]
+    safe_gt = [qp for qp in safe_gt if not env_colliding_configs_capsule(problem, qp).any()]
+    assert 0 < len(safe_gt) < k
+    q = torch.stack(qpaths)
+    sv, ev = qpaths_batched_self_collisions(problem, q), qpaths_batched_env_collisions(problem, q)
+    assert sv.dtype == torch.bool and sv.shape == (k, n) and ev.shape == (k, n)
+    returned = get_only_non_colliding_qpaths(qpaths, sv, ev)
+    assert len(returned) == len(safe_gt) and all(torch.equal(a, b) for a, b in zip(safe_gt, returned))
+    s2, e2 = qpaths_batched_collisions(problem, q)
+    assert torch.equal(s2, sv) and torch.equal(e2, ev)
+    rb.set_obstacles([], [])
+
+
+def test_x_is_valid_and_run_lm_optimization(robots):
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.optimization import run_lm_optimization, run_lm_pose_refinement
+    from cppflow_amd.optimization_utils import x_is_valid
+
+    rb = robots["fetch_arm"]
+    z = np.load(os.path.join(GOLDEN, "reference_paths.npz"))
+    target = z["fetch_arm__s__truncated"]  # BASELINE config C1: 59 waypoints
+    W = target.shape[0]
+    problem = problem_from_arrays(rb, target, device=DEV)
+    # a smooth joint-space seed: solve the first waypoint from several starts, then track the path warm-started
+    o = H.oracle64("fetch_arm")
+    ch = H.chain("fetch_arm")
+    rng = np.random.RandomState(0)
+    starts = rng.uniform(ch.lo * 0.5, ch.hi * 0.5, size=(64, 7))
+    sol = o.lm_steps(H.f32(starts), np.tile(target[:1].astype(np.float64), (64, 1)), 40, lm_lambda=1e-4)
+    pe, _ = o.pose_metrics_exact(sol, np.tile(target[:1].astype(np.float64), (64, 1)))
+    q = sol[int(np.argmin(pe))][None]
+    assert pe.min() < 1e-5
+    path = []
+    for w in range(W):
+        q = o.lm_steps(H.f32(q), target[w : w + 1].astype(np.float64), 10, lm_lambda=1e-4)
+        path.append(q[0])
+    q_star = np.array(path)
+    x_seed = dev(np.clip(q_star + 0.002 * rng.randn(W, 7), ch.lo, ch.hi))
+    # the noisy seed is not valid (pose error), the refined one is
+    x_sol, idx, flags = x_is_valid(problem, problem.constraints, problem.target_path, x_seed, parallel_count=1)
+    assert x_sol is None and idx is None and flags[0] is False
+    res = run_lm_optimization(problem, x_seed, tmax_sec=30.0, max_n_steps=20, return_if_valid_after_n_steps=15,
+                              convergence_threshold=0.3, parallel_count=1, verbosity=0)  # fmt: skip
+    pos_cm, rot_deg = (100 * t for t in rb.pose_error_metrics(res.x_opt, problem.target_path)[:1]), None
+    assert res.x_opt.shape == (W, 7)
+    pe_m, re_rad = rb.pose_error_metrics(res.x_opt, problem.target_path)
+    assert float(pe_m.max()) * 100 < problem.constraints.max_allowed_position_error_cm
+    assert float(torch.rad2deg(re_rad).max()) < problem.constraints.max_allowed_rotation_error_deg
+    del pos_cm, rot_deg
+    # batched form: 3 seeds at once, result identical to running each seed alone (rows are independent)
+    seeds = torch.cat([x_seed, dev(np.clip(q_star + 0.004 * rng.randn(W, 7), ch.lo, ch.hi)), x_seed.clone()])
+    batched = run_lm_pose_refinement(problem, seeds, n_steps=6)
+    alone = run_lm_pose_refinement(problem, seeds[W : 2 * W].contiguous(), n_steps=6)
+    assert torch.equal(batched.x[W : 2 * W], alone.x) and torch.equal(batched.ext_cost[1], alone.ext_cost[0])
+    assert torch.equal(batched.x[:W], batched.x[2 * W :])
+    assert batched.pos_err_m.shape == (3, W) and batched.self_mask.dtype == torch.bool
+    x_sol, idx, flags = x_is_valid(problem, problem.constraints, problem.target_path, batched.x, parallel_count=3)
+    assert flags[0] and flags[1]
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_baseline_configs_on_reference_paths(robots, cfg):
+    """BASELINE.json configs 2-4 at their full sizes on the reference's own target paths (tests/golden/reference_paths.npz),
+    checked through size-independent properties: joint limits hold, converged rows reproduce the target pose, the fused
+    masks equal the standalone masks, and seed-sharding the batch changes nothing (the multi-GPU partition)."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.optimization import run_lm_pose_refinement
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES
+
+    z = np.load(os.path.join(GOLDEN, "reference_paths.npz"))
+    name, key, S, obs = {
+        "C2": ("panda", "panda__1cube_first64", 128, []),
+        "C3": ("fetch", "fetch__hello_first256", 512, []),
+        "C4": ("panda", "panda__2cubes_resampled256", 1024, PANDA_2CUBES_OBSTACLES),
+    }[cfg]
+    rb = robots[name]
+    target = z[key]
+    W = target.shape[0]
+    problem = problem_from_arrays(rb, target, obs, device=DEV)
+    ch = H.chain(name)
+    g = torch.Generator().manual_seed(0)
+    lo, hi = torch.tensor(ch.lo, dtype=torch.float32), torch.tensor(ch.hi, dtype=torch.float32)
+    x0 = (lo + (hi - lo) * (0.25 + 0.5 * torch.rand((S * W, rb.ndof), generator=g))).to(DEV)
+    r = run_lm_pose_refinement(problem, x0, n_steps=20)
+    x = r.x
+    assert bool(((x >= lo.to(DEV)) & (x <= hi.to(DEV))).all())
+    conv = (r.pos_err_m < 1e-4) & (r.rot_err_rad < 1.75e-3)
+    assert float(conv.float().mean()) > 0.5  # random starts on a real path: most rows reach some IK branch in 20 steps
+    pe, re = rb.pose_error_metrics(x, problem.target_path)
+    assert torch.equal(pe.view(S, W), r.pos_err_m) and torch.equal(re.view(S, W), r.rot_err_rad)
+    cur = rb.forward_kinematics(x)
+    tgt = problem.target_path.repeat(S, 1)
+    assert float((cur[:, :3] - tgt[:, :3]).norm(dim=1)[conv.view(-1)].max()) < 1e-4
+    alone = rb.collision_masks(x.view(S, W, -1))
+    assert torch.equal(alone["self_mask"], r.self_mask) and torch.equal(alone["env_mask"], r.env_mask)
+    assert torch.equal(alone["jlim_mask"], r.jlim_mask) and torch.equal(alone["ext_cost"], r.ext_cost)
+    expect_cost = 100.0 * r.jlim_mask.float() + 1000.0 * r.env_mask.float() + 1000.0 * r.self_mask.float()
+    assert torch.equal(expect_cost, r.ext_cost)  # cppflow/search.py:146-150
+    half = S // 2
+    a = run_lm_pose_refinement(problem, x0[: half * W].contiguous(), n_steps=20)
+    b = run_lm_pose_refinement(problem, x0[half * W :].contiguous(), n_steps=20)
+    assert torch.equal(torch.cat([a.x, b.x]), x) and torch.equal(torch.cat([a.packed[: 4 * half * W], b.packed[: 4 * half * W]]).view(torch.float32), r.ext_cost.view(-1))
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
+
+
+def test_c5_shape_runs(robots):
+    """BASELINE config 5 geometry (12-DoF chain, 512 waypoints) at a reduced seed count: every row finite and clamped."""
+    rb = robots["chain12"]
+    S, W = 64, 512
+    x0, target = H.lm_problem("chain12", S, W, seed=5)
+    r = rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=10, want_errors=True)
+    assert bool(torch.isfinite(r["x"]).all()) and float((r["pos_err_m"] < 1e-4).float().mean()) > 0.9
