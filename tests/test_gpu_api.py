@@ -41,7 +41,7 @@ def test_golden_vectors(robots, name):
     r1 = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=1, clamp=False, return_residual=True)
     assert np.abs(host(r1["J"]) - z["J_scaled"]).max() < 1e-5
     assert np.abs(host(r1["e"])[:, :, 0] - z["e_scaled"]).max() < 1e-5
-    ok = np.linalg.svd(z["J_scaled"], compute_uv=False)[:, -1] >= 1e-2
+    ok = np.linalg.svd(z["J_scaled"], compute_uv=False)[:, -1] >= 2e-2
     assert np.abs(host(r1["x"]) - z["x_step1"])[ok].max() < 5e-3
     rK = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=K, want_errors=True)
     conv = (z["pos_err_K"] < 1e-4) & (z["rot_err_K"] < 1.2e-3)
@@ -101,8 +101,9 @@ def test_pose_residual_kat_on_gpu(robots):
     torch.testing.assert_close(r[:, :, 0].cpu(), expected, atol=1e-6, rtol=0)
     assert J.shape == (3, 6, 8) and x_new.shape == (3, 8)
     torch.testing.assert_close(J[:, :, 0].cpu(), torch.tensor([0, 0, 0, 0, 0, 0.25]).repeat(3, 1), atol=1e-6, rtol=0)
-    # the step moves the prismatic joint toward the target height
-    assert abs(float(x_new[0, 0]) - 0.05) < 1e-3 and abs(float(x_new[1, 0]) - 0.2) < 1e-3
+    # the step reduces the height error (the stretched-out zero pose is singular, so only the residual is pinned)
+    e_after, _ = get_6d_pose_errors(fetch, x_new, target)
+    assert float(e_after[0, 5, 0].abs()) < 0.1 and float(e_after[1, 5, 0].abs()) < 0.05
     e, cur = get_6d_pose_errors(fetch, qs, target)
     assert e.shape == (3, 6, 1) and cur.shape == (3, 7)
     torch.testing.assert_close(e[:, 5, 0].cpu(), torch.tensor([0.1, -0.05, 0.0]), atol=1e-6, rtol=0)
@@ -204,12 +205,19 @@ def test_baseline_configs_on_reference_paths(robots, cfg):
     ch = H.chain(name)
     g = torch.Generator().manual_seed(0)
     lo, hi = torch.tensor(ch.lo, dtype=torch.float32), torch.tensor(ch.hi, dtype=torch.float32)
-    x0 = (lo + (hi - lo) * (0.25 + 0.5 * torch.rand((S * W, rb.ndof), generator=g))).to(DEV)
+    # seeds as SURVEY.md 8(d) builds them: per (seed, waypoint) an IK branch q* (heavily damped LM from a random start),
+    # then x0 = clamp(q* + 0.1 randn) -- the construction of the reference's tests/optimization_test.py:82
+    x_rand = (lo + (hi - lo) * (0.15 + 0.7 * torch.rand((S * W, rb.ndof), generator=g))).to(DEV)
+    ik = rb.lm_pose_steps(x_rand, problem.target_path, 1e-2, 3.5, 0.35, n_steps=60, want_errors=True)
+    solved = ((ik["pos_err_m"] < 1e-4) & (ik["rot_err_rad"] < 1.75e-3)).view(S, W)
+    assert float(solved.float().mean()) > 0.3
+    noise = 0.1 * torch.randn((S * W, rb.ndof), generator=g).to(DEV)
+    x0 = torch.minimum(torch.maximum(ik["x"] + noise, lo.to(DEV)), hi.to(DEV)).contiguous()
     r = run_lm_pose_refinement(problem, x0, n_steps=20)
     x = r.x
     assert bool(((x >= lo.to(DEV)) & (x <= hi.to(DEV))).all())
     conv = (r.pos_err_m < 1e-4) & (r.rot_err_rad < 1.75e-3)
-    assert float(conv.float().mean()) > 0.5  # random starts on a real path: most rows reach some IK branch in 20 steps
+    assert float(conv[solved].float().mean()) > 0.85, float(conv[solved].float().mean())
     pe, re = rb.pose_error_metrics(x, problem.target_path)
     assert torch.equal(pe.view(S, W), r.pos_err_m) and torch.equal(re.view(S, W), r.rot_err_rad)
     cur = rb.forward_kinematics(x)
