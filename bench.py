@@ -64,9 +64,57 @@ def make_inputs(robot, S, W, device, seed):
     return x0.to(device), target.contiguous()
 
 
-def cpu_baseline(robot_name, obstacles, d, W, K, budget_s=15.0):
-    """Oracle (the CPU restatement of the reference path, oracle/lmik_oracle.c, fp32 canonical build, OpenMP over rows)
-    timed on this host on a bounded sample of the same workload: S_cpu seeds x W waypoints, K iterations + masks."""
+def _cpu_inputs(chain, W, d, S_cpu, seed=0):
+    rng = np.random.RandomState(seed)
+    q_star = rng.uniform(chain.lo, chain.hi, size=(W, d)).astype(np.float32)
+    x0 = np.clip(q_star[None] + 0.1 * rng.randn(S_cpu, W, d), chain.lo, chain.hi).reshape(S_cpu * W, d).astype(np.float32)
+    return q_star, x0
+
+
+def cpu_baseline_torch(robot_name, obstacles, d, W, K, budget_s=12.0):
+    """The reference-equivalent CPU path: oracle/ref_torch.py issues the reference's own torch op sequence
+    (cppflow/optimization.py:73-92: in-place row scaling, bmm x2, eye.repeat, torch.linalg.solve, python-loop clamp;
+    cppflow/collision_detection.py:27-69: distance tensors -> min -> "< 0") with batched-torch kinematics standing in for
+    the un-vendored jrl.  fp32, torch's default CPU threads, on a bounded sample of the same workload."""
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robot_zoo import ROBOT_SPECS
+    from oracle import ref_torch
+
+    spec = ROBOT_SPECS[robot_name]()
+    chain = canonicalize(spec)
+    rb = ref_torch.TorchRobot(spec, device="cpu", dtype=torch.float32)
+    cub = [torch.tensor(c) for c, _ in obstacles]
+    Ts = [torch.tensor(T) for _, T in obstacles]
+    eps_r, eps_p = float(np.deg2rad(1.5)), 0.03
+
+    def run(S_cpu):
+        q_star, x0 = _cpu_inputs(chain, W, d, S_cpu)
+        target = rb.forward_kinematics(torch.tensor(q_star)).repeat(S_cpu, 1)
+        x = torch.tensor(x0)
+        t0 = time.perf_counter()
+        x = ref_torch.lm_pose_steps(rb, x, target, K)
+        ref_torch.calculate_pose_error_m_rad(rb, x, target)
+        ref_torch.q_costs_external(rb, x.reshape(S_cpu, W, d), cub, Ts, eps_r, eps_p)
+        return time.perf_counter() - t0
+
+    run(1)
+    t_probe = run(32)
+    S_cpu = int(max(32, min(1024, 32 * budget_s / max(t_probe, 1e-6))))
+    t = run(S_cpu)
+    threads = torch.get_num_threads()
+    return {
+        "value": S_cpu * W * K / t,
+        "unit": "LM-IK iterations/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{S_cpu} seeds x {W} waypoints x {K} LM iterations + pose metrics + collision masks + cost; torch-CPU "
+        f"restatement of the reference's op sequence (oracle/ref_torch.py; jrl is not vendored so the reference itself "
+        f"cannot run), fp32, {threads} torch threads of {os.cpu_count()} host cores, {t:.2f} s",
+    }
+
+
+def cpu_baseline_c(robot_name, obstacles, d, W, K, budget_s=8.0):
+    """The C restatement (oracle/lmik_oracle.c, canonical fp32 build, LU solve in reference order), OpenMP over rows."""
     from cppflow_amd.robot_model import canonicalize
     from cppflow_amd.robot_zoo import ROBOT_SPECS
     from oracle import oracle as orc
@@ -75,32 +123,29 @@ def cpu_baseline(robot_name, obstacles, d, W, K, budget_s=15.0):
     cores = os.cpu_count() or 1
     chain = canonicalize(ROBOT_SPECS[robot_name]())
     o = orc.Oracle(chain, f32=True, threads=cores)
-    rng = np.random.RandomState(0)
-    q_star = rng.uniform(chain.lo, chain.hi, size=(W, d)).astype(np.float32).astype(np.float64)
-    target = o.fk(q_star)
     lo_b = np.array([np.float32(T[:3, 3]) + np.float32(c[:3]) for c, T in obstacles], dtype=np.float64).reshape(-1, 3)
     hi_b = np.array([np.float32(T[:3, 3]) + np.float32(c[3:]) for c, T in obstacles], dtype=np.float64).reshape(-1, 3)
 
     def run(S_cpu):
-        x0 = np.clip(np.tile(q_star[None], (S_cpu, 1, 1)) + 0.1 * rng.randn(S_cpu, W, d), chain.lo, chain.hi)
-        x0 = x0.reshape(S_cpu * W, d).astype(np.float32).astype(np.float64)
-        tgt = np.tile(target, (S_cpu, 1))
+        q_star, x0 = _cpu_inputs(chain, W, d, S_cpu)
+        tgt = np.tile(o.fk(q_star.astype(np.float64)), (S_cpu, 1))
+        x0 = x0.astype(np.float64)
         t0 = time.perf_counter()
         x = o.lm_steps(x0, tgt, K, 1e-6, 3.5, 0.35, solver=0)
         o.pose_metrics(x, tgt)
         o.masks(x, lo_b, hi_b, chain.lo, chain.hi)
         return time.perf_counter() - t0
 
-    t_probe = run(8)
-    S_cpu = int(max(8, min(1024, 8 * budget_s / max(t_probe, 1e-6))))
+    t_probe = run(64)
+    S_cpu = int(max(64, min(16384, 64 * budget_s / max(t_probe, 1e-6))))
     t = run(S_cpu)
     return {
         "value": S_cpu * W * K / t,
         "unit": "LM-IK iterations/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{S_cpu} seeds x {W} waypoints x {K} LM iterations + collision masks, fp32 C restatement "
-        f"(oracle/lmik_oracle.c, LU solve in reference order), OpenMP {cores} threads, {t:.2f} s",
+        "sample": f"{S_cpu} seeds x {W} waypoints x {K} LM iterations + pose metrics + collision masks; scalar C restatement "
+        f"(oracle/lmik_oracle.c, fp32 canonical build), OpenMP {cores} threads, {t:.2f} s",
     }
 
 
@@ -242,8 +287,10 @@ def main():
             "step_ms_hip_events": step_ms_events,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.robot, obstacles, d, W, K)
+            line["cpu_baseline"] = cpu_baseline_torch(args.robot, obstacles, d, W, K)
+            line["cpu_baseline_c"] = cpu_baseline_c(args.robot, obstacles, d, W, K)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            line["gpu_over_cpu_c"] = line["value"] / line["cpu_baseline_c"]["value"]
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
