@@ -252,13 +252,11 @@ __device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float 
     const float inv_a = 1.f / a, inv_e = 1.f / e;  // one IEEE division per capsule: shared by every pair it is in
     float s = denom > 0.f ? clamp01(CPPF_FMA(b, f, -(c * e)) / denom) : 0.f;
     float t = CPPF_FMA(b, s, f) * inv_e;
-    if (t < 0.f) {
-        t = 0.f;
-        s = clamp01(-c * inv_a);
-    } else if (t > 1.f) {
-        t = 1.f;
-        s = clamp01((b - c) * inv_a);
-    }
+    // branch-free form of { t < 0: t = 0, s = clamp(-c/a) ; t > 1: t = 1, s = clamp((b-c)/a) } -- lanes of a wave
+    // disagree on these cases all the time, so both candidates are always computed and selected
+    const float s_lo = clamp01(-c * inv_a), s_hi = clamp01((b - c) * inv_a);
+    s = t < 0.f ? s_lo : (t > 1.f ? s_hi : s);
+    t = clamp01(t);
     float df[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) df[i] = CPPF_FMA(d1[i], s, P1[i]) - CPPF_FMA(d2[i], t, P2[i]);
@@ -293,27 +291,21 @@ __device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float 
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) gv[k] = seg_box_g(P0, D, lo, hi, cand[k]);
-    float t;
-    if (gv[0] >= 0.f) {
-        t = 0.f;
-    } else if (gv[1] <= 0.f) {
-        t = 1.f;
-    } else {
-        float tl = 0.f, gl = gv[0], tr = 1.f, gr = gv[1];
+    // bracket the root of g among the candidates and interpolate (g is linear between adjacent candidates); branch-free:
+    // lanes disagree on the three cases, so the interior solution is always computed and then selected
+    float tl = 0.f, gl = gv[0], tr = 1.f, gr = gv[1];
 #pragma unroll
-        for (int k = 2; k < 8; ++k) {
-            if (gv[k] <= 0.f && cand[k] >= tl) {
-                tl = cand[k];
-                gl = gv[k];
-            }
-            if (gv[k] >= 0.f && cand[k] <= tr) {
-                tr = cand[k];
-                gr = gv[k];
-            }
-        }
-        const float dg = gr - gl;
-        t = dg > 0.f ? CPPF_FMA(tr - tl, (-gl) / dg, tl) : tl;
+    for (int k = 2; k < 8; ++k) {
+        const bool lo_side = gv[k] <= 0.f && cand[k] >= tl;
+        tl = lo_side ? cand[k] : tl;
+        gl = lo_side ? gv[k] : gl;
+        const bool hi_side = gv[k] >= 0.f && cand[k] <= tr;
+        tr = hi_side ? cand[k] : tr;
+        gr = hi_side ? gv[k] : gr;
     }
+    const float dg = gr - gl;
+    const float t_in = dg > 0.f ? CPPF_FMA(tr - tl, (-gl) / dg, tl) : tl;
+    const float t = gv[0] >= 0.f ? 0.f : (gv[1] <= 0.f ? 1.f : t_in);
     float ex[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {

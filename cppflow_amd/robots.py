@@ -306,6 +306,13 @@ class Robot:
         )
         return res
 
+    def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
+                       alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
+                       clamp: bool = True) -> "LmLaunchPlan":  # fmt: skip
+        """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
+        holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation."""
+        return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp)
+
     def collision_masks(
         self, q: torch.Tensor, want_min_dists: bool = False, only: Optional[Sequence[str]] = None
     ) -> Dict[str, torch.Tensor]:
@@ -372,6 +379,40 @@ class Robot:
             )
         )
         return out
+
+
+class LmLaunchPlan:
+    def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp):
+        x = robot._x2d(x)
+        x_out = robot._x2d(x_out, "x_out")
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0 and x_out.shape == x.shape
+        self._keep = (robot, x, target, x_out, packed_out)  # the plan owns references to every buffer it points at
+        self.outputs: Dict[str, torch.Tensor] = {"x": x_out}
+        out = _hip.LmOutputs()
+        out.x_out = x_out.data_ptr()
+        if packed_out is not None:
+            assert packed_out.dtype == torch.uint8 and packed_out.is_cuda and packed_out.is_contiguous()
+            assert packed_out.numel() == robot.PACKED_BYTES_PER_ROW * n and packed_out.data_ptr() % 4 == 0
+            f = packed_out[: 12 * n].view(torch.float32)
+            m = packed_out[12 * n :]
+            views = dict(ext_cost=f[:n], pos_err_m=f[n : 2 * n], rot_err_rad=f[2 * n :], self_mask=m[:n],
+                         env_mask=m[n : 2 * n], jlim_mask=m[2 * n :])  # fmt: skip
+            for k, v in views.items():
+                setattr(out, k, v.data_ptr())
+            self.outputs.update(views)
+        self._out = out
+        self._prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
+        self._fn = _hip.lib().cppf_lm_pose_steps
+        self._args = (robot._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(self._prm),
+                      ctypes.byref(self._out))  # fmt: skip
+        self._device = x.device
+
+    def launch(self) -> None:
+        rc = self._fn(*self._args, torch.cuda.current_stream(self._device).cuda_stream)
+        if rc:
+            _hip.check(rc)
 
 
 def get_robot(name: str) -> Robot:
