@@ -100,6 +100,10 @@ SIGNATURES = {
     ),
     "cppf_pose_error_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "cppf_seed_validity": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cppf_dp_search": (
+        ctypes.c_int,
+        [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
+    ),
 }
 
 _lib: Optional[ctypes.CDLL] = None

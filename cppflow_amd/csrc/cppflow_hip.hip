@@ -649,6 +649,172 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
     }
 }
 
+// ---- dp_search (cppflow/search.py:100-191) -----------------------------------------------------------------------------------
+// costs[b,t] = min_a { max(mjac(a->b,t-1), costs[a,t-1]) + ext[b,t] }, first minimal a recorded; one launch per timestep
+// (the recurrence is sequential in t; each step is a k x k (min,max) product).  The reference materialises
+// mjacs[k,k,T-1] (1 GB at k = 1024, T = 256); here every entry lives in a register for one compare.
+// Work arrays are time-major so that a step reads two contiguous [k,d] slabs: qT[t][a][j], costsT[t][a], memoT[t][b].
+
+// torch.remainder(x, 2pi) - pi for x = dq + pi, exactly as fmodf does it for |x| < 4 pi (one exact +-2pi step), fmodf beyond
+__device__ __forceinline__ float wrap_pi_bounded(float dq) {
+    const float pi = 3.14159265358979323846f, p2 = 2.f * pi;
+    const float x = dq + pi;
+    float r;
+    if (__builtin_expect(fabsf(x) < 2.f * p2, 1)) {
+        r = x >= p2 ? x - p2 : x;  // exact (Sterbenz)
+        r = r <= -p2 ? r + p2 : r;
+    } else {
+        r = __builtin_fmodf(x, p2);
+    }
+    if (r < 0.f) r += p2;
+    return r - pi;
+}
+
+__global__ __launch_bounds__(256) void dp_transpose_kernel(const float* __restrict__ q, const float* __restrict__ ext, int k,
+                                                           int T, int d, float* __restrict__ qT, float* __restrict__ costsT) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)k * T * d;
+    if (i < total) {
+        const int j = (int)(i % d);
+        const size_t r = i / d;
+        const int t = (int)(r % T), a = (int)(r / T);
+        qT[((size_t)t * k + a) * d + j] = q[i];
+    }
+    if (i < (size_t)k) costsT[i] = ext[i * T];  // costs[:,0] = q_costs_external[:,0]  (search.py:151)
+}
+
+constexpr int kDpBPB = 4;  // destination candidates per workgroup
+
+template <int D>
+__global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ q_prev, const float* __restrict__ q_cur,
+                                                      const float* __restrict__ cost_prev, const float* __restrict__ ext,
+                                                      int k, int T, int t, uint32_t pris_mask, float pscale,
+                                                      float* __restrict__ cost_cur, int32_t* __restrict__ memo_cur) {
+    __shared__ float red_v[kDpBPB][4];
+    __shared__ int red_a[kDpBPB][4];
+    const int b0 = blockIdx.x * kDpBPB;
+    float qb[kDpBPB][D], eb[kDpBPB], best[kDpBPB];
+    int arg[kDpBPB];
+#pragma unroll
+    for (int i = 0; i < kDpBPB; ++i) {
+        const int b = min(b0 + i, k - 1);
+#pragma unroll
+        for (int j = 0; j < D; ++j) qb[i][j] = q_cur[(size_t)b * D + j];
+        eb[i] = ext[(size_t)b * T + t];
+        best[i] = INFINITY;
+        arg[i] = 0;
+    }
+    for (int a = threadIdx.x; a < k; a += 256) {
+        float qa[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) qa[j] = q_prev[(size_t)a * D + j];
+        const float c = cost_prev[a];
+#pragma unroll
+        for (int i = 0; i < kDpBPB; ++i) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float dq = qb[i][j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
+                m = fmaxf(m, fabsf(wrap_pi_bounded(dq)));
+            }
+            const float v = fmaxf(m, c) + eb[i];  // search.py:157-158
+            if (v < best[i]) {
+                best[i] = v;
+                arg[i] = a;
+            }
+        }
+    }
+    // lexicographic (value, index) min: first minimal index, over the wave then over the 4 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kDpBPB; ++i) {
+        float v = best[i];
+        int a = arg[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off, 64);
+            const int oa = __shfl_xor(a, off, 64);
+            if (ov < v || (ov == v && oa < a)) {
+                v = ov;
+                a = oa;
+            }
+        }
+        if (lane == 0) {
+            red_v[i][wave] = v;
+            red_a[i][wave] = a;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kDpBPB) {
+        const int i = threadIdx.x;
+        float v = red_v[i][0];
+        int a = red_a[i][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = red_v[i][w];
+            const int oa = red_a[i][w];
+            if (ov < v || (ov == v && oa < a)) {
+                v = ov;
+                a = oa;
+            }
+        }
+        if (b0 + i < k) {
+            cost_cur[b0 + i] = v;
+            memo_cur[b0 + i] = a;
+        }
+    }
+}
+
+// argmin over the final costs (first minimal index), walk the memo table back, gather the path
+__global__ __launch_bounds__(256) void dp_backtrace_kernel(const float* __restrict__ q, const float* __restrict__ costsT,
+                                                           const int32_t* __restrict__ memoT, int k, int T, int d,
+                                                           int32_t* __restrict__ best_idx, float* __restrict__ best_path) {
+    __shared__ float red_v[4];
+    __shared__ int red_a[4];
+    const float* last = costsT + (size_t)(T - 1) * k;
+    float v = INFINITY;
+    int a = 0;
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const float c = last[i];
+        if (c < v) {
+            v = c;
+            a = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oa = __shfl_xor(a, off, 64);
+        if (ov < v || (ov == v && oa < a)) {
+            v = ov;
+            a = oa;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red_v[threadIdx.x >> 6] = v;
+        red_a[threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] < v || (red_v[w] == v && red_a[w] < a)) {
+                v = red_v[w];
+                a = red_a[w];
+            }
+        int i = a;
+        for (int t = T - 1; t >= 0; --t) {  // search.py:161-173
+            best_idx[t] = i;
+            i = memoT[(size_t)t * k + i];
+        }
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < T * d; n += 256) {
+        const int t = n / d, j = n % d;
+        best_path[n] = q[((size_t)best_idx[t] * T + t) * d + j];
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------------
 
 thread_local std::string g_err;
@@ -1048,6 +1214,34 @@ int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* tar
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((seed_validity_kernel<D>), dim3(S), dim3(64), 0, st,
                                                         robot->chain, robot->coll, S, W, x, target, out));
+    return check_launch(robot);
+}
+
+int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
+                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
+                   void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(k >= 1 && T >= 1, "k, T must be >= 1");
+    CPPF_REQUIRE(q && ext_cost && work_qT && work_costsT && work_memoT && best_path && best_idx, "NULL pointer");
+    CPPF_REQUIRE((size_t)k * T * robot->desc.ndof <= 0x7fffffffu, "k*T*d exceeds 2^31-1");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = robot->desc.ndof;
+    const size_t total = (size_t)k * T * d;
+    hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
+                       ext_cost, k, T, d, work_qT, work_costsT);
+    // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
+    CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
+    const unsigned blocks = (unsigned)((k + kDpBPB - 1) / kDpBPB);
+    for (int t = 1; t < T; ++t) {
+        const float* qp = work_qT + (size_t)(t - 1) * k * d;
+        const float* qc = work_qT + (size_t)t * k * d;
+        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_step_kernel<D>), dim3(blocks), dim3(256), 0, st, qp, qc,
+                                             work_costsT + (size_t)(t - 1) * k, ext_cost, k, T, t,
+                                             robot->chain.pris_mask, prismatic_scaling, work_costsT + (size_t)t * k,
+                                             work_memoT + (size_t)t * k));
+    }
+    hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
+                       best_path);
     return check_launch(robot);
 }
 

@@ -366,6 +366,27 @@ class Robot:
         )
         return pe, re
 
+    def dp_search(self, q: torch.Tensor, ext_cost: torch.Tensor, prismatic_joint_scaling: float = 5.0):
+        """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191."""
+        q = _require_device_tensor(q, "q")
+        ext_cost = _require_device_tensor(ext_cost, "q_costs_external")
+        assert q.dim() == 3 and q.shape[2] == self.ndof, tuple(q.shape)
+        k, T, d = q.shape
+        assert ext_cost.shape == (k, T), (tuple(ext_cost.shape), (k, T))
+        dev = q.device
+        qT = torch.empty((T, k, d), dtype=torch.float32, device=dev)
+        costsT = torch.empty((T, k), dtype=torch.float32, device=dev)
+        memoT = torch.empty((T, k), dtype=torch.int32, device=dev)
+        best_path = torch.empty((T, d), dtype=torch.float32, device=dev)
+        best_idx = torch.empty(T, dtype=torch.int32, device=dev)
+        _hip.check(
+            _hip.lib().cppf_dp_search(
+                self._handle(dev), q.data_ptr(), ext_cost.data_ptr(), k, T, float(prismatic_joint_scaling), qT.data_ptr(),
+                costsT.data_ptr(), memoT.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(), _stream_ptr(dev),
+            )  # fmt: skip
+        )
+        return best_path, best_idx, costsT
+
     def seed_validity(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """[S,4]: per seed max position error (cm), max rotation error (deg), mjac revolute (deg), mjac prismatic (cm)."""
         x = self._x2d(x)

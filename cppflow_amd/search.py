@@ -49,25 +49,20 @@ def q_costs_external(robot, q: torch.Tensor, problem=None) -> Tuple[torch.Tensor
     return r["ext_cost"], r["jlim_mask"], r["env_mask"], r["self_mask"]
 
 
-def _get_mjacs(q: torch.Tensor, robot, prismatic_joint_scaling: float = 5.0) -> torch.Tensor:
-    """[k, k, T-1]: max wrapped joint change from path a at t to path b at t+1 (cppflow/search.py:100-125)."""
-    dqs = q[:, 1:, :].unsqueeze(1) - q[:, :-1, :].unsqueeze(0)
-    if robot.has_prismatic_joints:
-        dqs = dqs.clone()
-        dqs[:, :, :, robot.prismatic_joint_idxs] *= prismatic_joint_scaling
-    return torch.abs(torch.remainder(dqs + math.pi, 2 * math.pi) - math.pi).amax(dim=3)
-
-
 def dp_search(
     robot,
     q: torch.Tensor,
-    self_collision_violations: torch.Tensor,
-    env_collision_violations: torch.Tensor,
+    self_collision_violations: Optional[torch.Tensor],
+    env_collision_violations: Optional[torch.Tensor],
     use_cuda: bool = True,
     verbosity: int = 0,
     q_costs: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """min-max dynamic programme over k candidate paths (cppflow/search.py:128-191) -> best path [T, d]."""
+    """min-max dynamic programme over k candidate paths (cppflow/search.py:128-191) -> best path [T, d], on the device
+    (`cppf_dp_search`: one small launch per timestep; the reference moves q to the CPU, `search.py:140-141`).
+
+    The external cost is `100*jlim + 1000*env + 1000*self` (`:146-150`): pass the two violation masks like the reference
+    does, or `q_costs` directly (the `ext_cost` output of the collision / fused launch)."""
     k, T, d = q.shape
     if q_costs is None:
         jlim = joint_limit_almost_violations_3d(robot, q)
@@ -76,17 +71,5 @@ def dp_search(
             + K_COLLISION_COST * env_collision_violations.to(q.device, torch.float32)
             + K_COLLISION_COST * self_collision_violations.to(q.device, torch.float32)
         )
-    costs = torch.zeros((k, T), device=q.device, dtype=q.dtype)
-    costs[:, 0] = q_costs[:, 0]
-    mjacs = _get_mjacs(q, robot)
-    memo = torch.zeros((k, T), dtype=torch.long, device=q.device)
-    for t in range(1, T):
-        # entry [b, a]: arrive at candidate b from candidate a
-        nxt = torch.maximum(mjacs[:, :, t - 1], costs[:, t - 1].unsqueeze(0)) + q_costs[:, t].unsqueeze(1)
-        costs[:, t], memo[:, t] = torch.min(nxt, dim=1)
-    best = torch.zeros((T, d), dtype=q.dtype, device=q.device)
-    i = torch.argmin(costs[:, -1])
-    for t in range(T - 1, -1, -1):
-        best[t] = q[i, t]
-        i = memo[i, t]
-    return best
+    best_path, _, _ = robot.dp_search(q, q_costs.contiguous())
+    return best_path

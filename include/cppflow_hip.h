@@ -150,6 +150,16 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
 int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
                        void* stream);
 
+/* dp_search(robot, q, ...) of cppflow/search.py:128-191 given the external cost matrix q_costs_external [k,T]
+ * (search.py:146-150, the `ext_cost` output of cppf_collision_masks / cppf_lm_pose_steps): the min-max dynamic programme
+ * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,
+ * 5.0 in the reference), then the back-trace.  Outputs best_path [T,d] and best_idx [T] (which candidate each waypoint
+ * came from).  The caller supplies the workspace (device): work_qT [T*k*d] floats, work_costsT [T*k] floats (on return:
+ * the cost table, time-major), work_memoT [T*k] int32.  T-1 small launches on `stream`, no host synchronisation. */
+int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
+                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -888,3 +888,55 @@ void orc_seed_validity(const void* h, const double* x, const double* target, int
     free(pe);
     free(re);
 }
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* dp_search (cppflow/search.py:100-191)                                                                            */
+
+/* Min-max dynamic programme over k candidate paths: costs[:,0] = ext[:,0];
+ *   costs[b,t] = min_a max(mjac(a->b, t-1), costs[a,t-1]) + ext[b,t],   memo[b,t] = argmin_a (first minimal a)
+ * with mjac(a->b, t-1) = max_j |remainder(s_j * (q[b,t,j] - q[a,t-1,j]) + pi, 2 pi) - pi|, s_j = prismatic_scaling for
+ * prismatic joints (search.py:119-123: the scaling is applied to dq BEFORE the wrap, to every joint it is given for) and
+ * 1 otherwise.  Then the back-trace of search.py:161-173 from argmin_b costs[b,T-1].  Outputs: best_idx[T], costs[k,T]. */
+void orc_dp_search(const void* h, const double* q, const double* ext, int k, int T, double prismatic_scaling, int* best_idx,
+                   double* costs_out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    REAL* costs = (REAL*)malloc(sizeof(REAL) * (size_t)k * T);
+    int* memo = (int*)calloc((size_t)k * T, sizeof(int));
+    for (int b = 0; b < k; ++b) costs[(size_t)b * T] = (REAL)ext[(size_t)b * T];
+    for (int t = 1; t < T; ++t) {
+#pragma omp parallel for schedule(static)
+        for (int b = 0; b < k; ++b) {
+            REAL best = INFINITY;
+            int arg = 0;
+            for (int a = 0; a < k; ++a) {
+                REAL m = 0;
+                for (int j = 0; j < d; ++j) {
+                    REAL dq = (REAL)q[((size_t)b * T + t) * d + j] - (REAL)q[((size_t)a * T + t - 1) * d + j];
+                    if (rb->jtype[j] == 1) dq *= (REAL)prismatic_scaling;
+                    const REAL v = FABS(wrap_pi(dq));
+                    if (v > m) m = v;
+                }
+                const REAL c = costs[(size_t)a * T + t - 1];
+                const REAL v = (m > c ? m : c) + (REAL)ext[(size_t)b * T + t];
+                if (v < best) {
+                    best = v;
+                    arg = a;
+                }
+            }
+            costs[(size_t)b * T + t] = best;
+            memo[(size_t)b * T + t] = arg;
+        }
+    }
+    int i = 0;
+    for (int b = 1; b < k; ++b)
+        if (costs[(size_t)b * T + T - 1] < costs[(size_t)i * T + T - 1]) i = b;
+    for (int t = T - 1; t >= 0; --t) {
+        best_idx[t] = i;
+        i = memo[(size_t)i * T + t];
+    }
+    if (costs_out)
+        for (size_t n = 0; n < (size_t)k * T; ++n) costs_out[n] = costs[n];
+    free(costs);
+    free(memo);
+}

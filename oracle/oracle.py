@@ -65,6 +65,7 @@ def _lib(f32: bool):
         ]  # fmt: skip
         lib.orc_angular_changes.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp]
         lib.orc_seed_validity.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]
+        lib.orc_dp_search.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, _ip, _dp]
         _LIBS[name] = lib
     return _LIBS[name]
 
@@ -232,3 +233,15 @@ class Oracle:
         out = np.empty((S, 4))
         self.lib.orc_seed_validity(self.h, _p(x), _p(target), S, W, _p(out))
         return out
+
+    def dp_search(self, q, ext_cost, prismatic_scaling=5.0):
+        """q [k,T,d], ext_cost [k,T] -> (best_idx [T] int, costs [k,T]) per cppflow/search.py:128-191."""
+        q = _d(q)
+        k, T, d = q.shape
+        assert d == self.ndof
+        ext = _d(ext_cost)
+        assert ext.shape == (k, T)
+        idx = np.zeros(T, dtype=np.int32)
+        costs = np.empty((k, T))
+        self.lib.orc_dp_search(self.h, _p(q), _p(ext), k, T, float(prismatic_scaling), idx.ctypes.data_as(_ip), _p(costs))
+        return idx, costs

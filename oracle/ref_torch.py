@@ -324,3 +324,30 @@ def q_costs_external(robot, q, cuboids, Tcuboids, eps_revolute, eps_prismatic):
     env = qpaths_batched_env_collisions(robot, q, cuboids, Tcuboids)
     slf = qpaths_batched_self_collisions(robot, q)
     return 100 * jl + 1000 * env + 1000 * slf, jl, env, slf
+
+
+def _get_mjacs(q: torch.Tensor, robot, prismatic_joint_scaling: float = 5.0) -> torch.Tensor:
+    """[k, k, T-1]: max wrapped joint change from path a at t to path b at t+1 (cppflow/search.py:100-125)."""
+    dqs = q[:, 1:, :].unsqueeze(1) - q[:, :-1, :].unsqueeze(0)
+    if len(robot.prismatic_joint_idxs) > 0:
+        dqs = dqs.clone()
+        dqs[:, :, :, robot.prismatic_joint_idxs] *= prismatic_joint_scaling
+    return torch.abs(torch.remainder(dqs + math.pi, 2 * math.pi) - math.pi).amax(dim=3)
+
+
+def dp_search(robot, q: torch.Tensor, q_costs_external: torch.Tensor) -> torch.Tensor:
+    """The torch recurrence of cppflow/search.py:145-173 given the external cost matrix -> best path [T, d]."""
+    k, T, d = q.shape
+    costs = torch.zeros((k, T), dtype=q.dtype)
+    costs[:, 0] = q_costs_external[:, 0]
+    mjacs = _get_mjacs(q, robot)
+    memo = torch.zeros((k, T), dtype=torch.long)
+    for t in range(1, T):
+        nxt = torch.maximum(mjacs[:, :, t - 1], costs[:, t - 1].unsqueeze(0)) + q_costs_external[:, t].unsqueeze(1)
+        costs[:, t], memo[:, t] = torch.min(nxt, dim=1)
+    best = torch.zeros((T, d), dtype=q.dtype)
+    i = torch.argmin(costs[:, -1])
+    for t in range(T - 1, -1, -1):
+        best[t] = q[i, t]
+        i = memo[i, t]
+    return best

@@ -243,3 +243,29 @@ def test_c5_shape_runs(robots):
     x0, target = H.lm_problem("chain12", S, W, seed=5)
     r = rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=10, want_errors=True)
     assert bool(torch.isfinite(r["x"]).all()) and float((r["pos_err_m"] < 1e-4).float().mean()) > 0.9
+
+
+@pytest.mark.parametrize("name,k,T", [("panda", 175, 59), ("fetch", 64, 40), ("panda", 1024, 64), ("chain12", 7, 5)])
+def test_dp_search_on_device_matches_oracle(robots, name, k, T):
+    """cppf_dp_search vs the fp32 oracle restatement of cppflow/search.py:128-191: cost table and chosen candidates
+    bit-exact (same operation order, first minimal index), best path identical."""
+    from cppflow_amd.search import dp_search
+
+    rb = robots[name]
+    rng = np.random.RandomState(k + T)
+    ch = H.chain(name)
+    # k candidate paths that are noisy copies of a few smooth branches, so the optimum actually switches candidates
+    base = rng.uniform(ch.lo, ch.hi, size=(4, 1, rb.ndof)) + 0.3 * np.cumsum(rng.randn(4, T, rb.ndof) * 0.1, axis=1)
+    q = H.f32(np.clip(base[rng.randint(0, 4, size=k)] + 0.02 * rng.randn(k, T, rb.ndof), ch.lo, ch.hi))
+    ext = ((rng.rand(k, T) < 0.15) * 1000.0 + (rng.rand(k, T) < 0.1) * 100.0).astype(np.float32)
+    path, idx, costsT = rb.dp_search(dev(q), dev(ext))
+    want_idx, want_costs = H.oracle32(name).dp_search(q, ext)
+    assert np.array_equal(host(costsT).T, want_costs)
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    assert np.array_equal(host(path), q[want_idx, np.arange(T)])
+    assert len(set(want_idx.tolist())) > 1 or k < 8
+    # the reference-named entry point with the masks instead of the cost matrix
+    z = torch.zeros((k, T), dtype=torch.bool, device=DEV)
+    p2 = dp_search(rb, dev(q), z, z)
+    jl = rb.collision_masks(dev(q), only=("jlim",))  # padding unset -> all zero
+    assert p2.shape == (T, rb.ndof) and not bool(jl["jlim_mask"].any())

@@ -179,14 +179,27 @@ def _dp_search_reference_semantics(q, costs_ext):
     return path
 
 
-def test_dp_search_matches_slow_recurrence():
-    rb = get_robot("panda")
+def test_dp_search_oracle_matches_slow_and_vectorised_recurrences():
+    """The oracle's dp_search against a scalar restatement of dp_search_slow (cppflow/search.py:55-97) and the torch
+    restatement of the vectorised recurrence (cppflow/search.py:145-173), with a prismatic joint (scaled by 5, :119-121)."""
+    from cppflow_amd.robot_zoo import ROBOT_SPECS
+    from oracle import ref_torch
+    from tests import helpers as H
+
     rng = np.random.RandomState(0)
-    k, T = 6, 12
-    q = rng.uniform(-1, 1, size=(k, T, 7)).astype(np.float32)
-    ext = (rng.rand(k, T) < 0.2).astype(np.float32) * 1000
-    got = search.dp_search(rb, torch.tensor(q), None, None, q_costs=torch.tensor(ext)).numpy()
-    np.testing.assert_allclose(got, _dp_search_reference_semantics(q.astype(np.float64), ext), atol=1e-6)
+    k, T = 9, 14
+    for name, d in (("panda", 7), ("fetch", 8)):
+        q = rng.uniform(-1, 1, size=(k, T, d)).astype(np.float32)
+        ext = ((rng.rand(k, T) < 0.2) * 1000 + (rng.rand(k, T) < 0.2) * 100).astype(np.float32)
+        for o in (H.oracle64(name), H.oracle32(name)):
+            idx, _ = o.dp_search(q, ext)
+            path = q[idx, np.arange(T)]
+            got_t = ref_torch.dp_search(ref_torch.TorchRobot(ROBOT_SPECS[name]()), torch.tensor(q), torch.tensor(ext)).numpy()
+            np.testing.assert_allclose(path, got_t, atol=0)
+            if name == "panda":
+                np.testing.assert_allclose(path, _dp_search_reference_semantics(q.astype(np.float64), ext), atol=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        search.dp_search(get_robot("panda"), torch.zeros((2, 3, 7)), None, None, q_costs=torch.zeros((2, 3)))
 
 
 def test_seed_shard_and_packed_layout():
