@@ -269,3 +269,72 @@ def test_dp_search_on_device_matches_oracle(robots, name, k, T):
     p2 = dp_search(rb, dev(q), z, z)
     jl = rb.collision_masks(dev(q), only=("jlim",))  # padding unset -> all zero
     assert p2.shape == (T, rb.ndof) and not bool(jl["jlim_mask"].any())
+
+
+def test_edge_sizes(robots):
+    """Empty, single-row, single-waypoint and ragged inputs (the reference's functions accept any k, T >= 1)."""
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
+
+    rb = robots["panda"]
+    obs = obstacle_arrays(PANDA_2CUBES_OBSTACLES)
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    empty = torch.empty((0, 7), device=DEV)
+    tgt1 = rb.forward_kinematics(dev(H.random_configs("panda", 1, seed=0)))
+    assert rb.jacobian(empty).shape == (0, 6, 7) and rb.self_collision_distances(empty).shape == (0, rb.n_collision_pairs)
+    r = rb.lm_pose_steps(empty, tgt1, 1e-6, 3.5, 0.35, n_steps=3, want_errors=True, want_collisions=True)
+    assert r["x"].shape == (0, 7) and r["ext_cost"].shape == (0,)
+    assert rb.collision_masks(torch.empty((0, 5, 7), device=DEV))["self_mask"].shape == (0, 5)
+    # W = 1 (a single target for every row), n = 1, and n = 257 (one lane into a second workgroup)
+    for n in (1, 257):
+        x = dev(H.random_configs("panda", n, seed=n))
+        r = rb.lm_pose_steps(x, tgt1, 1e-6, 3.5, 0.35, n_steps=2, want_errors=True, want_collisions=True)
+        want = H.oracle64("panda").lm_steps(host(x), np.tile(host(tgt1), (n, 1)), 2)
+        ok = np.abs(want - host(x)).max(axis=1) < 0.5
+        if ok.any():
+            assert np.abs(host(r["x"]) - want)[ok].max() < 5e-3
+        assert r["self_mask"].shape == (n,) and bool(torch.isfinite(r["x"]).all())
+        m = H.oracle32("panda").masks(host(r["x"]), *H.box_corners([c for c, _ in obs], [T for _, T in obs]), None, None)
+        assert np.array_equal(r["self_mask"].cpu().numpy(), m["self_mask"]) and np.array_equal(r["env_mask"].cpu().numpy(), m["env_mask"])
+    # dp_search with a single candidate / a single timestep
+    q = dev(H.random_configs("panda", 6, seed=3)).reshape(1, 6, 7)
+    path, idx, _ = rb.dp_search(q, torch.zeros((1, 6), device=DEV))
+    assert torch.equal(path, q[0]) and idx.tolist() == [0] * 6
+    q = dev(H.random_configs("panda", 5, seed=4)).reshape(5, 1, 7)
+    ext = dev([[3.0], [1.0], [2.0], [1.0], [5.0]])
+    path, idx, _ = rb.dp_search(q, ext)
+    assert idx.tolist() == [1] and torch.equal(path[0], q[1, 0])  # first minimal index
+    # seed_validity with W = 1: no joint deltas
+    sv = rb.seed_validity(dev(H.random_configs("panda", 3, seed=5)), tgt1)
+    assert sv.shape == (3, 4) and float(sv[:, 2:].abs().max()) == 0.0
+    rb.set_obstacles([], [])
+
+
+def test_c5_full_size(robots):
+    """BASELINE config 5 at full size on one GPU: 12-DoF chain, 4096 seeds x 512 waypoints = 2 097 152 rows, 2 cuboids.
+    Checked by sampling: 4096 random rows of the result against the oracle evaluated at the kernel's own x."""
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
+
+    rb = robots["chain12"]
+    S, W = 4096, 512
+    obs = obstacle_arrays(PANDA_2CUBES_OBSTACLES)
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    ch = H.chain("chain12")
+    g = torch.Generator().manual_seed(0)
+    lo, hi = torch.tensor(ch.lo, dtype=torch.float32), torch.tensor(ch.hi, dtype=torch.float32)
+    q_star = lo + (hi - lo) * torch.rand((W, 12), generator=g)
+    target = rb.forward_kinematics(q_star.to(DEV))
+    x0 = torch.minimum(torch.maximum(q_star[None] + 0.1 * torch.randn((S, W, 12), generator=g), lo), hi).reshape(S * W, 12).to(DEV)
+    r = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=10, want_errors=True, want_collisions=True, want_min_dists=True)
+    assert float((r["pos_err_m"] < 1e-4).float().mean()) > 0.9
+    rows = torch.randint(0, S * W, (4096,), generator=g)
+    x = host(r["x"][rows.to(DEV)])
+    tgt = host(target)[(rows % W).numpy()]
+    pe, re = H.oracle64("chain12").pose_metrics_exact(x, tgt)
+    assert np.abs(host(r["pos_err_m"][rows.to(DEV)]) - pe).max() < 1e-5
+    assert np.abs(host(r["rot_err_rad"][rows.to(DEV)]) - re).max() < 1e-5
+    lo_b, hi_b = H.box_corners([c for c, _ in obs], [T for _, T in obs])
+    m = H.oracle32("chain12").masks(x, lo_b, hi_b, None, None)
+    assert np.array_equal(r["self_mask"][rows.to(DEV)].cpu().numpy(), m["self_mask"])
+    assert np.array_equal(r["env_mask"][rows.to(DEV)].cpu().numpy(), m["env_mask"])
+    assert np.array_equal(host(r["min_self"][rows.to(DEV)]), m["min_self"])
+    rb.set_obstacles([], [])
