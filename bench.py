@@ -121,7 +121,7 @@ def cpu_baseline_torch(robot_name, obstacles, d, W, K, budget_s=12.0):
         if t_probe is None or tt < t_probe:
             best_threads, t_probe = th, tt
     torch.set_num_threads(best_threads)
-    S_cpu = int(max(32, min(1024, 32 * budget_s / max(t_probe, 1e-6))))
+    S_cpu = int(max(32, min(8192, 32 * budget_s / max(t_probe, 1e-6))))
     t = run(S_cpu)
     threads = torch.get_num_threads()
     return {
@@ -135,7 +135,7 @@ def cpu_baseline_torch(robot_name, obstacles, d, W, K, budget_s=12.0):
     }
 
 
-def cpu_baseline_c(robot_name, obstacles, d, W, K, budget_s=8.0):
+def cpu_baseline_c(robot_name, obstacles, d, W, K, budget_s=6.0):
     """The C restatement (oracle/lmik_oracle.c, canonical fp32 build, LU solve in reference order), OpenMP over rows."""
     from cppflow_amd.robot_model import canonicalize
     from cppflow_amd.robot_zoo import ROBOT_SPECS
@@ -159,7 +159,7 @@ def cpu_baseline_c(robot_name, obstacles, d, W, K, budget_s=8.0):
         return time.perf_counter() - t0
 
     t_probe = run(64)
-    S_cpu = int(max(64, min(16384, 64 * budget_s / max(t_probe, 1e-6))))
+    S_cpu = int(max(64, min(32768, 64 * budget_s / max(t_probe, 1e-6))))
     t = run(S_cpu)
     return {
         "value": S_cpu * W * K / t,
