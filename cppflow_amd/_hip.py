@@ -55,6 +55,16 @@ class LmParams(ctypes.Structure):
     ]
 
 
+class FullParams(ctypes.Structure):
+    """struct cppf_full_params"""
+
+    _fields_ = [(k, _f) for k in ("lm_lambda", "alpha_position", "alpha_rotation", "alpha_differencing",
+                                  "alpha_differencing_prismatic_scaling", "alpha_virtual_configs", "alpha_self_collision",
+                                  "alpha_env_collision")] + [(k, _i32) for k in (
+        "use_pose", "use_differencing", "use_virtual_configs", "n_virtual_configs", "use_self_collisions",
+        "use_env_collisions")]  # fmt: skip
+
+
 class LmOutputs(ctypes.Structure):
     """struct cppf_lm_outputs (device pointers; 0 = not requested)"""
 
@@ -100,6 +110,10 @@ SIGNATURES = {
     ),
     "cppf_pose_error_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "cppf_seed_validity": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cppf_lm_full_step": (
+        ctypes.c_int,
+        [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FullParams), _vp, _vp, _vp, _vp, _vp],
+    ),
     "cppf_dp_search": (
         ctypes.c_int,
         [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],

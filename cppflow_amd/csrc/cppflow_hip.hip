@@ -649,6 +649,356 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
     }
 }
 
+// ---- coupled ("full") LM step: cppflow/optimization.py:95-144 + LmResidualFns.get_r_and_J (optimization_utils.py:486-731) -------
+// The reference stacks pose / differencing / virtual-config / collision residuals of ONE trajectory into a dense
+// J [(6T + d(T-1) + ...) x dT], forms the dense dT x dT normal matrix and factors it (O((dT)^3)).  Structurally
+// A = J^T J + lambda I is block-tridiagonal with d x d blocks: pose and collision rows only touch their own waypoint's
+// block, the differencing row (t,j) = a_j * wrap(x[t+1,j] - x[t,j]) couples (t,j) with (t+1,j) through -a_j^2 on the
+// off-diagonal, virtual-config rows and lambda add to the diagonal.  So:
+//   full_blocks_kernel  (one lane per (seed, waypoint) row): the waypoint-local part  M_t = sum Js^T Js + sum alpha^2 g g^T,
+//                        m_t = Js^T es - sum alpha^2 dist g   (g = gradient of a colliding capsule distance)
+//   full_solve_kernel   (one lane per seed): adds the analytic differencing / virtual-config / lambda terms and runs the
+//                        block-tridiagonal elimination D'_t = A_tt - E G_{t-1} E,  G_t = D'_t^-1  (E = -diag(a^2)) forward and
+//                        back -- O(T d^3) per trajectory, any number of trajectories at once (the reference: one, :128).
+
+struct FullK {
+    float lm_lambda, a_pos, a_rot, a_diff, a_diff_pris, a_vq, a_self, a_env;
+    int32_t use_pose, use_diff, use_vq, n_vq, use_self, use_env;
+    int32_t S, W;
+};
+
+// gradient of a point rigidly attached to moving link `link`, projected on n:  n . d(c)/dq_j  for every joint j
+template <class RB>
+__device__ __forceinline__ void point_grad(const RB& rb, int link, const float (&n)[3], const float (&c)[3],
+                                           const float (&ax)[RB::D][3], const float (&og)[RB::D][3], float sign,
+                                           float (&g)[RB::D]) {
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        float v;
+        if (!rb.pris(j)) {
+            const float rx = c[0] - og[j][0], ry = c[1] - og[j][1], rz = c[2] - og[j][2];
+            const float cx = ax[j][1] * rz - ax[j][2] * ry, cy = ax[j][2] * rx - ax[j][0] * rz,
+                        cz = ax[j][0] * ry - ax[j][1] * rx;
+            v = n[0] * cx + n[1] * cy + n[2] * cz;
+        } else {
+            v = n[0] * ax[j][0] + n[1] * ax[j][1] + n[2] * ax[j][2];
+        }
+        g[j] += (j <= link) ? sign * v : 0.f;
+    }
+}
+
+// M (upper triangle, row-major i <= j) += w * g g^T ;  m += wm * g
+template <int D>
+__device__ __forceinline__ void rank1(float (&M)[D * (D + 1) / 2], float (&m)[D], const float (&g)[D], float w, float wm) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float wi = w * g[i];
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            M[k] = CPPF_FMA(wi, g[j], M[k]);
+            ++k;
+        }
+        m[i] = CPPF_FMA(wm, g[i], m[i]);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ target,
+                                                             float* __restrict__ blocks) {
+    extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    constexpr int NT = D * (D + 1) / 2;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    const size_t n = (size_t)prm.S * prm.W;
+    if (row >= n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3], M[NT], m[D];
+    load_x<D>(x, row, q);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) M[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) m[j] = 0.f;
+
+    // FK with joint axes / origins, capsule end points to LDS (same canonical chain as everywhere else)
+    frame_identity(R, p);
+    for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, rb.pris(j), q[j]);
+        for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
+            float w0[3], w1[3];
+            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
+            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lds[(c * 6 + k) * kBlock + tid] = w0[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+            }
+        }
+    }
+
+    if (prm.use_pose) {  // optimization_utils.py:503-543
+        float Re[9], pe[3], Rt[9], tt[3], J[6][D], e[6];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Re[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pe[k] = p[k];
+        fk_fixed_ee(rb, Re, pe);
+        load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+        pose_error(Rt, tt, Re, pe, e);
+        jacobian_from_axes<RB>(rb, pe, ax, og, J);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float a = i < 3 ? prm.a_rot : prm.a_pos;
+            float g[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) g[j] = a * J[i][j];
+            rank1<D>(M, m, g, 1.f, a * e[i]);
+        }
+    }
+    if (prm.use_self) {  // :645-680: rows where -alpha * dist > 0
+        const float w = prm.a_self * prm.a_self;
+        for (int pi = 0; pi < co.npairs; ++pi) {
+            const int a = co.pair_a[pi], b = co.pair_b[pi];
+            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            const float sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
+            if (dist < 0.f) {
+                float nrm[3] = {0.f, 0.f, 0.f}, g[D];
+                if (sd > 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) g[j] = 0.f;
+                point_grad<RB>(rb, co.cap_link[a], nrm, c1, ax, og, 1.f, g);
+                point_grad<RB>(rb, co.cap_link[b], nrm, c2, ax, og, -1.f, g);
+                rank1<D>(M, m, g, w, -w * dist);
+            }
+        }
+    }
+    if (prm.use_env) {  // :685-727
+        const float w = prm.a_env * prm.a_env;
+        for (int o = 0; o < co.nobs; ++o)
+            for (int c = 0; c < co.ncaps; ++c) {
+                float w0[3], w1[3], cs[3], cb[3];
+                lds_capsule(lds, tid, c, w0, w1);
+                const float sd = seg_box_closest(w0, w1, co.obs_lo[o], co.obs_hi[o], cs, cb);
+                const float dist = sd - co.cap_r[c];
+                if (dist < 0.f) {
+                    float nrm[3] = {0.f, 0.f, 0.f}, g[D];
+                    if (sd > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) g[j] = 0.f;
+                    point_grad<RB>(rb, co.cap_link[c], nrm, cs, ax, og, 1.f, g);
+                    rank1<D>(M, m, g, w, -w * dist);
+                }
+            }
+    }
+    float* o = blocks + row * (NT + D);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) o[k] = M[k];
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[NT + j] = m[j];
+}
+
+// inverse of a symmetric positive definite D x D matrix (full storage in, full storage out) by Cholesky; pivots floored
+template <int D>
+__device__ __forceinline__ void spd_inverse(const float (&A)[D][D], float floor_v, float (&G)[D][D]) {
+    float L[D][D], Li[D][D], inv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[j][k], L[j][k], s);
+        s = fmaxf(s, floor_v);
+        inv[j] = __frsqrt_rn(s);
+        L[j][j] = s * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            float t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = CPPF_FMA(-L[i][k], L[j][k], t);
+            L[i][j] = t * inv[j];
+        }
+    }
+    // Li = L^-1 (lower triangular)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        Li[j][j] = inv[j];
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) t = CPPF_FMA(-L[i][k], Li[k][j], t);
+            Li[i][j] = t * inv[i];
+        }
+    }
+    // G = Li^T Li
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < D; ++k) t = CPPF_FMA(Li[k][i], Li[k][j], t);
+            G[i][j] = t;
+            G[j][i] = t;
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                        const float* __restrict__ xv, const float* __restrict__ blocks,
+                                                        float* __restrict__ workG, float* __restrict__ worky,
+                                                        float* __restrict__ x_out) {
+    constexpr int NT = D * (D + 1) / 2;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= prm.S) return;
+    const int T = prm.W;
+    const size_t base = (size_t)s * T;
+    float a2[D];  // a_j^2 = (alpha_differencing * prismatic scaling)^2  (optimization_utils.py:607-612)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float a = prm.use_diff ? prm.a_diff * (((ch.pris_mask >> j) & 1u) ? prm.a_diff_pris : 1.f) : 0.f;
+        a2[j] = a * a;
+    }
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+
+    float G[D][D], y[D], xp[D], xc[D], xn[D];
+    load_x<D>(x, base, xc);
+    // ---- forward elimination
+    for (int t = 0; t < T; ++t) {
+        const float* blk = blocks + (base + t) * (NT + D);
+        float A[D][D], b[D];
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    const float v = blk[k++];
+                    A[i][j] = v;
+                    A[j][i] = v;
+                }
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = blk[NT + j];
+        }
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        if (has_next) load_x<D>(x, base + t + 1, xn);
+        const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            A[j][j] += cnt * a2[j] + (vq ? beta2 : 0.f) + prm.lm_lambda;
+            // J^T r of the differencing rows: +a^2 w_t at (t,j), -a^2 w_{t-1} at (t,j)   (w = wrapped joint change)
+            if (has_next) b[j] = CPPF_FMA(a2[j], wrap_pi(xn[j] - xc[j]), b[j]);
+            if (has_prev) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xp[j]), b[j]);
+        }
+        if (vq) {  // r = beta * wrap(x - x_virtual), J = -beta I  (optimization_utils.py:430-484)
+            float v[D];
+            if (xv) load_x<D>(xv, base + t, v);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? wrap_pi(xc[j] - v[j]) : 0.f, b[j]);
+        }
+        if (has_prev) {
+            // D' = A - E G E ,  y = b - E G y_prev   with E = -diag(a2)
+            float Gy[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    acc = CPPF_FMA(G[i][j], y[j], acc);
+                    A[i][j] = CPPF_FMA(-(a2[i] * a2[j]), G[i][j], A[i][j]);
+                }
+                Gy[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[i] = CPPF_FMA(a2[i], Gy[i], b[i]);  // b - (-a2) * (G y_prev)
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[i] = b[i];
+        }
+        spd_inverse<D>(A, prm.lm_lambda, G);
+        float* gout = workG + (base + t) * NT;
+        float* yout = worky + (base + t) * D;
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) gout[k++] = G[i][j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) yout[j] = y[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            xp[j] = xc[j];
+            xc[j] = xn[j];
+        }
+    }
+    // ---- back substitution: delta_t = G_t (y_t - E delta_{t+1}) = G_t (y_t + a2 .* delta_{t+1})
+    float dl[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) dl[j] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float* gin = workG + (base + t) * NT;
+        const float* yin = worky + (base + t) * D;
+        float rhs[D], Gt[D][D];
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    const float v = gin[k++];
+                    Gt[i][j] = v;
+                    Gt[j][i] = v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) rhs[j] = (t + 1 < T) ? CPPF_FMA(a2[j], dl[j], yin[j]) : yin[j];
+        float nd[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc = CPPF_FMA(Gt[i][j], rhs[j], acc);
+            nd[i] = acc;
+        }
+        float xr[D];
+        load_x<D>(x, base + t, xr);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            dl[j] = nd[j];
+            xr[j] += nd[j];  // optimization.py:113: x + delta_x
+        }
+        store_x<D>(x_out, base + t, xr);
+    }
+}
+
 // ---- dp_search (cppflow/search.py:100-191) -----------------------------------------------------------------------------------
 // costs[b,t] = min_a { max(mjac(a->b,t-1), costs[a,t-1]) + ext[b,t] }, first minimal a recorded; one launch per timestep
 // (the recurrence is sequential in t; each step is a k x k (min,max) product).  The reference materialises
@@ -993,6 +1343,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
             co.cap_p1[c][k] = desc->cap_p1[c][k];
         }
         co.cap_r[c] = desc->cap_r[c];
+        co.cap_link[c] = (int8_t)desc->cap_link[c];
     }
     // cap_begin[l+1] = first capsule whose link >= l
     for (int l = -1; l <= d; ++l) {
@@ -1214,6 +1565,47 @@ int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* tar
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((seed_validity_kernel<D>), dim3(S), dim3(64), 0, st,
                                                         robot->chain, robot->coll, S, W, x, target, out));
+    return check_launch(robot);
+}
+
+int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* target, const float* virtual_configs, int S,
+                      int W, const cppf_full_params* params, float* work_blocks, float* work_G, float* work_y,
+                      float* x_out, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(params, "params is NULL");
+    CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
+    CPPF_REQUIRE(params->lm_lambda > 0.f, "lm_lambda must be > 0");
+    CPPF_REQUIRE(!params->use_virtual_configs || (params->n_virtual_configs > 0 && 2 * params->n_virtual_configs < W),
+                 "2 * n_virtual_configs must be < number of waypoints (optimization_utils.py:449-451)");
+    CPPF_REQUIRE(x_out != x_in, "x_out must not alias x_in (the back substitution reads x_in)");
+    if (S == 0) return CPPF_OK;
+    CPPF_REQUIRE(x_in && target && work_blocks && work_G && work_y && x_out, "NULL pointer");
+    const size_t n = (size_t)S * W;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    FullK prm;
+    prm.lm_lambda = params->lm_lambda;
+    prm.a_pos = params->alpha_position;
+    prm.a_rot = params->alpha_rotation;
+    prm.a_diff = params->alpha_differencing;
+    prm.a_diff_pris = params->alpha_differencing_prismatic_scaling;
+    prm.a_vq = params->alpha_virtual_configs;
+    prm.a_self = params->alpha_self_collision;
+    prm.a_env = params->alpha_env_collision;
+    prm.use_pose = params->use_pose;
+    prm.use_diff = params->use_differencing;
+    prm.use_vq = params->use_virtual_configs;
+    prm.n_vq = params->n_virtual_configs;
+    prm.use_self = params->use_self_collisions;
+    prm.use_env = params->use_env_collisions;
+    prm.S = S;
+    prm.W = W;
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((full_blocks_kernel<D>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st,
+                                       robot->chain, robot->coll, prm, x_in, target, work_blocks));
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((full_solve_kernel<D>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,
+                                       robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out));
     return check_launch(robot);
 }
 

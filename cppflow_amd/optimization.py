@@ -4,9 +4,10 @@ step (`:61-92`), the loop (`:147-373`) and the entry point (`:376-426`).
 What runs where
   * `levenberg_marquardt_only_pose` = ONE launch of the fused kernel with K = 1 and no clamp (x_new, and J / e scaled
     exactly as the reference returns them when `return_residual=True`).
-  * `run_lm_alternating_loss` keeps the reference's Python control flow (termination rules, TL bookkeeping) around
-    launches of the fused kernel; the coupled "differencing" step (`levenberg_marquardt_full`, `:95-144`) is SURVEY.md
-    8(f) item 1 ("next") and is not built: where the reference would take it, `on_pose_valid` decides (default "stop").
+  * `levenberg_marquardt_full` = the coupled step (`:95-144`) as a block-tridiagonal solve per trajectory on the device
+    (`cppf_lm_full_step`), for any number of seeds.
+  * `run_lm_alternating_loss` keeps the reference's Python control flow (alternation rule, TL convergence, termination)
+    around those launches.
   * `run_lm_pose_refinement` is the batched form the MI355X path is built for: all S seeds x W waypoints, K fused
     iterations, per-seed validity and collision masks / search cost in the same launch.
 """
@@ -94,9 +95,20 @@ def levenberg_marquardt_only_pose(
     return res["x"]
 
 
-def levenberg_marquardt_full(*_args, **_kwargs):
-    raise NotImplementedError(
-        "the coupled differencing step (cppflow/optimization.py:95-144) is SURVEY.md 8(f) item 1 and is not built yet"
+def levenberg_marquardt_full(
+    opt_problem: OptimizationProblem,
+    opt_state: OptimizationState,
+    opt_params: OptimizationParameters,
+    return_residual: bool = False,
+):
+    """The coupled LM step (cppflow/optimization.py:116-144): pose / differencing / virtual-config / capsule-collision
+    residuals of whole trajectories, solved as a block-tridiagonal system per trajectory on the device
+    (`cppf_lm_full_step`).  Unlike the reference (`assert parallel_count == 1`, :128) any number of seeds is accepted:
+    opt_state.x is [parallel_count * W, ndof] and every trajectory is smoothed independently in the same launch."""
+    assert not return_residual, "the dense residual / Jacobian are never formed on the device"
+    opt_problem.problem.bind_obstacles()
+    return opt_problem.robot.lm_full_step(
+        opt_state.x, _unstacked_target(opt_problem), opt_params, virtual_configs=opt_params.virtual_configs
     )
 
 
@@ -113,53 +125,81 @@ def run_lm_alternating_loss(
     verbosity: int = 0,
     save_images: bool = False,
     results_df: Optional[Dict] = None,
-    on_pose_valid: str = "stop",
-    fused_steps: int = 1,
+    on_pose_valid: str = "differencing",
 ):
-    """The reference's loop (cppflow/optimization.py:147-373) with its termination rules, driving fused launches.
+    """The alternating loop of cppflow/optimization.py:147-373 with its bookkeeping and termination rules.
 
-    Every iteration: { pose-only step ; clamp } (`fused_steps` of them per launch, 1 = the reference's cadence), then
-    `x_is_valid`.  When both pose flags are valid the reference switches to the differencing step; that step is not
-    built, so `on_pose_valid` = "stop" ends the loop there and "continue" keeps taking pose steps."""
+    Per iteration: if both pose flags are valid take the coupled differencing step (virtual configs := current x, :253),
+    else a pose-only step; clamp; evaluate `x_is_valid`; TL-convergence (:275-297) and termination (:326-358) as in the
+    reference.  `on_pose_valid` = "stop" / "continue" replace the differencing branch by stopping / more pose steps."""
     assert not return_residuals and not save_images and results_df is None, "debug outputs are not supported"
-    assert on_pose_valid in ("stop", "continue")
+    assert on_pose_valid in ("differencing", "stop", "continue")
     if tmax_sec is None:
         assert (max_n_steps is not None) and (return_if_valid_after_n_steps is not None)
         assert return_if_valid_after_n_steps <= max_n_steps
     if max_n_steps is None:
         assert tmax_sec is not None
         max_n_steps = 10**6
-    del params_diff
     robot = opt_problem.robot
     target = _unstacked_target(opt_problem)
     printc = print if verbosity > 1 else (lambda *a, **k: None)
+    W = opt_problem.n_timesteps
+    # copies: the loop overwrites virtual_configs (the reference copies for the same reason, :184-187)
+    params_diff = OptimizationParameters(**params_diff.__dict__)
+    params_pose = OptimizationParameters(**params_pose.__dict__)
 
     def calc_TL(qpath):
         rev, _ = robot.split_configs_to_revolute_and_prismatic(qpath)
+        if opt_problem.parallel_count > 1:  # per-seed joint changes: do not difference across trajectory boundaries
+            rev = rev.view(opt_problem.parallel_count, W, -1)
+            return float(torch.stack([angular_changes(r).abs().sum() for r in rev]).sum().item())
         return angular_changes(rev).abs().sum().item()
 
+    tls_post_differencing = []
     last_valid, last_valid_idx, valid_seed_idx = None, -1, 0
     pose_pos_valid, pose_rot_valid = True, False  # the reference's initial values (:218-219): lead with a pose step
+    converged = False
     t0 = time()
     i = -1
     for i in range(max_n_steps):
+        took_differencing = False
         if pose_pos_valid and pose_rot_valid and on_pose_valid == "stop":
-            printc("  pose is valid; the differencing step is not built -- stopping")
+            printc("  pose is valid -- stopping (on_pose_valid='stop')")
             break
-        printc(f"i: {i}  --> only pose")
-        res = robot.lm_pose_steps(
-            opt_state.x, target, params_pose.lm_lambda, params_pose.alpha_position, params_pose.alpha_rotation,
-            n_steps=fused_steps, clamp=True,
-        )  # fmt: skip
-        opt_state.x = res["x"]
-        opt_state.n_steps += fused_steps
-        printc(f"  tl: {calc_TL(opt_state.x)}")
+        if pose_pos_valid and pose_rot_valid and on_pose_valid == "differencing":
+            printc(f"i: {i}  ----> differencing")
+            params_diff.virtual_configs = opt_state.x.clone()  # :253
+            x_new = levenberg_marquardt_full(opt_problem, opt_state, params_diff)
+            took_differencing = True
+        else:
+            printc(f"i: {i}  --> only pose")
+            x_new = levenberg_marquardt_only_pose(opt_problem, opt_state, params_pose)
+        opt_state.x = clamp_to_joint_limits(robot, x_new)  # :259
+        opt_state.n_steps += 1
+
+        tl_new = calc_TL(opt_state.x)
+        printc(f"  tl: {tl_new}")
+        stop_now = False
+        if took_differencing:  # :275-297
+            if not converged and len(tls_post_differencing) > 0:
+                diff = abs(tl_new - tls_post_differencing[-1])
+                if diff < convergence_threshold:
+                    converged = True
+                    if last_valid_idx == i - 1:
+                        stop_now = True
+            tls_post_differencing.append(tl_new)
+        if stop_now:
+            break
+
         x_sol, seed_idx, flags = x_is_valid(
             opt_problem.problem, opt_problem.constraints, target, opt_state.x, opt_problem.parallel_count, verbosity=verbosity
         )
         pose_pos_valid, pose_rot_valid = flags[0], flags[1]
         if x_sol is not None:
             last_valid_idx, last_valid, valid_seed_idx = i, opt_state.x.clone(), seed_idx
+            if converged:
+                printc(make_text_green_or_red("  x is valid and TL has converged, exiting", True))
+                break
             printc(make_text_green_or_red("  x is valid, continuing", True))
         if tmax_sec is not None and time() - t0 > tmax_sec:
             if last_valid is not None:
@@ -183,7 +223,7 @@ def run_lm_optimization(
     parallel_count: int = 1,
     results_df: Optional[Dict] = None,
     verbosity: int = 1,
-    on_pose_valid: str = "stop",
+    on_pose_valid: str = "differencing",
 ) -> OptimizationResult:
     """Optimise a trajectory (or `parallel_count` seeds at once): x_seed is [parallel_count * W, ndof]
     (cppflow/optimization.py:376-426).  The target path is NOT stacked: rows index it modulo W."""

@@ -366,6 +366,46 @@ class Robot:
         )
         return pe, re
 
+    def lm_full_step(self, x: torch.Tensor, target: torch.Tensor, opt_params, virtual_configs: Optional[torch.Tensor] = None,
+                     x_out: Optional[torch.Tensor] = None) -> torch.Tensor:  # fmt: skip
+        """One coupled LM step (levenberg_marquardt_full, cppflow/optimization.py:95-144) for every trajectory in
+        x [S*W, d]; target [W,7].  `opt_params` is an OptimizationParameters (e.g. ALT_LOSS_V2_1_DIFF)."""
+        x = self._x2d(x)
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0
+        p = opt_params
+        assert not p.pose_do_scale_down_satisfied and not p.differencing_do_ignore_satisfied, "option not implemented"
+        assert not p.differencing_do_scale_satisfied, "option not implemented"
+        xv = None
+        if virtual_configs is not None and p.use_virtual_configs and virtual_configs.numel() > 0:
+            xv = self._x2d(virtual_configs, "virtual_configs")
+            assert xv.shape == x.shape, "virtual_configs must have the shape of x (optimization_utils.py:433)"
+
+        def f(v):
+            return 0.0 if v is None else float(v)
+
+        prm = _hip.FullParams(f(p.lm_lambda), f(p.alpha_position), f(p.alpha_rotation), f(p.alpha_differencing),
+                              f(p.alpha_differencing_prismatic_scaling), f(p.alpha_virtual_configs),
+                              f(p.alpha_self_collision), f(p.alpha_env_collision), int(bool(p.use_pose)),
+                              int(bool(p.use_differencing)), int(bool(p.use_virtual_configs)), int(p.n_virtual_configs or 0),
+                              int(bool(p.use_self_collisions)), int(bool(p.use_env_collisions)))  # fmt: skip
+        d = self.ndof
+        nt = d * (d + 1) // 2
+        dev = x.device
+        blocks = torch.empty(n * (nt + d), dtype=torch.float32, device=dev)
+        G = torch.empty(n * nt, dtype=torch.float32, device=dev)
+        y = torch.empty(n * d, dtype=torch.float32, device=dev)
+        if x_out is None:
+            x_out = torch.empty_like(x)
+        _hip.check(
+            _hip.lib().cppf_lm_full_step(
+                self._handle(dev), x.data_ptr(), target.data_ptr(), xv.data_ptr() if xv is not None else None, n // W, W,
+                ctypes.byref(prm), blocks.data_ptr(), G.data_ptr(), y.data_ptr(), x_out.data_ptr(), _stream_ptr(dev),
+            )  # fmt: skip
+        )
+        return x_out
+
     def dp_search(self, q: torch.Tensor, ext_cost: torch.Tensor, prismatic_joint_scaling: float = 5.0):
         """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191."""
         q = _require_device_tensor(q, "q")

@@ -150,6 +150,28 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
 int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
                        void* stream);
 
+/* cppflow/lm_hyper_parameters.py:14-56: the fields the coupled step reads (values of ALT_LOSS_V2_1_DIFF at :86-118) */
+typedef struct cppf_full_params {
+    float lm_lambda;
+    float alpha_position, alpha_rotation;        /* pose block (only when use_pose) */
+    float alpha_differencing;                    /* 0.00375 */
+    float alpha_differencing_prismatic_scaling;  /* 1.0 */
+    float alpha_virtual_configs;                 /* multiplies alpha_differencing */
+    float alpha_self_collision, alpha_env_collision; /* 0.01, 0.01 */
+    int32_t use_pose, use_differencing, use_virtual_configs, n_virtual_configs, use_self_collisions, use_env_collisions;
+} cppf_full_params;
+
+/* levenberg_marquardt_full (cppflow/optimization.py:95-144) with the residual / Jacobian of LmResidualFns.get_r_and_J
+ * (cppflow/optimization_utils.py:486-731; the "satisfied" scaling / filtering options, off in both presets, are not
+ * implemented): one coupled LM step for each of S trajectories x_in [S*W, d] (the reference: one trajectory, :128).
+ * target [W,7]; virtual_configs [S*W, d] or NULL (= x_in, which is what the loop sets at optimization.py:253).
+ * Obstacles are those of cppf_set_obstacles.  The normal matrix is never formed densely: it is block-tridiagonal and is
+ * eliminated per trajectory.  Workspace (device): work_blocks [S*W * (d(d+1)/2 + d)], work_G [S*W * d(d+1)/2],
+ * work_y [S*W * d] floats.  x_out [S*W, d] must not alias x_in. */
+int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* target, const float* virtual_configs, int S,
+                      int W, const cppf_full_params* params, float* work_blocks, float* work_G, float* work_y,
+                      float* x_out, void* stream);
+
 /* dp_search(robot, q, ...) of cppflow/search.py:128-191 given the external cost matrix q_costs_external [k,T]
  * (search.py:146-150, the `ext_cost` output of cppf_collision_masks / cppf_lm_pose_steps): the min-max dynamic programme
  * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,

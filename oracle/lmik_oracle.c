@@ -634,8 +634,9 @@ void orc_pose_metrics_exact(const void* h, const double* x, const double* target
 static inline REAL dot3(const REAL* a, const REAL* b) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
 static inline REAL clamp01(REAL v) { return v < 0 ? (REAL)0 : (v > 1 ? (REAL)1 : v); }
 
-/* closest distance between segments P1Q1 and P2Q2 (non-degenerate), Ericson "Real-Time Collision Detection" 5.1.9 */
-static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2) {
+/* closest distance between segments P1Q1 and P2Q2 (non-degenerate), Ericson "Real-Time Collision Detection" 5.1.9;
+ * also returns the closest points c1 (on P1Q1) and c2 (on P2Q2) */
+static REAL seg_seg_closest(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2, REAL* c1, REAL* c2) {
     REAL d1[3], d2[3], rr[3];
     for (int i = 0; i < 3; ++i) {
         d1[i] = Q1[i] - P1[i];
@@ -655,8 +656,17 @@ static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const R
         s = clamp01((b - c) * inv_a);
     }
     REAL df[3];
-    for (int i = 0; i < 3; ++i) df[i] = FMA(d1[i], s, P1[i]) - FMA(d2[i], t, P2[i]);
+    for (int i = 0; i < 3; ++i) {
+        c1[i] = FMA(d1[i], s, P1[i]);
+        c2[i] = FMA(d2[i], t, P2[i]);
+        df[i] = c1[i] - c2[i];
+    }
     return SQRT(dot3(df, df));
+}
+
+static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2) {
+    REAL c1[3], c2[3];
+    return seg_seg_closest(P1, Q1, P2, Q2, c1, c2);
 }
 
 /* g(t) = 1/2 d/dt dist^2(P + t D, box) = sum_i D_i * (x_i - clamp(x_i, lo_i, hi_i)) : nondecreasing, piecewise linear */
@@ -674,7 +684,7 @@ static REAL seg_box_g(const REAL* P, const REAL* D, const REAL* lo, const REAL* 
  * dist^2 along the segment is convex and piecewise quadratic; its half-derivative g is evaluated at t = 0, t = 1 and at
  * the (clamped) parameters where a coordinate crosses a box face; the minimiser is the root of g, bracketed by the
  * largest candidate with g <= 0 and the smallest with g >= 0, between which g is linear. */
-static REAL seg_box_dist(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi) {
+static REAL seg_box_closest(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi, REAL* cs, REAL* cb) {
     REAL D[3], cand[8], gv[8];
     for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
     cand[0] = 0;
@@ -709,9 +719,16 @@ static REAL seg_box_dist(const REAL* P0, const REAL* P1, const REAL* lo, const R
     for (int i = 0; i < 3; ++i) {
         const REAL x = FMA(D[i], t, P0[i]);
         const REAL cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
+        cs[i] = x;
+        cb[i] = cl;
         ex[i] = x - cl;
     }
     return SQRT(dot3(ex, ex));
+}
+
+static REAL seg_box_dist(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi) {
+    REAL cs[3], cb[3];
+    return seg_box_closest(P0, P1, lo, hi, cs, cb);
 }
 
 static void capsule_endpoints(const orc_robot* rb, const REAL* q, REAL (*w0)[3], REAL (*w1)[3]) {
@@ -940,3 +957,270 @@ void orc_dp_search(const void* h, const double* q, const double* ext, int k, int
     free(costs);
     free(memo);
 }
+
+/* ------------------------------------------------------------------------------------------------------------- */
+/* the coupled ("full") LM step: cppflow/optimization.py:95-144 + LmResidualFns.get_r_and_J, optimization_utils.py:486-731 */
+
+typedef struct {
+    double lm_lambda, alpha_position, alpha_rotation, alpha_differencing, alpha_differencing_prismatic_scaling,
+        alpha_virtual_configs, alpha_self_collision, alpha_env_collision;
+    int use_pose, use_differencing, use_virtual_configs, n_virtual_configs, use_self_collisions, use_env_collisions;
+} orc_full_params;
+
+/* d(point rigidly attached to moving link `link`)/dq_j, world frame: z_j x (c - o_j) (revolute) or z_j (prismatic) for
+ * j <= link, 0 otherwise (joint j moves link l iff j <= l) */
+static void point_jacobian_col(const orc_robot* rb, int link, int j, const REAL (*axis)[3], const REAL (*origin)[3],
+                               const REAL* c, REAL* out) {
+    out[0] = out[1] = out[2] = 0;
+    if (j > link) return;
+    const REAL* z = axis[j];
+    if (rb->jtype[j] == 0) {
+        const REAL rx = c[0] - origin[j][0], ry = c[1] - origin[j][1], rz = c[2] - origin[j][2];
+        out[0] = z[1] * rz - z[2] * ry;
+        out[1] = z[2] * rx - z[0] * rz;
+        out[2] = z[0] * ry - z[1] * rx;
+    } else {
+        out[0] = z[0], out[1] = z[1], out[2] = z[2];
+    }
+}
+
+/* capsule world end points + joint axes / origins for one configuration */
+static void capsules_and_axes(const orc_robot* rb, const REAL* q, REAL (*w0)[3], REAL (*w1)[3], REAL (*axis)[3],
+                              REAL (*origin)[3]) {
+    frame_t links[ORC_MAX_DOF];
+    fk_chain(rb, q, links, axis, origin, NULL);
+    for (int c = 0; c < rb->ncaps; ++c) {
+        const int li = rb->cap_link[c];
+        for (int i = 0; i < 3; ++i) {
+            if (li < 0) {
+                w0[c][i] = rb->cap_p0[c][i];
+                w1[c][i] = rb->cap_p1[c][i];
+            } else {
+                const frame_t* f = &links[li];
+                const REAL r0 = f->R[3 * i], r1 = f->R[3 * i + 1], r2 = f->R[3 * i + 2];
+                w0[c][i] = FMA(r2, rb->cap_p0[c][2], FMA(r1, rb->cap_p0[c][1], FMA(r0, rb->cap_p0[c][0], f->p[i])));
+                w1[c][i] = FMA(r2, rb->cap_p1[c][2], FMA(r1, rb->cap_p1[c][1], FMA(r0, rb->cap_p1[c][0], f->p[i])));
+            }
+        }
+    }
+}
+
+/* signed self-collision distances [P] and their gradients [P,d] for one configuration: the derivative of the minimum
+ * distance equals the derivative with the closest points held fixed on their links (envelope theorem); where the
+ * segments touch (distance 0) the direction is undefined and the gradient is set to 0.
+ * (jrl.Robot.self_collision_distances_jacobian, call site cppflow/optimization_utils.py:670 -- un-vendored; this is the
+ * analytic gradient of this build's own distance definition, checked against finite differences in the tests.) */
+static void self_dists_and_grads(const orc_robot* rb, const REAL* q, REAL* dist, REAL* grad) {
+    const int d = rb->ndof;
+    REAL w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3], axis[ORC_MAX_DOF][3], origin[ORC_MAX_DOF][3];
+    capsules_and_axes(rb, q, w0, w1, axis, origin);
+    for (int p = 0; p < rb->npairs; ++p) {
+        const int a = rb->pair_a[p], b = rb->pair_b[p];
+        REAL c1[3], c2[3];
+        const REAL sd = seg_seg_closest(w0[a], w1[a], w0[b], w1[b], c1, c2);
+        dist[p] = sd - (rb->cap_r[a] + rb->cap_r[b]);
+        REAL n[3] = {0, 0, 0};
+        if (sd > 0)
+            for (int i = 0; i < 3; ++i) n[i] = (c1[i] - c2[i]) / sd;
+        for (int j = 0; j < d; ++j) {
+            REAL j1[3], j2[3];
+            point_jacobian_col(rb, rb->cap_link[a], j, axis, origin, c1, j1);
+            point_jacobian_col(rb, rb->cap_link[b], j, axis, origin, c2, j2);
+            grad[p * d + j] = n[0] * (j1[0] - j2[0]) + n[1] * (j1[1] - j2[1]) + n[2] * (j1[2] - j2[2]);
+        }
+    }
+}
+
+static void env_dists_and_grads(const orc_robot* rb, const REAL* q, const REAL* lo, const REAL* hi, REAL* dist, REAL* grad) {
+    const int d = rb->ndof;
+    REAL w0[ORC_MAX_CAPS][3], w1[ORC_MAX_CAPS][3], axis[ORC_MAX_DOF][3], origin[ORC_MAX_DOF][3];
+    capsules_and_axes(rb, q, w0, w1, axis, origin);
+    for (int c = 0; c < rb->ncaps; ++c) {
+        REAL cs[3], cb[3];
+        const REAL sd = seg_box_closest(w0[c], w1[c], lo, hi, cs, cb);
+        dist[c] = sd - rb->cap_r[c];
+        REAL n[3] = {0, 0, 0};
+        if (sd > 0)
+            for (int i = 0; i < 3; ++i) n[i] = (cs[i] - cb[i]) / sd;
+        for (int j = 0; j < d; ++j) {
+            REAL j1[3];
+            point_jacobian_col(rb, rb->cap_link[c], j, axis, origin, cs, j1);
+            grad[c * d + j] = n[0] * j1[0] + n[1] * j1[1] + n[2] * j1[2];
+        }
+    }
+}
+
+/* x[n,d] -> dists[n,P], grads[n,P,d] / dists[n,L], grads[n,L,d]  (test helpers; finite-difference checks) */
+void orc_self_dists_grads(const void* h, const double* x, int n, double* dists, double* grads) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof, P = rb->npairs;
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], dist[ORC_MAX_PAIRS], grad[ORC_MAX_PAIRS * ORC_MAX_DOF];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        self_dists_and_grads(rb, q, dist, grad);
+        for (int p = 0; p < P; ++p) {
+            dists[(size_t)r * P + p] = dist[p];
+            for (int j = 0; j < d; ++j) grads[((size_t)r * P + p) * d + j] = grad[p * d + j];
+        }
+    }
+}
+
+void orc_env_dists_grads(const void* h, const double* x, int n, const double* box_lo, const double* box_hi, double* dists,
+                         double* grads) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof, L = rb->ncaps;
+    REAL lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) lo[i] = (REAL)box_lo[i], hi[i] = (REAL)box_hi[i];
+    for (int r = 0; r < n; ++r) {
+        REAL q[ORC_MAX_DOF], dist[ORC_MAX_CAPS], grad[ORC_MAX_CAPS * ORC_MAX_DOF];
+        for (int j = 0; j < d; ++j) q[j] = (REAL)x[(size_t)r * d + j];
+        env_dists_and_grads(rb, q, lo, hi, dist, grad);
+        for (int c = 0; c < L; ++c) {
+            dists[(size_t)r * L + c] = dist[c];
+            for (int j = 0; j < d; ++j) grads[((size_t)r * L + c) * d + j] = grad[c * d + j];
+        }
+    }
+}
+
+/* Dense residual r [rows] and Jacobian J [rows, T*d] of ONE trajectory x [T,d], stacked in the reference's order
+ * (LmResidual.get_r, optimization_utils.py:59-72): pose, differencing, virtual configs, self collisions, env collisions.
+ * Returns the number of rows; r_out / J_out must hold max_rows rows. */
+static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const REAL* x, const REAL* target, const REAL* xv,
+                        int T, int nobs, const REAL* box_lo, const REAL* box_hi, REAL* r, REAL* J, int max_rows) {
+    const int d = rb->ndof, N = T * d;
+    int row = 0;
+#define NEW_ROW()                                    \
+    do {                                             \
+        if (row >= max_rows) return -1;              \
+        for (int c_ = 0; c_ < N; ++c_) J[(size_t)row * N + c_] = 0; \
+    } while (0)
+    if (pm->use_pose) { /* optimization_utils.py:503-543: r = pose errors, J = FK Jacobian, rows scaled by the alphas */
+        for (int t = 0; t < T; ++t) {
+            REAL Jt[6 * ORC_MAX_DOF], e[6], cur[7];
+            frame_t ee;
+            jacobian_row(rb, x + (size_t)t * d, Jt, &ee);
+            frame_to_pose(&ee, cur);
+            pose_error_row(cur, target + (size_t)t * 7, e);
+            for (int i = 0; i < 6; ++i) {
+                const REAL a = (REAL)(i < 3 ? pm->alpha_rotation : pm->alpha_position);
+                NEW_ROW();
+                r[row] = a * e[i];
+                for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = a * Jt[i * d + j];
+                ++row;
+            }
+        }
+    }
+    if (pm->use_differencing) { /* :549-613: r = alpha * angular_changes(x); J = +1 at (t,j), -1 at (t+1,j) */
+        for (int t = 0; t + 1 < T; ++t)
+            for (int j = 0; j < d; ++j) {
+                REAL a = (REAL)pm->alpha_differencing;
+                if (rb->jtype[j] == 1) a *= (REAL)pm->alpha_differencing_prismatic_scaling;
+                NEW_ROW();
+                r[row] = a * wrap_pi(x[(size_t)(t + 1) * d + j] - x[(size_t)t * d + j]);
+                J[(size_t)row * N + t * d + j] = a;
+                J[(size_t)row * N + (t + 1) * d + j] = -a;
+                ++row;
+            }
+    }
+    if (pm->use_virtual_configs) { /* :618-640, :430-484: first / last n_vq configs, r = b * (x - x_virtual), J = -b I */
+        const REAL b = (REAL)(pm->alpha_virtual_configs * pm->alpha_differencing);
+        const int nv = pm->n_virtual_configs;
+        for (int side = 0; side < 2; ++side)
+            for (int i = 0; i < nv; ++i) {
+                const int t = side == 0 ? i : T - nv + i;
+                for (int j = 0; j < d; ++j) {
+                    NEW_ROW();
+                    r[row] = b * wrap_pi(x[(size_t)t * d + j] - xv[(size_t)t * d + j]);
+                    J[(size_t)row * N + t * d + j] = -b;
+                    ++row;
+                }
+            }
+    }
+    if (pm->use_self_collisions) { /* :645-680: r = -alpha * dist where that is > 0, J = alpha * d(dist)/dq */
+        for (int t = 0; t < T; ++t) {
+            REAL dist[ORC_MAX_PAIRS], grad[ORC_MAX_PAIRS * ORC_MAX_DOF];
+            self_dists_and_grads(rb, x + (size_t)t * d, dist, grad);
+            for (int p = 0; p < rb->npairs; ++p) {
+                const REAL rv = -(REAL)pm->alpha_self_collision * dist[p];
+                if (!(rv > 0)) continue;
+                NEW_ROW();
+                r[row] = rv;
+                for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = (REAL)pm->alpha_self_collision * grad[p * d + j];
+                ++row;
+            }
+        }
+    }
+    if (pm->use_env_collisions) { /* :685-727: per obstacle, same rule */
+        for (int o = 0; o < nobs; ++o)
+            for (int t = 0; t < T; ++t) {
+                REAL dist[ORC_MAX_CAPS], grad[ORC_MAX_CAPS * ORC_MAX_DOF];
+                env_dists_and_grads(rb, x + (size_t)t * d, box_lo + 3 * o, box_hi + 3 * o, dist, grad);
+                for (int c = 0; c < rb->ncaps; ++c) {
+                    const REAL rv = -(REAL)pm->alpha_env_collision * dist[c];
+                    if (!(rv > 0)) continue;
+                    NEW_ROW();
+                    r[row] = rv;
+                    for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = (REAL)pm->alpha_env_collision * grad[c * d + j];
+                    ++row;
+                }
+            }
+    }
+#undef NEW_ROW
+    return row;
+}
+
+static int chol_solve_n(REAL* A, REAL* b, int n); /* below */
+
+/* One coupled LM step for each of S trajectories: dense J^T J + lambda I, Cholesky, x + delta (optimization.py:95-113).
+ * x [S*T,d], target [T,7] (shared), xv [S*T,d] (virtual configs; NULL = x, as the loop sets them at :253).
+ * Optionally returns the first trajectory's stacked residual (r_out, *rows_out).  Returns the number of failed solves. */
+int orc_lm_full_step(const void* h, const double* x, const double* target, const double* xv, int S, int T,
+                     const orc_full_params* pm, int nobs, const double* box_lo, const double* box_hi, double* x_new,
+                     double* r_out, int* rows_out) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof, N = T * d;
+    const int max_rows = 6 * T + d * T + 2 * d * (pm->n_virtual_configs > 0 ? pm->n_virtual_configs : 0) +
+                         T * (rb->npairs + rb->ncaps * (nobs > 0 ? nobs : 0)) + 8;
+    REAL* tg = (REAL*)malloc(sizeof(REAL) * (size_t)T * 7);
+    REAL lo[3 * ORC_MAX_OBS], hi[3 * ORC_MAX_OBS];
+    for (int i = 0; i < T * 7; ++i) tg[i] = (REAL)target[i];
+    for (int i = 0; i < 3 * nobs; ++i) lo[i] = (REAL)box_lo[i], hi[i] = (REAL)box_hi[i];
+    int fails = 0;
+    for (int s = 0; s < S; ++s) {
+        REAL* xs = (REAL*)malloc(sizeof(REAL) * (size_t)N);
+        REAL* xvs = (REAL*)malloc(sizeof(REAL) * (size_t)N);
+        REAL* r = (REAL*)malloc(sizeof(REAL) * (size_t)max_rows);
+        REAL* J = (REAL*)malloc(sizeof(REAL) * (size_t)max_rows * N);
+        REAL* A = (REAL*)calloc((size_t)N * N, sizeof(REAL));
+        REAL* b = (REAL*)calloc((size_t)N, sizeof(REAL));
+        for (int i = 0; i < N; ++i) {
+            xs[i] = (REAL)x[(size_t)s * N + i];
+            xvs[i] = xv ? (REAL)xv[(size_t)s * N + i] : xs[i];
+        }
+        const int rows = full_r_and_J(rb, pm, xs, tg, xvs, T, nobs, lo, hi, r, J, max_rows);
+        if (s == 0 && r_out) {
+            for (int i = 0; i < rows; ++i) r_out[i] = r[i];
+            if (rows_out) *rows_out = rows;
+        }
+        /* A = J^T J + lambda I, b = J^T r (optimization.py:108-110); J is sparse per row: skip zeros */
+        for (int k = 0; k < rows; ++k) {
+            const REAL* Jk = J + (size_t)k * N;
+            int nz[2 * ORC_MAX_DOF + 2], nnz = 0;
+            for (int c = 0; c < N && nnz < 2 * ORC_MAX_DOF; ++c)
+                if (Jk[c] != 0) nz[nnz++] = c;
+            for (int a = 0; a < nnz; ++a) {
+                b[nz[a]] += Jk[nz[a]] * r[k];
+                for (int c = 0; c < nnz; ++c) A[(size_t)nz[a] * N + nz[c]] += Jk[nz[a]] * Jk[nz[c]];
+            }
+        }
+        for (int i = 0; i < N; ++i) A[(size_t)i * N + i] += (REAL)pm->lm_lambda;
+        if (chol_solve_n(A, b, N) != 0) ++fails;
+        for (int i = 0; i < N; ++i) x_new[(size_t)s * N + i] = xs[i] + b[i];
+        free(xs), free(xvs), free(r), free(J), free(A), free(b);
+    }
+    free(tg);
+    return fails;
+}
+
+/* Cholesky solve for a heap matrix of any size (same algorithm as chol_solve) */
+static int chol_solve_n(REAL* A, REAL* b, int n) { return chol_solve(A, b, n); }

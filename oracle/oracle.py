@@ -27,6 +27,27 @@ def build(force: bool = False) -> None:
     subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
 
 
+class FullParams(ctypes.Structure):
+    """orc_full_params: the fields of OptimizationParameters the coupled step reads (lm_hyper_parameters.py:14-56)."""
+
+    _fields_ = [(k, ctypes.c_double) for k in (
+        "lm_lambda", "alpha_position", "alpha_rotation", "alpha_differencing", "alpha_differencing_prismatic_scaling",
+        "alpha_virtual_configs", "alpha_self_collision", "alpha_env_collision")] + [(k, ctypes.c_int) for k in (
+        "use_pose", "use_differencing", "use_virtual_configs", "n_virtual_configs", "use_self_collisions",
+        "use_env_collisions")]  # fmt: skip
+
+    @classmethod
+    def from_params(cls, p):
+        def f(v):
+            return 0.0 if v is None else float(v)
+
+        return cls(f(p.lm_lambda), f(p.alpha_position), f(p.alpha_rotation), f(p.alpha_differencing),
+                   f(p.alpha_differencing_prismatic_scaling), f(p.alpha_virtual_configs), f(p.alpha_self_collision),
+                   f(p.alpha_env_collision), int(bool(p.use_pose)), int(bool(p.use_differencing)),
+                   int(bool(p.use_virtual_configs)), int(p.n_virtual_configs or 0), int(bool(p.use_self_collisions)),
+                   int(bool(p.use_env_collisions)))  # fmt: skip
+
+
 def _lib(f32: bool):
     name = "liborc32.so" if f32 else "liborc64.so"
     if name not in _LIBS:
@@ -65,6 +86,13 @@ def _lib(f32: bool):
         ]  # fmt: skip
         lib.orc_angular_changes.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp]
         lib.orc_seed_validity.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]
+        lib.orc_self_dists_grads.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp]
+        lib.orc_env_dists_grads.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp, _dp, _dp]
+        lib.orc_lm_full_step.restype = ctypes.c_int
+        lib.orc_lm_full_step.argtypes = [
+            ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FullParams), ctypes.c_int, _dp, _dp,
+            _dp, _dp, _ip,
+        ]  # fmt: skip
         lib.orc_dp_search.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, _ip, _dp]
         _LIBS[name] = lib
     return _LIBS[name]
@@ -245,3 +273,38 @@ class Oracle:
         costs = np.empty((k, T))
         self.lib.orc_dp_search(self.h, _p(q), _p(ext), k, T, float(prismatic_scaling), idx.ctypes.data_as(_ip), _p(costs))
         return idx, costs
+
+    def self_dists_grads(self, x):
+        x = self._x(x)
+        n = x.shape[0]
+        dists, grads = np.empty((n, self.n_pairs)), np.empty((n, self.n_pairs, self.ndof))
+        self.lib.orc_self_dists_grads(self.h, _p(x), n, _p(dists), _p(grads))
+        return dists, grads
+
+    def env_dists_grads(self, x, box_lo, box_hi):
+        x, lo, hi = self._x(x), _d(box_lo), _d(box_hi)
+        n = x.shape[0]
+        dists, grads = np.empty((n, self.n_caps)), np.empty((n, self.n_caps, self.ndof))
+        self.lib.orc_env_dists_grads(self.h, _p(x), n, _p(lo), _p(hi), _p(dists), _p(grads))
+        return dists, grads
+
+    def lm_full_step(self, x, target, params, S, T, virtual_configs=None, boxes_lo=None, boxes_hi=None, return_residual=False):
+        """One coupled LM step (cppflow/optimization.py:95-144) for S trajectories x [S*T,d]; target [T,7] shared.
+        `params` is an OptimizationParameters-like object.  Returns x_new (and the first trajectory's stacked residual)."""
+        x, target = self._x(x), _d(target)
+        assert x.shape[0] == S * T and target.shape == (T, 7)
+        xv = _d(virtual_configs) if virtual_configs is not None else None
+        lo = _d(boxes_lo).reshape(-1, 3) if boxes_lo is not None and len(boxes_lo) else np.zeros((0, 3))
+        hi = _d(boxes_hi).reshape(-1, 3) if boxes_hi is not None and len(boxes_hi) else np.zeros((0, 3))
+        fp = FullParams.from_params(params)
+        out = np.empty_like(x)
+        max_rows = 6 * T + self.ndof * T + 2 * self.ndof * max(fp.n_virtual_configs, 0) + T * (self.n_pairs + self.n_caps * lo.shape[0]) + 8
+        r = np.zeros(max_rows)
+        rows = ctypes.c_int(0)
+        null = ctypes.cast(None, _dp)
+        fails = self.lib.orc_lm_full_step(
+            self.h, _p(x), _p(target), _p(xv) if xv is not None else null, S, T, ctypes.byref(fp), lo.shape[0],
+            _p(lo) if lo.shape[0] else null, _p(hi) if lo.shape[0] else null, _p(out), _p(r), ctypes.byref(rows),
+        )  # fmt: skip
+        assert fails == 0, f"{fails} Cholesky failures"
+        return (out, r[: rows.value]) if return_residual else out

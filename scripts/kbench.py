@@ -39,6 +39,8 @@ def main():
                               rb.lm_pose_steps(x0, t, 1e-6, 3.5, 0.35, n_steps=K, x_out=xo, packed_out=pk if coll else None, want_errors=not coll)), K))
         cases.append((f"{name} collision_masks", (lambda rb=rb, q3=q3: rb.collision_masks(q3)), 0))
         cases.append((f"{name} fk", (lambda rb=rb, x0=x0: rb.forward_kinematics(x0)), 0))
+        from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF
+        cases.append((f"{name} lm_full_step (diff preset)", (lambda rb=rb, x0=x0, t=target: rb.lm_full_step(x0, t, ALT_LOSS_V2_1_DIFF)), 0))
         ext = torch.zeros((args.seeds, args.waypoints), device=dev)
         cases.append((f"{name} dp_search k={args.seeds}", (lambda rb=rb, q3=q3, ext=ext: rb.dp_search(q3, ext)), 0))
         q175 = q3[:175].contiguous()

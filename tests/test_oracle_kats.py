@@ -241,3 +241,66 @@ def test_segment_box_distance_against_brute_force():
     assert (d <= brute + 1e-12).all()
     np.testing.assert_allclose(d, brute, atol=2e-6)
     del rng
+
+
+# ---- coupled ("full") LM step ---------------------------------------------------------------------------------------------
+
+
+def test_differencing_residual_kat():
+    """tests/optimization_utils_test.py:590-637 of the reference: r.differencing for a 4-config Panda path with
+    alpha_differencing = 1 -- pins r = x[t+1] - x[t], ordering (t major, joint minor)."""
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+
+    x = np.array([[0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7],
+                  [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07]])  # fmt: skip
+    pm = OptimizationParameters(**{**ALT_LOSS_V2_1_DIFF.__dict__, "alpha_differencing": 1.0, "use_virtual_configs": False,
+                                   "virtual_configs": None, "n_virtual_configs": None, "use_self_collisions": False,
+                                   "use_env_collisions": False})  # fmt: skip
+    o = H.oracle64("panda")
+    _, r = o.lm_full_step(x, o.fk(x), pm, 1, 4, return_residual=True)
+    expected = np.array([0.09, 0.18, 0.27, 0.36, 0.45, 0.54, 0.63, -0.09, -0.18, -0.27, -0.36, -0.45, -0.54, -0.63] + [0.0] * 7)
+    np.testing.assert_allclose(r, expected, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_distance_gradients_equal_finite_differences(name):
+    """The analytic capsule-distance gradients of the coupled step (closest points held fixed on their links) vs central
+    differences of the distances themselves."""
+    o, ch = H.oracle64(name), H.chain(name)
+    q = H.random_configs(name, 100, seed=13)
+    eps = 1e-6
+    d, g = o.self_dists_grads(q)
+    np.testing.assert_allclose(d, o.self_dists(q), atol=0)
+    lo, hi = H.box_corners([c for c, _ in H.PANDA_2CUBES], [T for _, T in H.PANDA_2CUBES])
+    de, ge = o.env_dists_grads(q, lo[0], hi[0])
+    fd, fde = np.zeros_like(g), np.zeros_like(ge)
+    for j in range(o.ndof):
+        qp, qm = q.copy(), q.copy()
+        qp[:, j] += eps
+        qm[:, j] -= eps
+        fd[:, :, j] = (o.self_dists(qp) - o.self_dists(qm)) / (2 * eps)
+        fde[:, :, j] = (o.env_dists(qp, lo[0], hi[0]) - o.env_dists(qm, lo[0], hi[0])) / (2 * eps)
+    rsum = np.array([ch.cap_r[a] + ch.cap_r[b] for a, b in ch.pairs])
+    touching = np.abs(d + rsum) < 1e-6  # segments intersect: direction undefined, gradient defined as 0
+    assert np.abs(g - fd)[~touching].max() < 1e-7
+    inside = np.abs(de + ch.cap_r[None]) < 1e-6
+    assert np.abs(ge - fde)[~inside].max() < 1e-6
+
+
+def test_coupled_step_smooths_a_trajectory_and_respects_obstacles():
+    """Sanity of the restated step with the reference's differencing preset: the summed joint change (the loop's 'TL',
+    optimization.py:173-175) drops, and colliding configurations are pushed out along the distance gradient."""
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF
+
+    o, ch = H.oracle64("panda"), H.chain("panda")
+    rng = np.random.RandomState(2)
+    T = 30
+    base = np.clip(rng.uniform(ch.lo * 0.5, ch.hi * 0.5, size=(1, 7)) + np.cumsum(0.03 * rng.randn(T, 7), axis=0), ch.lo, ch.hi)
+    x = H.f32(base)
+    tl = lambda v: np.abs(o.angular_changes(v)).sum()  # noqa: E731
+    lo, hi = H.box_corners([c for c, _ in H.PANDA_2CUBES], [T_ for _, T_ in H.PANDA_2CUBES])
+    x1 = o.lm_full_step(x, o.fk(x), ALT_LOSS_V2_1_DIFF, 1, T, boxes_lo=lo, boxes_hi=hi)
+    assert tl(x1) < tl(x)
+    # S independent trajectories in one call == each alone
+    x2 = o.lm_full_step(np.concatenate([x, x[::-1]]), o.fk(x), ALT_LOSS_V2_1_DIFF, 2, T, boxes_lo=lo, boxes_hi=hi)
+    np.testing.assert_allclose(x2[:T], x1, atol=1e-12)
