@@ -260,7 +260,7 @@ __device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co
 
 // Robot-specialised variant: capsule ids, link ids and the pair list are compile-time, so the end points live in VGPRs
 // (static indices after unrolling) and no LDS is touched.  Same canonical operation order as the LDS variant.
-template <class RB>
+template <class RB, bool WANT_MIN>
 __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co, const float (&q)[RB::D], float (&R)[9],
                                                   float (&p)[3], bool do_self, bool do_env) {
     using T = typename RB::Table;
@@ -291,15 +291,21 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
     }
     CollOut r;
     r.min_self = INFINITY;
+    r.self_hit = 0;
     if (do_self) {
 #pragma unroll
         for (int pi = 0; pi < T::P; ++pi) {
             const int a = T::pair_a[pi], b = T::pair_b[pi];
-            const float v = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]) - (T::cap_r[a] + T::cap_r[b]);
-            r.min_self = v < r.min_self ? v : r.min_self;
+            const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
+            if constexpr (WANT_MIN) {
+                const float v = __builtin_sqrtf(d2) - (T::cap_r[a] + T::cap_r[b]);
+                r.min_self = v < r.min_self ? v : r.min_self;
+            } else {
+                r.self_hit |= d2 < T::pair_thr[pi];
+            }
         }
     }
-    r.self_hit = r.min_self < 0.f;
+    if constexpr (WANT_MIN) r.self_hit = r.min_self < 0.f;
     r.min_env = INFINITY;
     r.env_hit = 0;
     if (do_env) {
@@ -307,11 +313,18 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
             float me = INFINITY;
 #pragma unroll
             for (int c = 0; c < T::L; ++c) {
-                const float v = seg_box_dist(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]) - T::cap_r[c];
-                me = v < me ? v : me;
+                const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
+                if constexpr (WANT_MIN) {
+                    const float v = __builtin_sqrtf(d2) - T::cap_r[c];
+                    me = v < me ? v : me;
+                } else {
+                    r.env_hit |= d2 < T::cap_thr[c];
+                }
             }
-            r.env_hit |= (me < 0.f);
-            r.min_env = me < r.min_env ? me : r.min_env;
+            if constexpr (WANT_MIN) {
+                r.env_hit |= (me < 0.f);
+                r.min_env = me < r.min_env ? me : r.min_env;
+            }
         }
     }
     return r;
@@ -325,21 +338,31 @@ __device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int t
     }
 }
 
+// WANT_MIN = false: masks only.  sqrt(d2) - r < 0  <=>  d2 < thr(r) exactly (thr = smallest fp32 y with sqrt_rn(y) >= r,
+// tabulated per pair / capsule), so the correctly rounded square root -- ~18 instructions and a branch each on gfx950 -- is
+// skipped without changing a bit of the masks.  WANT_MIN = true additionally tracks the signed minimum distances.
+template <bool WANT_MIN>
 __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float* __restrict__ lds, int tid,
                                                     bool do_self, bool do_env) {
     CollOut r;
     r.min_self = INFINITY;
+    r.self_hit = 0;
     if (do_self) {
         for (int pi = 0; pi < co.npairs; ++pi) {
             const int a = co.pair_a[pi], b = co.pair_b[pi];
             float a0[3], a1[3], b0[3], b1[3];
             lds_capsule(lds, tid, a, a0, a1);
             lds_capsule(lds, tid, b, b0, b1);
-            const float v = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
-            r.min_self = v < r.min_self ? v : r.min_self;
+            const float d2 = seg_seg_dist2(a0, a1, b0, b1);
+            if constexpr (WANT_MIN) {
+                const float v = __builtin_sqrtf(d2) - (co.cap_r[a] + co.cap_r[b]);
+                r.min_self = v < r.min_self ? v : r.min_self;
+            } else {
+                r.self_hit |= d2 < co.pair_thr[pi];
+            }
         }
     }
-    r.self_hit = r.min_self < 0.f;  // collision_detection.py:66-68
+    if constexpr (WANT_MIN) r.self_hit = r.min_self < 0.f;  // collision_detection.py:66-68
     r.min_env = INFINITY;
     r.env_hit = 0;
     if (do_env) {
@@ -348,25 +371,32 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
             for (int c = 0; c < co.ncaps; ++c) {
                 float w0[3], w1[3];
                 lds_capsule(lds, tid, c, w0, w1);
-                const float v = seg_box_dist(w0, w1, co.obs_lo[o], co.obs_hi[o]) - co.cap_r[c];
-                me = v < me ? v : me;
+                const float d2 = seg_box_dist2(w0, w1, co.obs_lo[o], co.obs_hi[o]);
+                if constexpr (WANT_MIN) {
+                    const float v = __builtin_sqrtf(d2) - co.cap_r[c];
+                    me = v < me ? v : me;
+                } else {
+                    r.env_hit |= d2 < co.cap_thr[c];
+                }
             }
-            r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
-            r.min_env = me < r.min_env ? me : r.min_env;
+            if constexpr (WANT_MIN) {
+                r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
+                r.min_env = me < r.min_env ? me : r.min_env;
+            }
         }
     }
     return r;
 }
 
 // capsule FK + distances for one row; leaves the LAST LINK frame in R, p (the caller applies F_ee for the metrics)
-template <class RB>
+template <class RB, bool WANT_MIN>
 __device__ __forceinline__ CollOut collide_row(const RB& rb, const CollK& co, const float (&q)[RB::D], float* lds, int tid,
                                                float (&R)[9], float (&p)[3], bool do_self, bool do_env) {
     if constexpr (RB::kStatic) {
-        return collide_static<RB>(rb, co, q, R, p, do_self, do_env);
+        return collide_static<RB, WANT_MIN>(rb, co, q, R, p, do_self, do_env);
     } else {
         fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
-        return collide_from_lds(co, lds, tid, do_self, do_env);
+        return collide_from_lds<WANT_MIN>(co, lds, tid, do_self, do_env);
     }
 }
 
@@ -399,7 +429,8 @@ __device__ __forceinline__ void load_target(const float* __restrict__ target, in
     quat_to_mat(t[3], t[4], t[5], t[6], Rt);
 }
 
-template <class RB, bool COLL>
+// COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances
+template <class RB, int COLL>
 __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
@@ -439,11 +470,11 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
     }
     if (out.x_out) store_x<D>(out.x_out, row, q);
 
-    if constexpr (COLL) {
+    if constexpr (COLL != 0) {
         float R[9], p[3];
         const bool do_self = out.self_mask || out.min_self || out.ext_cost;
         const bool do_env = out.env_mask || out.min_env || out.ext_cost;
-        const CollOut c = collide_row<RB>(rb, co, q, lds, tid, R, p, do_self, do_env);
+        const CollOut c = collide_row<RB, COLL == 2>(rb, co, q, lds, tid, R, p, do_self, do_env);
         if (out.pos_err_m || out.rot_err_rad) {
             float pe, re;
             fk_fixed_ee(rb, R, p);
@@ -464,7 +495,7 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
     }
 }
 
-template <class RB>
+template <class RB, bool WANT_MIN>
 __global__ __launch_bounds__(kBlock, CPPF_WAVES_COLL) void collision_kernel(const ChainK ch, const CollK co, int n,
                                                            const float* __restrict__ x, uint8_t* self_mask,
                                                            uint8_t* env_mask, uint8_t* jlim_mask, float* ext_cost,
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_COLL) void collision_kernel(cons
     CollOut c;
     c.min_self = c.min_env = INFINITY;
     c.self_hit = c.env_hit = 0;
-    if (do_self || do_env) c = collide_row<RB>(rb, co, q, lds, tid, R, p, do_self, do_env);
+    if (do_self || do_env) c = collide_row<RB, WANT_MIN>(rb, co, q, lds, tid, R, p, do_self, do_env);
     write_coll_outputs(row, c, jlim_hit<D>(co, q), self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env);
 }
 
@@ -1201,6 +1232,15 @@ struct cppf_robot {
 
 namespace {
 
+// smallest fp32 y with sqrt_rn(y) >= r (host sqrtf is correctly rounded): sqrtf(d2) - r < 0  <=>  d2 < y for all d2 >= 0
+float sqrt_threshold(float r) {
+    if (!(r > 0.f)) return 0.f;
+    float y = r * r;
+    while (std::sqrt(y) >= r) y = std::nextafterf(y, 0.f);
+    while (std::sqrt(y) < r) y = std::nextafterf(y, INFINITY);
+    return y;
+}
+
 // does a description equal a generated compile-time table exactly?
 template <class T>
 bool desc_matches(const cppf_robot_desc& d) {
@@ -1344,6 +1384,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         }
         co.cap_r[c] = desc->cap_r[c];
         co.cap_link[c] = (int8_t)desc->cap_link[c];
+        co.cap_thr[c] = sqrt_threshold(desc->cap_r[c]);
     }
     // cap_begin[l+1] = first capsule whose link >= l
     for (int l = -1; l <= d; ++l) {
@@ -1355,6 +1396,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     for (int p = 0; p < co.npairs; ++p) {
         co.pair_a[p] = (uint8_t)desc->pairs[p][0];
         co.pair_b[p] = (uint8_t)desc->pairs[p][1];
+        co.pair_thr[p] = sqrt_threshold(desc->cap_r[desc->pairs[p][0]] + desc->cap_r[desc->pairs[p][1]]);
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
     rb->static_id = find_static_robot(*desc);
@@ -1472,15 +1514,21 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self || out->min_env;
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
-    if (coll) {
-#define CPPF_BODY                                                                                                    \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+    if (coll && (out->min_self || out->min_env)) {
+#define CPPF_BODY                                                                                                 \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+                       prm, x_in, target, *out)
+        CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
+    } else if (coll) {
+#define CPPF_BODY                                                                                                 \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
                        prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else {
-#define CPPF_BODY                                                                                                    \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, false>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
+#define CPPF_BODY                                                                                               \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
                        prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
@@ -1498,11 +1546,19 @@ int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, 
     CPPF_REQUIRE(q, "q is NULL");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
-#define CPPF_BODY                                                                                                     \
-    hipLaunchKernelGGL((collision_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, (int)n, \
-                       q, self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env)
-    CPPF_DISPATCH_RB(robot)
+    if (min_self || min_env) {
+#define CPPF_BODY                                                                                                    \
+    hipLaunchKernelGGL((collision_kernel<RB, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+                       (int)n, q, self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env)
+        CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
+    } else {
+#define CPPF_BODY                                                                                                     \
+    hipLaunchKernelGGL((collision_kernel<RB, false>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+                       (int)n, q, self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env)
+        CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
+    }
     return check_launch(robot);
 }
 

@@ -35,6 +35,8 @@ struct CollK {
     float cap_r[CPPF_MAX_CAPSULES];
     int32_t cap_begin[CPPF_MAX_DOF + 2];  // capsules of link l (-1..d-1) are [cap_begin[l+1], cap_begin[l+2])
     int8_t cap_link[CPPF_MAX_CAPSULES];   // moving link of each capsule (-1 = base)
+    float pair_thr[CPPF_MAX_PAIRS];       // smallest y with sqrt_rn(y) >= r_a + r_b:  sqrt(d2) - (r_a+r_b) < 0  <=>  d2 < y
+    float cap_thr[CPPF_MAX_CAPSULES];     // the same for r alone (capsule vs cuboid)
     uint8_t pair_a[CPPF_MAX_PAIRS];
     uint8_t pair_b[CPPF_MAX_PAIRS];
     float obs_lo[CPPF_MAX_OBSTACLES][3];  // world-frame box corners
@@ -236,8 +238,8 @@ __device__ __forceinline__ void quat_to_mat(float w, float x, float y, float z, 
 // ---- distances (canonical order) ------------------------------------------------------------------------------------------
 // closest distance between two non-degenerate segments (Ericson, Real-Time Collision Detection 5.1.9); also returns the
 // closest points c1 (on P1Q1) and c2 (on P2Q2)
-__device__ __forceinline__ float seg_seg_closest(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
-                                                 const float (&Q2)[3], float (&c1)[3], float (&c2)[3]) {
+__device__ __forceinline__ float seg_seg_closest2(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
+                                                  const float (&Q2)[3], float (&c1)[3], float (&c2)[3]) {
     float d1[3], d2[3], rr[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -266,13 +268,24 @@ __device__ __forceinline__ float seg_seg_closest(const float (&P1)[3], const flo
         c2[i] = CPPF_FMA(d2[i], t, P2[i]);
         df[i] = c1[i] - c2[i];
     }
-    return __builtin_sqrtf(dot3(df[0], df[1], df[2], df[0], df[1], df[2]));
+    return dot3(df[0], df[1], df[2], df[0], df[1], df[2]);
+}
+
+// squared distance (what the mask-only kernels compare against the sqrt thresholds) and the distance itself
+__device__ __forceinline__ float seg_seg_dist2(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
+                                               const float (&Q2)[3]) {
+    float c1[3], c2[3];
+    return seg_seg_closest2(P1, Q1, P2, Q2, c1, c2);
+}
+
+__device__ __forceinline__ float seg_seg_closest(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
+                                                 const float (&Q2)[3], float (&c1)[3], float (&c2)[3]) {
+    return __builtin_sqrtf(seg_seg_closest2(P1, Q1, P2, Q2, c1, c2));
 }
 
 __device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
                                               const float (&Q2)[3]) {
-    float c1[3], c2[3];
-    return seg_seg_closest(P1, Q1, P2, Q2, c1, c2);
+    return __builtin_sqrtf(seg_seg_dist2(P1, Q1, P2, Q2));
 }
 
 __device__ __forceinline__ float seg_box_g(const float (&P)[3], const float (&D)[3], const float* __restrict__ lo,
@@ -288,8 +301,8 @@ __device__ __forceinline__ float seg_box_g(const float (&P)[3], const float (&D)
 
 // exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 when they intersect): root of the nondecreasing,
 // piecewise-linear half-derivative g of dist^2, bracketed among t = 0, 1 and the six (clamped) face-crossing parameters.
-__device__ __forceinline__ float seg_box_closest(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
-                                                 const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
+__device__ __forceinline__ float seg_box_closest2(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+                                                  const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
     float D[3], cand[8], gv[8];
 #pragma unroll
     for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
@@ -326,13 +339,23 @@ __device__ __forceinline__ float seg_box_closest(const float (&P0)[3], const flo
         cb[i] = clampf(x, lo[i], hi[i]);
         ex[i] = x - cb[i];
     }
-    return __builtin_sqrtf(dot3(ex[0], ex[1], ex[2], ex[0], ex[1], ex[2]));
+    return dot3(ex[0], ex[1], ex[2], ex[0], ex[1], ex[2]);
+}
+
+__device__ __forceinline__ float seg_box_dist2(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+                                               const float* __restrict__ hi) {
+    float cs[3], cb[3];
+    return seg_box_closest2(P0, P1, lo, hi, cs, cb);
+}
+
+__device__ __forceinline__ float seg_box_closest(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+                                                 const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
+    return __builtin_sqrtf(seg_box_closest2(P0, P1, lo, hi, cs, cb));
 }
 
 __device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
                                               const float* __restrict__ hi) {
-    float cs[3], cb[3];
-    return seg_box_closest(P0, P1, lo, hi, cs, cb);
+    return __builtin_sqrtf(seg_box_dist2(P0, P1, lo, hi));
 }
 
 // torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153)
