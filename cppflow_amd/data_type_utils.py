@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import yaml
 
-from cppflow_amd.data_types import DEFAULT_CONSTRAINTS, Constraints, Problem
+from cppflow_amd.data_types import DEFAULT_CONSTRAINTS, Constraints, Plan, Problem
 from cppflow_amd.robots import Robot, get_robot
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -203,3 +203,26 @@ def resample_path(path: np.ndarray, n: int) -> np.ndarray:
             q = (np.sin((1 - a) * th) * q0 + np.sin(a * th) * q1) / np.sin(th)
         out[k, 3:7] = q / np.linalg.norm(q)
     return out
+
+
+def plan_from_qpath(qpath: torch.Tensor, problem: Problem) -> Plan:
+    """Evaluate a joint-space path against its problem (cppflow/data_type_utils.py:244-276): FK, pose errors, maximum
+    joint changes, capsule collisions (the reference also runs klampt's exact meshes here), the validity verdict."""
+    from cppflow_amd.evaluation_utils import seed_metrics_are_below_threshold
+
+    rb = problem.robot
+    assert qpath.shape == (problem.n_timesteps, rb.ndof), tuple(qpath.shape)
+    q = qpath.contiguous()
+    pose_path = rb.forward_kinematics(q)
+    pe, re = rb.pose_error_metrics(q, problem.target_path)
+    metrics = rb.seed_validity(q, problem.target_path)[0].cpu()
+    problem.bind_obstacles()
+    masks = rb.collision_masks(q.unsqueeze(0), only=("self", "env"))
+    self_c, env_c = masks["self_mask"][0], masks["env_mask"][0]
+    ok, _ = seed_metrics_are_below_threshold(problem.constraints, metrics)
+    return Plan(
+        q_path=q, pose_path=pose_path, target_path=problem.target_path, positional_errors_cm=100 * pe,
+        rotational_errors_deg=torch.rad2deg(re), mjac_deg=float(metrics[2]), mjac_cm=float(metrics[3]),
+        self_colliding_per_ts=self_c, env_colliding_per_ts=env_c,
+        is_valid=bool(ok and not bool(self_c.any()) and not bool(env_c.any())),
+    )  # fmt: skip

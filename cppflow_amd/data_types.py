@@ -59,6 +59,47 @@ class PlannerSettings:
 
 
 @dataclass
+class Plan:
+    """What a planner returns (a reduced form of cppflow/data_types.py:86-264: the path, its error metrics and the
+    validity verdict; the printing / data-frame plumbing of the reference is not reproduced)."""
+
+    q_path: torch.Tensor  # [T, d]
+    pose_path: torch.Tensor  # [T, 7]
+    target_path: torch.Tensor  # [T, 7]
+    positional_errors_cm: torch.Tensor  # [T]
+    rotational_errors_deg: torch.Tensor  # [T]
+    mjac_deg: float
+    mjac_cm: float
+    self_colliding_per_ts: torch.Tensor  # bool [T] (capsules)
+    env_colliding_per_ts: torch.Tensor  # bool [T] (capsules)
+    is_valid: bool
+
+    @property
+    def max_positional_error_cm(self) -> float:
+        return float(self.positional_errors_cm.max())
+
+    @property
+    def max_rotational_error_deg(self) -> float:
+        return float(self.rotational_errors_deg.max())
+
+    def __str__(self) -> str:
+        return (
+            f"<Plan T={self.q_path.shape[0]} valid={self.is_valid} max_pos_err={self.max_positional_error_cm:.5f} cm "
+            f"max_rot_err={self.max_rotational_error_deg:.5f} deg mjac={self.mjac_deg:.3f} deg / {self.mjac_cm:.3f} cm "
+            f"self_coll={int(self.self_colliding_per_ts.sum())} env_coll={int(self.env_colliding_per_ts.sum())}>"
+        )
+
+
+@dataclass
+class PlannerResult:
+    plan: Plan
+    timing: TimingData
+    other_plans: List[Plan]
+    other_plans_names: List[str]
+    debug_info: dict
+
+
+@dataclass
 class Problem:
     constraints: Constraints
     target_path: torch.Tensor  # [W, 7] = x y z qw qx qy qz

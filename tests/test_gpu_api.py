@@ -436,3 +436,27 @@ def test_alternating_loop_with_differencing(robots):
     assert tl(b.x_opt) <= tl(a.x_opt) + 1e-3
     pe, re = rb.pose_error_metrics(b.x_opt, problem.target_path)
     assert float(pe.max()) * 100 < 0.01 and float(torch.rad2deg(re).max()) < 0.1
+
+
+def test_planner_end_to_end(robots):
+    """CppFlowPlanner.generate_plan on a problem file in the reference's format (panda__line: a straight 20 cm line next
+    to a cuboid): candidates -> collision masks -> dp_search -> LM optimisation, all on the device; the plan is valid."""
+    from cppflow_amd.data_type_utils import problem_from_filename
+    from cppflow_amd.data_types import PlannerSettings
+    from cppflow_amd.planners import CppFlowPlanner, LmIkSeedProvider, PlannerSearcher
+
+    problem = problem_from_filename(None, "panda__line", robot=None, device=DEV)
+    settings = PlannerSettings(k=64, tmax_sec=30.0, anytime_mode_enabled=False, verbosity=0)
+    searcher = PlannerSearcher(settings, problem.robot, LmIkSeedProvider(seed=1))
+    s = searcher.generate_plan(problem)
+    assert s.plan.q_path.shape == (problem.n_timesteps, 7) and s.timing.dp_search > 0
+    planner = CppFlowPlanner(settings, problem.robot, LmIkSeedProvider(seed=1))
+    r = planner.generate_plan(problem)
+    plan = r.plan
+    assert plan.is_valid, str(plan)
+    assert plan.max_positional_error_cm < 0.01 and plan.max_rotational_error_deg < 0.1 and plan.mjac_deg < 7.0
+    assert not bool(plan.self_colliding_per_ts.any()) and not bool(plan.env_colliding_per_ts.any())
+    # the optimised plan is at least as accurate as the raw search path
+    assert plan.max_positional_error_cm <= s.plan.max_positional_error_cm + 1e-6
+    problem.robot.set_obstacles([], [])
+    problem.robot.set_joint_limit_padding(None, None)
