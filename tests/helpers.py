@@ -73,3 +73,28 @@ def cuboid_obstacle(x, y, z, sx, sy, sz):
 
 PANDA_2CUBES = [cuboid_obstacle(0.2, 0.3, 0.4, 0.15, 0.15, 0.15), cuboid_obstacle(-0.25, 0.3, 0.75, 0.15, 0.15, 0.15)]
 PANDA_1CUBE = [cuboid_obstacle(0.0, 0.2, 0.7, 0.25, 0.25, 0.25)]
+
+
+def random_chain_spec(ndof, seed, n_prismatic=1, general_axes=True):
+    """A random serial chain in the URDF vocabulary: arbitrary (non-principal) joint axes, random fixed transforms with
+    rotations, fixed joints in between, a prismatic joint somewhere, capsules on every other link."""
+    from cppflow_amd.robot_model import CapsuleSpec, JointSpec, RobotSpec
+
+    rng = np.random.RandomState(seed)
+    pris = set(rng.choice(ndof, size=n_prismatic, replace=False).tolist()) if n_prismatic else set()
+    joints, capsules = [], [CapsuleSpec("base", (0, 0, 0), (0, 0, 0.08), 0.05)]
+    for i in range(ndof):
+        if i % 3 == 2:  # a fixed joint in the middle of the chain
+            joints.append(JointSpec(f"fix{i}", f"flink{i}", tuple(rng.uniform(-0.05, 0.05, 3)), tuple(rng.uniform(-0.5, 0.5, 3)), jtype="fixed"))
+        axis = rng.randn(3) if general_axes and i % 2 == 0 else np.eye(3)[rng.randint(3)] * rng.choice([-1.0, 1.0])
+        xyz = tuple(rng.uniform(-0.15, 0.15, 3) + np.array([0, 0, 0.12]))
+        rpy = tuple(rng.uniform(-1.0, 1.0, 3))
+        if i in pris:
+            joints.append(JointSpec(f"j{i}", f"link{i}", xyz, rpy, tuple(axis), "prismatic", (-0.1, 0.3)))
+        else:
+            joints.append(JointSpec(f"j{i}", f"link{i}", xyz, rpy, tuple(axis), "revolute", (-2.5, 2.0 + 0.1 * i)))
+        if i % 2 == 1:
+            capsules.append(CapsuleSpec(f"link{i}", tuple(rng.uniform(-0.03, 0.03, 3)), tuple(rng.uniform(0.05, 0.12, 3)), 0.03 + 0.01 * (i % 3)))
+    joints.append(JointSpec("tool", "tool", (0.02, -0.01, 0.1), (0.3, -0.2, 0.5), jtype="fixed"))
+    capsules.append(CapsuleSpec("tool", (0, 0, -0.05), (0, 0.02, 0.02), 0.025))
+    return RobotSpec(f"random{ndof}_{seed}", f"random {ndof}-dof chain", "base", joints, capsules, min_link_gap=2)

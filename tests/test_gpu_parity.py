@@ -251,3 +251,50 @@ def test_specialised_kernels_equal_generic_kernels(robots, name):
         assert torch.equal(ca[k], cb[k]), k
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
+
+
+@pytest.mark.parametrize("ndof,seed", [(6, 0), (7, 1), (8, 2), (12, 3)])
+def test_arbitrary_chains_through_the_generic_kernels(ndof, seed):
+    """Descriptions that match no generated table (random chains with general joint axes, rotated fixed transforms, a
+    prismatic joint, fixed joints inside the chain) run the generic kernels: FK / masks bit-exact with the fp32 oracle,
+    LM parity as for the shipped robots."""
+    from cppflow_amd import _hip
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    spec = H.random_chain_spec(ndof, seed)
+    rb = Robot(spec)
+    ch = canonicalize(spec)
+    o64, o32 = Oracle(ch, f32=False), Oracle(ch, f32=True)
+    assert _hip.lib().cppf_robot_specialization(rb._handle(torch.device("cuda:0"))) == -1
+    rng = np.random.RandomState(seed)
+    q = H.f32(rng.uniform(ch.lo, ch.hi, size=(2048, ndof)))
+    assert np.array_equal(host(rb.forward_kinematics(dev(q))), o32.fk(q))
+    assert np.abs(host(rb.jacobian(dev(q))) - o64.jacobian(q)).max() < 1e-5
+    obs = [H.cuboid_obstacle(0.1, 0.1, 0.5, 0.3, 0.3, 0.3)]
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    lo, hi = H.box_corners([c for c, _ in obs], [T for _, T in obs])
+    jl_lo, jl_hi = rb.padded_joint_limits()
+    want = o32.masks(q, lo, hi, jl_lo, jl_hi)
+    for want_min in (False, True):
+        got = rb.collision_masks(dev(q).reshape(32, 64, ndof), want_min_dists=want_min)
+        for k in ("self_mask", "env_mask", "jlim_mask"):
+            assert np.array_equal(got[k].cpu().numpy().reshape(-1).astype(np.uint8), want[k]), (k, want_min)
+        assert np.array_equal(host(got["ext_cost"]).reshape(-1), want["ext_cost"])
+    assert np.array_equal(host(got["min_self"]).reshape(-1), want["min_self"])
+    assert np.array_equal(host(got["min_env"]).reshape(-1), want["min_env"])
+    assert want["self_mask"].any() or want["env_mask"].any()
+    # LM: K fused steps converge like the oracle's
+    S, W, K = 8, 64, 10
+    q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(W, ndof)))
+    target = H.f32(o64.fk(q_star))
+    x0 = H.f32(np.clip(q_star[None] + 0.1 * rng.randn(S, W, ndof), ch.lo, ch.hi).reshape(S * W, ndof))
+    r = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, **LM)
+    x_o = o64.lm_steps(x0, H.stacked(target, S), K)
+    pe_o, re_o = o64.pose_metrics_exact(x_o, H.stacked(target, S))
+    conv = (pe_o < 1e-4) & (re_o < 1.2e-3)
+    assert conv.mean() > 0.8
+    assert np.abs(host(r["pos_err_m"]) - pe_o)[conv].max() < 1e-5
+    assert np.abs(host(r["rot_err_rad"]) - re_o)[conv].max() < 1e-5
