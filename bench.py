@@ -4,9 +4,10 @@
 A "step" is ONE pass of the hot path over one batch of synthetic seeds: a single launch of the fused kernel
 (cppf_lm_pose_steps) doing `--lm-steps` K iterations of { pose-only LM step ; clamp to joint limits } on every
 (seed, waypoint) row, then the pose-error metrics, self / environment collision masks, joint-limit mask and search cost of
-the result -- and, for N > 1, the one RCCL all-gather of the packed per-row costs / masks / errors that dp_search
-consumes.  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S seeds:
-weak scaling, seeds sharded, no data-path collective other than that all-gather).
+the result, followed by the per-seed summary reduction (8 floats per seed: the x_is_valid maxima, collision counts, summed
+cost) -- and, for N > 1, one RCCL all-gather of those summaries (32 KB per rank; asynchronous, double-buffered, so it
+overlaps the next step's kernel).  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S
+seeds: weak scaling, seeds sharded, no data-path collective other than that all-gather).
 
 Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two
 cuboids of panda__2cubes -- the configuration the metric is quoted on ("1024 seeds x 256 waypoints x 7-DoF at 1 MI355X").
@@ -192,9 +193,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # CPPF_BENCH_FORCE_DIST=1 initialises the RCCL process group even for one rank (rehearses the N > 1 code path)
+    force_dist = os.environ.get("CPPF_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")  # the tiny collective should not queue behind a full-chip kernel
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -214,12 +219,18 @@ def main():
     x0, target = make_inputs(robot, S, W, device, seed=rank)
     x_out = torch.empty_like(x0)
     packed = torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
-    gathered = torch.empty(world * packed.numel(), dtype=torch.uint8, device=device) if (world > 1 and collide) else None
     prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
+    # per-seed summaries (8 floats per seed) are what every rank needs from every other rank each step; kept in a ring of
+    # buffers so that the all-gather of step i (on the communicator's stream) overlaps the fused kernels of later steps
+    NBUF = 4  # ring depth: the collective of step i only has to be complete before step i + NBUF reuses its buffers
+    summaries = [torch.empty((S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if collide else None
+    gathered = [torch.empty((world * S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if (dist is not None and collide) else None
+    works = [None] * NBUF
 
     if collide:
         plan = robot.lm_launch_plan(x0, target, n_steps=K, x_out=x_out, packed_out=packed, **prm)
         launch, outputs = plan.launch, plan.outputs
+        summarise = [plan.summary_launcher(sm) for sm in summaries]
     else:
         pos_err = torch.empty(n, dtype=torch.float32, device=device)
 
@@ -228,10 +239,25 @@ def main():
 
         outputs = None
 
+    step_no = [0]
+
     def step():
+        b = step_no[0] % NBUF
+        step_no[0] += 1
+        if works[b] is not None:
+            works[b].wait()  # stream-side wait: the buffers of step i-2 are free again
+            works[b] = None
         launch()
+        if collide:
+            summarise[b]()
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, packed)
+            works[b] = dist.all_gather_into_tensor(gathered[b], summaries[b], async_op=True)
+
+    def drain():
+        for b in range(NBUF):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
 
     def barrier():
         if dist is not None:
@@ -240,10 +266,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     # kernel duration: a second, untimed pass with HIP events bracketing each launch on the launch stream (torch's
@@ -297,7 +325,8 @@ def main():
                 "lm_iterations_per_step": K,
                 "collision_fused": collide,
                 "obstacles": len(obstacles),
-                "allgather_bytes_per_rank": int(packed.numel()) if gathered is not None else 0,
+                "per_step": "fused launch + per-seed summary reduction" + (" + async all-gather of the [S,8] summaries" if gathered is not None else ""),
+                "allgather_bytes_per_rank": int(summaries[0].numel() * 4) if gathered is not None else 0,
                 "converged_frac_pos_err_lt_1e-4": conv_frac,
             },
             "roofline": {

@@ -680,6 +680,64 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
     }
 }
 
+// ---- per-seed summary of a fused launch's per-row outputs ---------------------------------------------------------------------
+// One wavefront per seed: reduces the packed per-row outputs of lm_fused_kernel (no FK) and the joint changes between
+// consecutive waypoints of x into 8 floats -- what x_is_valid (cppflow/optimization_utils.py:845-884) and a cross-GPU seed
+// selection need, and the payload of the per-step all-gather (32 B per seed instead of 15 B per row):
+//   [0] max position error (cm)   [1] max rotation error (deg)   [2] max |revolute joint change| (deg)
+//   [3] max |prismatic joint change| (cm)   [4] # self-colliding waypoints   [5] # env-colliding waypoints
+//   [6] # waypoints within the joint-limit padding   [7] sum of the external cost (search.py:146-150)
+template <int D>
+__global__ __launch_bounds__(64) void seed_summary_kernel(const ChainK ch, int S, int W, const float* __restrict__ x,
+                                                          const float* __restrict__ ext_cost,
+                                                          const float* __restrict__ pos_err,
+                                                          const float* __restrict__ rot_err,
+                                                          const uint8_t* __restrict__ self_mask,
+                                                          const uint8_t* __restrict__ env_mask,
+                                                          const uint8_t* __restrict__ jlim_mask, float* __restrict__ out) {
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    const float rad2deg = 57.29577951308232087680f;
+    float mp = 0.f, mr = 0.f, mrev = 0.f, mpri = 0.f, ns = 0.f, ne = 0.f, nj = 0.f, sc = 0.f;
+    for (int w = threadIdx.x; w < W; w += 64) {
+        const size_t row = (size_t)s * W + w;
+        mp = fmaxf(mp, 100.f * pos_err[row]);
+        mr = fmaxf(mr, rad2deg * rot_err[row]);
+        ns += (float)self_mask[row];
+        ne += (float)env_mask[row];
+        nj += (float)jlim_mask[row];
+        sc += ext_cost[row];
+        if (w + 1 < W) {
+            float q[D], qn[D];
+            load_x<D>(x, row, q);
+            load_x<D>(x, row + 1, qn);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float dq = qn[j] - q[j];
+                if ((ch.pris_mask >> j) & 1u)
+                    mpri = fmaxf(mpri, fabsf(100.f * dq));
+                else
+                    mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mp = fmaxf(mp, __shfl_xor(mp, off, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, off, 64));
+        mrev = fmaxf(mrev, __shfl_xor(mrev, off, 64));
+        mpri = fmaxf(mpri, __shfl_xor(mpri, off, 64));
+        ns += __shfl_xor(ns, off, 64);
+        ne += __shfl_xor(ne, off, 64);
+        nj += __shfl_xor(nj, off, 64);
+        sc += __shfl_xor(sc, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        float* o = out + (size_t)s * 8;
+        o[0] = mp, o[1] = mr, o[2] = mrev, o[3] = mpri, o[4] = ns, o[5] = ne, o[6] = nj, o[7] = sc;
+    }
+}
+
 // ---- coupled ("full") LM step: cppflow/optimization.py:95-144 + LmResidualFns.get_r_and_J (optimization_utils.py:486-731) -------
 // The reference stacks pose / differencing / virtual-config / collision residuals of ONE trajectory into a dense
 // J [(6T + d(T-1) + ...) x dT], forms the dense dT x dT normal matrix and factors it (O((dT)^3)).  Structurally
@@ -1621,6 +1679,20 @@ int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* tar
     hipStream_t st = (hipStream_t)stream;
     CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((seed_validity_kernel<D>), dim3(S), dim3(64), 0, st,
                                                         robot->chain, robot->coll, S, W, x, target, out));
+    return check_launch(robot);
+}
+
+int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, const float* ext_cost, const float* pos_err_m,
+                      const float* rot_err_rad, const uint8_t* self_mask, const uint8_t* env_mask,
+                      const uint8_t* jlim_mask, float* out, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
+    if (S == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && ext_cost && pos_err_m && rot_err_rad && self_mask && env_mask && jlim_mask && out, "NULL pointer");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((seed_summary_kernel<D>), dim3(S), dim3(64), 0, st, robot->chain, S, W, x, ext_cost,
+                                       pos_err_m, rot_err_rad, self_mask, env_mask, jlim_mask, out));
     return check_launch(robot);
 }
 

@@ -4,8 +4,11 @@ seeds, the robot / target path / obstacles are replicated, and ONE all-gather of
 the `[S_total, W]` cost and mask matrices `dp_search` consumes (cppflow/search.py:146-151).
 
 The collective is `torch.distributed.all_gather_into_tensor` -- RCCL over xGMI with the "nccl" backend on MI355X, gloo
-on CPU in the unit tests.  Messages are small (15 B per row: 3.9 MB per rank at 1024 x 256), so the collective is
-latency-bound: it is issued once per planning call, after the last fused step, on one contiguous buffer.
+on CPU in the unit tests.  Two payloads:
+  * `allgather_seed_summaries`: 8 floats per SEED (`Robot.seed_summary`: the four x_is_valid maxima, collision counts,
+    summed cost) -- 32 KB per rank at 1024 seeds, latency-bound, cheap enough for every step and asynchronous;
+  * `allgather_seed_outputs`: the full per-row buffer (15 B per row: 3.9 MB per rank at 1024 x 256) when a rank needs the
+    whole `[S_total, W]` cost / mask matrices (dp_search over every rank's candidates): once per planning call.
 """
 
 from dataclasses import dataclass
@@ -15,6 +18,23 @@ import torch
 import torch.distributed as dist
 
 PACKED_BYTES_PER_ROW = 15
+
+
+SEED_SUMMARY_FLOATS = 8  # Robot.SEED_SUMMARY_FIELDS
+
+
+def allgather_seed_summaries(summary: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                             out: Optional[torch.Tensor] = None, async_op: bool = False):
+    """All-gather the [S_local, 8] per-seed summaries (`Robot.seed_summary`) -> [world * S_local, 8]: 32 bytes per seed,
+    so the collective is latency-bound and can be issued every step; with `async_op=True` it returns (out, work) and runs
+    on the communicator's own stream beside the next step's kernel."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return (summary, None) if async_op else summary
+    if out is None:
+        out = torch.empty((world * summary.shape[0], summary.shape[1]), dtype=summary.dtype, device=summary.device)
+    work = dist.all_gather_into_tensor(out, summary.contiguous(), group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def seed_shard(n_seeds_total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -366,6 +366,26 @@ class Robot:
         )
         return pe, re
 
+    SEED_SUMMARY_FIELDS = ("max_pos_err_cm", "max_rot_err_deg", "mjac_rev_deg", "mjac_pris_cm", "n_self_colliding",
+                           "n_env_colliding", "n_jlim", "sum_ext_cost")  # fmt: skip
+
+    def seed_summary(self, x: torch.Tensor, packed: torch.Tensor, S: int, W: int, out: Optional[torch.Tensor] = None):
+        """[S,8] per-seed reduction (SEED_SUMMARY_FIELDS) of a fused launch's packed per-row outputs and its x_out."""
+        x = self._x2d(x)
+        n = S * W
+        assert x.shape[0] == n and packed.dtype == torch.uint8 and packed.numel() == self.PACKED_BYTES_PER_ROW * n
+        assert packed.is_cuda and packed.is_contiguous() and packed.data_ptr() % 4 == 0
+        if out is None:
+            out = torch.empty((S, 8), dtype=torch.float32, device=x.device)
+        base = packed.data_ptr()
+        _hip.check(
+            _hip.lib().cppf_seed_summary(
+                self._handle(x.device), x.data_ptr(), S, W, base, base + 4 * n, base + 8 * n, base + 12 * n, base + 13 * n,
+                base + 14 * n, out.data_ptr(), _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return out
+
     def lm_full_step(self, x: torch.Tensor, target: torch.Tensor, opt_params, virtual_configs: Optional[torch.Tensor] = None,
                      x_out: Optional[torch.Tensor] = None) -> torch.Tensor:  # fmt: skip
         """One coupled LM step (levenberg_marquardt_full, cppflow/optimization.py:95-144) for every trajectory in
@@ -474,6 +494,25 @@ class LmLaunchPlan:
         rc = self._fn(*self._args, torch.cuda.current_stream(self._device).cuda_stream)
         if rc:
             _hip.check(rc)
+
+    def summary_launcher(self, out: torch.Tensor):
+        """A zero-allocation callable that reduces this plan's per-row outputs into `out` [S,8] (`Robot.seed_summary`)."""
+        robot, x, target, x_out, packed = self._keep
+        assert packed is not None, "the plan has no packed per-row outputs"
+        n, W = x.shape[0], target.shape[0]
+        assert out.shape == (n // W, 8) and out.dtype == torch.float32 and out.is_cuda and out.is_contiguous()
+        base = packed.data_ptr()
+        fn = _hip.lib().cppf_seed_summary
+        args = (robot._handle(self._device), x_out.data_ptr(), n // W, W, base, base + 4 * n, base + 8 * n, base + 12 * n,
+                base + 13 * n, base + 14 * n, out.data_ptr())  # fmt: skip
+        device = self._device
+
+        def launch() -> None:
+            rc = fn(*args, torch.cuda.current_stream(device).cuda_stream)
+            if rc:
+                _hip.check(rc)
+
+        return launch
 
 
 def get_robot(name: str) -> Robot:

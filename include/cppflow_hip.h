@@ -150,6 +150,15 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
 int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
                        void* stream);
 
+/* Per-seed reduction of the per-row outputs of cppf_lm_pose_steps (no FK is repeated): out [S,8] =
+ *   max position error (cm), max rotation error (deg), max |revolute joint change| (deg), max |prismatic joint change| (cm)
+ *   -- the four quantities x_is_valid thresholds (cppflow/optimization_utils.py:861-884, evaluation_utils.py:29-75) --
+ *   then # self-colliding, # env-colliding, # joint-limit-padding waypoints and the summed external cost (search.py:146-150).
+ * 32 bytes per seed: the payload a multi-GPU run all-gathers every step (the per-row buffer is 15 B per row). */
+int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, const float* ext_cost, const float* pos_err_m,
+                      const float* rot_err_rad, const uint8_t* self_mask, const uint8_t* env_mask,
+                      const uint8_t* jlim_mask, float* out, void* stream);
+
 /* cppflow/lm_hyper_parameters.py:14-56: the fields the coupled step reads (values of ALT_LOSS_V2_1_DIFF at :86-118) */
 typedef struct cppf_full_params {
     float lm_lambda;

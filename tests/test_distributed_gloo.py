@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cppflow_amd.distributed import PACKED_BYTES_PER_ROW, allgather_seed_outputs, seed_shard, unpack_rows
+from cppflow_amd.distributed import (PACKED_BYTES_PER_ROW, allgather_seed_outputs, allgather_seed_summaries, seed_shard,
+                                     unpack_rows)  # fmt: skip
 from tests import helpers as H
 
 S_TOTAL, W, K = 6, 16, 3
@@ -45,6 +46,15 @@ def _worker(rank, world, port, out_dir):
         b, e = seed_shard(S_TOTAL, rank, world)
         packed = _fill_packed("panda", x0[b * W : e * W], target, e - b)
         g = allgather_seed_outputs(packed, e - b, W)
+        # the per-step payload: 8 floats per seed, gathered asynchronously
+        cost, pe, re, sm, em, jm = unpack_rows(packed, (e - b) * W)
+        summary = torch.stack([100 * pe.view(e - b, W).amax(1), torch.rad2deg(re.view(e - b, W).amax(1)),
+                               torch.zeros(e - b), torch.zeros(e - b), sm.view(e - b, W).sum(1).float(),
+                               em.view(e - b, W).sum(1).float(), jm.view(e - b, W).sum(1).float(),
+                               cost.view(e - b, W).sum(1)], dim=1).contiguous()  # fmt: skip
+        gathered, work = allgather_seed_summaries(summary, async_op=True)
+        work.wait()
+        np.save(os.path.join(out_dir, f"summary_rank{rank}.npy"), gathered.numpy())
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cost=g.ext_cost.numpy(), pe=g.pos_err_m.numpy(),
                  re=g.rot_err_rad.numpy(), sm=g.self_mask.numpy(), em=g.env_mask.numpy(), jm=g.jlim_mask.numpy())  # fmt: skip
     finally:
@@ -65,3 +75,7 @@ def test_two_rank_allgather_equals_single_process(tmp_path):
         assert np.array_equal(z["sm"], sm.astype(bool)) and np.array_equal(z["em"], em.astype(bool))
         assert np.array_equal(z["jm"], jm.astype(bool))
     assert cost.max() >= 1000.0  # the case does contain collisions
+    s0, s1 = (np.load(os.path.join(str(tmp_path), f"summary_rank{r}.npy")) for r in range(2))
+    assert s0.shape == (S_TOTAL, 8) and np.array_equal(s0, s1)
+    np.testing.assert_allclose(s0[:, 7], cost.sum(1), rtol=1e-6)
+    assert np.array_equal(s0[:, 4], sm.sum(1)) and np.array_equal(s0[:, 5], em.sum(1))

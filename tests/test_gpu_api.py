@@ -460,3 +460,32 @@ def test_planner_end_to_end(robots):
     assert plan.max_positional_error_cm <= s.plan.max_positional_error_cm + 1e-6
     problem.robot.set_obstacles([], [])
     problem.robot.set_joint_limit_padding(None, None)
+
+
+def test_seed_summary_matches_oracle_pieces(robots):
+    """cppf_seed_summary reduces the fused launch's own per-row outputs: compare with the same reductions done in numpy on
+    those outputs, and its four validity maxima with cppf_seed_validity (which recomputes FK)."""
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
+
+    rb = robots["fetch"]
+    obs = obstacle_arrays([(0.7, 0.1, 0.8, 0.3, 0.3, 0.3)])
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    S, W = 37, 59
+    x0, target = H.lm_problem("fetch", S, W, seed=31)
+    packed = torch.empty(rb.PACKED_BYTES_PER_ROW * S * W, dtype=torch.uint8, device=DEV)
+    r = rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=3, packed_out=packed)
+    got = host(rb.seed_summary(r["x"], packed, S, W))
+    pe = host(r["pos_err_m"]).reshape(S, W)
+    re = host(r["rot_err_rad"]).reshape(S, W)
+    np.testing.assert_allclose(got[:, 0], 100 * pe.max(1), rtol=1e-6)
+    np.testing.assert_allclose(got[:, 1], np.rad2deg(re.max(1)), rtol=1e-6)
+    sv = host(rb.seed_validity(r["x"], dev(target)))
+    np.testing.assert_allclose(got[:, :4], sv, rtol=1e-5, atol=1e-6)
+    for col, key in ((4, "self_mask"), (5, "env_mask"), (6, "jlim_mask")):
+        assert np.array_equal(got[:, col], r[key].cpu().numpy().reshape(S, W).sum(1).astype(np.float64))
+    np.testing.assert_allclose(got[:, 7], host(r["ext_cost"]).reshape(S, W).sum(1), rtol=1e-6)
+    want = H.oracle64("fetch").seed_validity(host(r["x"]), H.stacked(target, S), S, W)
+    assert np.abs(got[:, 2:4] - want[:, 2:4]).max() < 1e-3
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
