@@ -216,6 +216,59 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
     }
 }
 
+// Fewer than 6 joints: J J^T (6x6) is rank-deficient and the dual form loses its conditioning advantage, while J^T J (d x d)
+// is well conditioned -- solve the reference's primal system (optimization.py:85-88) by Cholesky.
+template <int D>
+__device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
+                                                float a_rot, float (&delta)[D]) {
+    const float s2[2] = {a_rot * a_rot, a_pos * a_pos};
+    float L[D][D], inv[D], y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+#pragma unroll
+        for (int i = j; i < D; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s = CPPF_FMA(s2[k >= 3] * J[k][i], J[k][j], s);
+            if (i == j) s += lambda;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
+            if (i == j) {
+                s = fmaxf(s, lambda);
+                inv[j] = __frsqrt_rn(s);
+            } else {
+                L[i][j] = s * inv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s = CPPF_FMA(s2[k >= 3] * J[k][i], e[k], s);
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < D; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
+        y[i] = s * inv[i];
+        delta[i] = y[i];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void lm_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos, float a_rot,
+                                         float (&delta)[D]) {
+    if constexpr (D < 6)
+        lm_primal_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+    else
+        lm_dual_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+}
+
 template <class RB>
 __device__ __forceinline__ void clamp_row(const RB& rb, float (&q)[RB::D]) {
 #pragma unroll
@@ -449,7 +502,7 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
         fk_ee_axes<RB>(rb, q, R, p, ax, og);
         pose_error(Rt, tt, R, p, e);
         jacobian_from_axes<RB>(rb, p, ax, og, J);
-        lm_dual_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+        lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
         if (it == prm.n_steps - 1) {
             // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
             if (out.J_out) {
@@ -1344,11 +1397,16 @@ int find_static_robot(const cppf_robot_desc& d) {
         switch ((robot)->static_id) { CPPF_FOR_EACH_STATIC_ROBOT(CPPF_STATIC_CASE) default: break; }                  \
     } else {                                                                                                          \
         switch ((robot)->desc.ndof) {                                                                                 \
+            case 3: { using RB = DynRobot<3>; CPPF_BODY; } break;                                                     \
+            case 4: { using RB = DynRobot<4>; CPPF_BODY; } break;                                                     \
+            case 5: { using RB = DynRobot<5>; CPPF_BODY; } break;                                                     \
             case 6: { using RB = DynRobot<6>; CPPF_BODY; } break;                                                     \
             case 7: { using RB = DynRobot<7>; CPPF_BODY; } break;                                                     \
             case 8: { using RB = DynRobot<8>; CPPF_BODY; } break;                                                     \
+            case 9: { using RB = DynRobot<9>; CPPF_BODY; } break;                                                     \
+            case 10: { using RB = DynRobot<10>; CPPF_BODY; } break;                                                   \
             case 12: { using RB = DynRobot<12>; CPPF_BODY; } break;                                                   \
-            default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {6, 7, 8, 12}");  \
+            default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {3..10, 12}");     \
         }                                                                                                             \
     }
 
@@ -1357,11 +1415,16 @@ bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
     switch (d) {                                                                                              \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break;                                                  \
+        case 4: { constexpr int D = 4; __VA_ARGS__; } break;                                                  \
+        case 5: { constexpr int D = 5; __VA_ARGS__; } break;                                                  \
         case 6: { constexpr int D = 6; __VA_ARGS__; } break;                                                  \
         case 7: { constexpr int D = 7; __VA_ARGS__; } break;                                                  \
         case 8: { constexpr int D = 8; __VA_ARGS__; } break;                                                  \
+        case 9: { constexpr int D = 9; __VA_ARGS__; } break;                                                  \
+        case 10: { constexpr int D = 10; __VA_ARGS__; } break;                                                \
         case 12: { constexpr int D = 12; __VA_ARGS__; } break;                                                \
-        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {6, 7, 8, 12}"); \
+        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {3..10, 12}");  \
     }
 
 int check_launch(const cppf_robot* rb) {

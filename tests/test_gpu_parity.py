@@ -253,7 +253,7 @@ def test_specialised_kernels_equal_generic_kernels(robots, name):
     rb.set_joint_limit_padding(None, None)
 
 
-@pytest.mark.parametrize("ndof,seed", [(6, 0), (7, 1), (8, 2), (12, 3)])
+@pytest.mark.parametrize("ndof,seed", [(3, 4), (4, 5), (5, 6), (6, 0), (7, 1), (8, 2), (9, 7), (10, 8), (12, 3)])
 def test_arbitrary_chains_through_the_generic_kernels(ndof, seed):
     """Descriptions that match no generated table (random chains with general joint axes, rotated fixed transforms, a
     prismatic joint, fixed joints inside the chain) run the generic kernels: FK / masks bit-exact with the fp32 oracle,
