@@ -288,45 +288,44 @@ __device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float 
     return __builtin_sqrtf(seg_seg_dist2(P1, Q1, P2, Q2));
 }
 
-__device__ __forceinline__ float seg_box_g(const float (&P)[3], const float (&D)[3], const float* __restrict__ lo,
-                                           const float* __restrict__ hi, float t) {
-    float ex[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float x = CPPF_FMA(D[i], t, P[i]);
-        ex[i] = x - clampf(x, lo[i], hi[i]);
-    }
-    return dot3(D[0], D[1], D[2], ex[0], ex[1], ex[2]);
-}
-
 // exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 when they intersect): root of the nondecreasing,
 // piecewise-linear half-derivative g of dist^2, bracketed among t = 0, 1 and the six (clamped) face-crossing parameters.
 __device__ __forceinline__ float seg_box_closest2(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
                                                   const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
-    float D[3], cand[8], gv[8];
+    // Along the segment x_i(t) = P0_i + t D_i the excess over the slab [lo_i, hi_i] is D_i (t - clamp(t, a_i, b_i)) with
+    // [a_i, b_i] the parameter interval in which coordinate i is inside the slab, so the half-derivative of dist^2 is
+    //     g(t) = sum_i w_i (t - clamp(t, a_i, b_i)),   w_i = D_i^2
+    // nondecreasing and piecewise linear with break points a_i, b_i.  (D_i = 0: w_i = 0, the term vanishes.)
+    float D[3], w[3], ta[3], tb[3], cand[8], gv[8];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
+    for (int i = 0; i < 3; ++i) {
+        D[i] = P1[i] - P0[i];
+        const float inv = D[i] != 0.f ? 1.f / D[i] : 0.f;
+        const float t0 = (lo[i] - P0[i]) * inv, t1 = (hi[i] - P0[i]) * inv;
+        ta[i] = fminf(t0, t1);
+        tb[i] = fmaxf(t0, t1);
+        w[i] = D[i] * D[i];
+        cand[2 + 2 * i] = clamp01(ta[i]);
+        cand[3 + 2 * i] = clamp01(tb[i]);
+    }
     cand[0] = 0.f;
     cand[1] = 1.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float inv = D[i] != 0.f ? 1.f / D[i] : 0.f;
-        cand[2 + 2 * i] = clamp01((lo[i] - P0[i]) * inv);
-        cand[3 + 2 * i] = clamp01((hi[i] - P0[i]) * inv);
+    for (int k = 0; k < 8; ++k) {
+        const float t = cand[k];
+        gv[k] = CPPF_FMA(w[2], t - clampf(t, ta[2], tb[2]),
+                         CPPF_FMA(w[1], t - clampf(t, ta[1], tb[1]), w[0] * (t - clampf(t, ta[0], tb[0]))));
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) gv[k] = seg_box_g(P0, D, lo, hi, cand[k]);
-    // bracket the root of g among the candidates and interpolate (g is linear between adjacent candidates); branch-free:
-    // lanes disagree on the three cases, so the interior solution is always computed and then selected
+    // g is monotone, so the bracket of its root is two independent max / min reductions over the candidates:
+    //   tl = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0};  tr = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}
     float tl = 0.f, gl = gv[0], tr = 1.f, gr = gv[1];
 #pragma unroll
     for (int k = 2; k < 8; ++k) {
-        const bool lo_side = gv[k] <= 0.f && cand[k] >= tl;
-        tl = lo_side ? cand[k] : tl;
-        gl = lo_side ? gv[k] : gl;
-        const bool hi_side = gv[k] >= 0.f && cand[k] <= tr;
-        tr = hi_side ? cand[k] : tr;
-        gr = hi_side ? gv[k] : gr;
+        const bool neg = gv[k] <= 0.f;
+        tl = fmaxf(tl, neg ? cand[k] : 0.f);
+        gl = fmaxf(gl, neg ? gv[k] : gv[0]);
+        tr = fminf(tr, neg ? 1.f : cand[k]);
+        gr = fminf(gr, neg ? gv[1] : gv[k]);
     }
     const float dg = gr - gl;
     const float t_in = dg > 0.f ? CPPF_FMA(tr - tl, (-gl) / dg, tl) : tl;

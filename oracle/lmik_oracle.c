@@ -669,59 +669,53 @@ static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const R
     return seg_seg_closest(P1, Q1, P2, Q2, c1, c2);
 }
 
-/* g(t) = 1/2 d/dt dist^2(P + t D, box) = sum_i D_i * (x_i - clamp(x_i, lo_i, hi_i)) : nondecreasing, piecewise linear */
-static REAL seg_box_g(const REAL* P, const REAL* D, const REAL* lo, const REAL* hi, REAL t) {
-    REAL ex[3];
-    for (int i = 0; i < 3; ++i) {
-        const REAL x = FMA(D[i], t, P[i]);
-        const REAL cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
-        ex[i] = x - cl;
-    }
-    return dot3(D, ex);
-}
+static inline REAL clampr(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline REAL maxr(REAL a, REAL b) { return a > b ? a : b; }
+static inline REAL minr(REAL a, REAL b) { return a < b ? a : b; }
 
-/* exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 if they intersect).
- * dist^2 along the segment is convex and piecewise quadratic; its half-derivative g is evaluated at t = 0, t = 1 and at
- * the (clamped) parameters where a coordinate crosses a box face; the minimiser is the root of g, bracketed by the
- * largest candidate with g <= 0 and the smallest with g >= 0, between which g is linear. */
+/* exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 if they intersect), with the closest points.
+ * Along the segment x_i(t) = P0_i + t D_i the excess over the slab [lo_i, hi_i] is D_i (t - clamp(t, a_i, b_i)), [a_i, b_i]
+ * being the parameter interval in which coordinate i is inside the slab; so the half-derivative of dist^2 is
+ *     g(t) = sum_i w_i (t - clamp(t, a_i, b_i)),  w_i = D_i^2,
+ * nondecreasing and piecewise linear with break points a_i, b_i.  g is evaluated at t = 0, 1 and the six clamped break
+ * points; because g is monotone the bracket of its root is two independent max / min reductions over those candidates
+ * (tl = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0}; tr = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}), and the root is
+ * interpolated linearly inside the bracket. */
 static REAL seg_box_closest(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi, REAL* cs, REAL* cb) {
-    REAL D[3], cand[8], gv[8];
-    for (int i = 0; i < 3; ++i) D[i] = P1[i] - P0[i];
+    REAL D[3], w[3], ta[3], tb[3], cand[8], gv[8];
+    for (int i = 0; i < 3; ++i) {
+        D[i] = P1[i] - P0[i];
+        const REAL inv = D[i] != 0 ? (REAL)1 / D[i] : (REAL)0;
+        const REAL t0 = (lo[i] - P0[i]) * inv, t1 = (hi[i] - P0[i]) * inv;
+        ta[i] = minr(t0, t1);
+        tb[i] = maxr(t0, t1);
+        w[i] = D[i] * D[i];
+        cand[2 + 2 * i] = clamp01(ta[i]);
+        cand[3 + 2 * i] = clamp01(tb[i]);
+    }
     cand[0] = 0;
     cand[1] = 1;
-    for (int i = 0; i < 3; ++i) {
-        const REAL inv = D[i] != 0 ? (REAL)1 / D[i] : (REAL)0;
-        cand[2 + 2 * i] = clamp01((lo[i] - P0[i]) * inv);
-        cand[3 + 2 * i] = clamp01((hi[i] - P0[i]) * inv);
+    for (int k = 0; k < 8; ++k) {
+        const REAL t = cand[k];
+        gv[k] = FMA(w[2], t - clampr(t, ta[2], tb[2]), FMA(w[1], t - clampr(t, ta[1], tb[1]), w[0] * (t - clampr(t, ta[0], tb[0]))));
     }
-    for (int k = 0; k < 8; ++k) gv[k] = seg_box_g(P0, D, lo, hi, cand[k]);
-    REAL t;
-    if (gv[0] >= 0) {
-        t = 0;
-    } else if (gv[1] <= 0) {
-        t = 1;
-    } else {
-        REAL tl = 0, gl = gv[0], tr = 1, gr = gv[1];
-        for (int k = 2; k < 8; ++k) {
-            if (gv[k] <= 0 && cand[k] >= tl) {
-                tl = cand[k];
-                gl = gv[k];
-            }
-            if (gv[k] >= 0 && cand[k] <= tr) {
-                tr = cand[k];
-                gr = gv[k];
-            }
-        }
-        const REAL dg = gr - gl;
-        t = dg > 0 ? FMA(tr - tl, (-gl) / dg, tl) : tl;
+    REAL tl = 0, gl = gv[0], tr = 1, gr = gv[1];
+    for (int k = 2; k < 8; ++k) {
+        const int neg = gv[k] <= 0;
+        tl = maxr(tl, neg ? cand[k] : (REAL)0);
+        gl = maxr(gl, neg ? gv[k] : gv[0]);
+        tr = minr(tr, neg ? (REAL)1 : cand[k]);
+        gr = minr(gr, neg ? gv[1] : gv[k]);
     }
+    const REAL dg = gr - gl;
+    const REAL t_in = dg > 0 ? FMA(tr - tl, (-gl) / dg, tl) : tl;
+    const REAL t = gv[0] >= 0 ? (REAL)0 : (gv[1] <= 0 ? (REAL)1 : t_in);
     REAL ex[3];
     for (int i = 0; i < 3; ++i) {
         const REAL x = FMA(D[i], t, P0[i]);
-        const REAL cl = x < lo[i] ? lo[i] : (x > hi[i] ? hi[i] : x);
         cs[i] = x;
-        cb[i] = cl;
-        ex[i] = x - cl;
+        cb[i] = clampr(x, lo[i], hi[i]);
+        ex[i] = x - cb[i];
     }
     return SQRT(dot3(ex, ex));
 }
