@@ -1175,9 +1175,8 @@ __global__ __launch_bounds__(256) void dp_transpose_kernel(const float* __restri
     if (i < (size_t)k) costsT[i] = ext[i * T];  // costs[:,0] = q_costs_external[:,0]  (search.py:151)
 }
 
-constexpr int kDpBPB = 4;  // destination candidates per workgroup
-
-template <int D>
+// BPB = destination candidates per workgroup: fewer for small k so that a step still fills the chip with workgroups
+template <int D, int kDpBPB>
 __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ q_prev, const float* __restrict__ q_cur,
                                                       const float* __restrict__ cost_prev, const float* __restrict__ ext,
                                                       int k, int T, int t, uint32_t pris_mask, float pscale,
@@ -1814,14 +1813,23 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
                        ext_cost, k, T, d, work_qT, work_costsT);
     // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
-    const unsigned blocks = (unsigned)((k + kDpBPB - 1) / kDpBPB);
+    const int bpb = k >= 2048 ? 4 : (k >= 512 ? 2 : 1);
+    const unsigned blocks = (unsigned)((k + bpb - 1) / bpb);
     for (int t = 1; t < T; ++t) {
         const float* qp = work_qT + (size_t)(t - 1) * k * d;
         const float* qc = work_qT + (size_t)t * k * d;
-        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_step_kernel<D>), dim3(blocks), dim3(256), 0, st, qp, qc,
-                                             work_costsT + (size_t)(t - 1) * k, ext_cost, k, T, t,
-                                             robot->chain.pris_mask, prismatic_scaling, work_costsT + (size_t)t * k,
-                                             work_memoT + (size_t)t * k));
+#define CPPF_DP_LAUNCH(BPB)                                                                                             \
+    CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_step_kernel<D, BPB>), dim3(blocks), dim3(256), 0, st, qp, qc,               \
+                                         work_costsT + (size_t)(t - 1) * k, ext_cost, k, T, t, robot->chain.pris_mask, \
+                                         prismatic_scaling, work_costsT + (size_t)t * k, work_memoT + (size_t)t * k))
+        if (bpb == 4) {
+            CPPF_DP_LAUNCH(4);
+        } else if (bpb == 2) {
+            CPPF_DP_LAUNCH(2);
+        } else {
+            CPPF_DP_LAUNCH(1);
+        }
+#undef CPPF_DP_LAUNCH
     }
     hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
                        best_path);

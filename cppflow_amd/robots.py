@@ -158,6 +158,17 @@ class Robot:
     def padded_joint_limits(self) -> Optional[Tuple[np.ndarray, np.ndarray]]:
         return self._jl_padding
 
+    def set_padded_joint_limits(self, padded: Optional[Tuple[np.ndarray, np.ndarray]]) -> None:
+        """Install already-padded (lo, hi) fp32 arrays (or None to disable the joint-limit mask)."""
+        if padded is None:
+            self._jl_padding = None
+        else:
+            lo, hi = (np.ascontiguousarray(a, dtype=np.float32) for a in padded)
+            assert lo.shape == (self.ndof,) and hi.shape == (self.ndof,)
+            self._jl_padding = (lo, hi)
+        for h in self._handles.values():
+            self._apply_jl_padding(h)
+
     # ---- jrl-compatible compute methods --------------------------------------------------------------------------------
     def _x2d(self, x: torch.Tensor, name: str = "x") -> torch.Tensor:
         x = _require_device_tensor(x, name)

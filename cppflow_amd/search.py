@@ -31,12 +31,7 @@ def joint_limit_almost_violations_3d(
     try:
         out = robot.collision_masks(qs, only=("jlim",))["jlim_mask"]
     finally:
-        if prev is None:
-            robot.set_joint_limit_padding(None, None)
-        else:
-            robot._jl_padding = prev
-            for h in robot._handles.values():
-                robot._apply_jl_padding(h)
+        robot.set_padded_joint_limits(prev)
     return out.type(torch.float32)
 
 

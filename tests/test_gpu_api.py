@@ -54,9 +54,7 @@ def test_golden_vectors(robots, name):
     obs = H.PANDA_2CUBES
     rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
     ch = H.chain(name)
-    rb._jl_padding = (ch.lo.astype(np.float32), ch.hi.astype(np.float32))
-    for h in rb._handles.values():
-        rb._apply_jl_padding(h)
+    rb.set_padded_joint_limits((ch.lo, ch.hi))
     m = rb.collision_masks(q.reshape(1, -1, rb.ndof), want_min_dists=True)
     assert np.array_equal(m["self_mask"].cpu().numpy().reshape(-1).astype(np.uint8), z["self_mask"])
     assert np.array_equal(m["env_mask"].cpu().numpy().reshape(-1).astype(np.uint8), z["env_mask"])
