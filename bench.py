@@ -183,7 +183,18 @@ def main():
     ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
     ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
+                    help="BASELINE.json configs[1..4] geometry per GPU (default = C4, the configuration the metric is quoted on)")  # fmt: skip
     args = ap.parse_args()
+    if args.config is not None:
+        preset = {  # robot, seeds per GPU, waypoints, collision fused
+            "C2": ("panda", 128, 64, False),  # FK+Jacobian+LM only
+            "C3": ("fetch", 512, 256, True),  # + collision fused (fetch__hello has no obstacles: self-collision only)
+            "C4": ("panda", 1024, 256, True),
+            "C5": ("chain12", 4096, 512, True),
+        }[args.config]
+        args.robot, args.seeds, args.waypoints = preset[0], preset[1], preset[2]
+        args.no_collide = not preset[3]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +223,7 @@ def main():
     d, S, W, K = robot.ndof, args.seeds, args.waypoints, args.lm_steps
     n = S * W
     collide = not args.no_collide
-    obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if collide else []
+    obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if (collide and args.config != "C3") else []
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
 
@@ -316,7 +327,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.robot}__2cubes geometry, {S} seeds/GPU x {W} waypoints x {d}-DoF, K={K} fused LM "
+                "workload": f"{args.robot}{'__2cubes geometry' if obstacles else ''}, {S} seeds/GPU x {W} waypoints x {d}-DoF, K={K} fused LM "
                 f"iterations per launch" + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
                 "robot": args.robot,
                 "seeds_per_gpu": S,
