@@ -1141,6 +1141,112 @@ __global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const F
     }
 }
 
+// Wavefront-parallel form of full_solve_kernel for D <= 8: one wavefront per trajectory, lane l <-> element
+// (i, j) = (l >> 3, l & 7) of the 8 x 8 matrix that holds the d x d block padded with the identity.  The elimination is
+// inherently sequential in t, so the only parallelism inside a trajectory is inside the d x d operations: the block inverse
+// is an in-place Gauss-Jordan sweep (per pivot: one v_readlane for the pivot, two cross-lane reads for its row and column,
+// one fused update on all 64 lanes), matrix-vector products are a lane-local multiply plus a 3-step xor-butterfly over the
+// row or column bits.  Operands of step t+1 are requested before step t is computed, so their latency hides behind it.
+template <int D>
+__global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                             const float* __restrict__ xv,
+                                                             const float* __restrict__ blocks, float* __restrict__ workG,
+                                                             float* __restrict__ worky, float* __restrict__ x_out) {
+    static_assert(D <= 8, "one 8x8 tile per wavefront");
+    constexpr int NT = D * (D + 1) / 2;
+    const int s = blockIdx.x;
+    if (s >= prm.S) return;
+    const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
+    const bool in = i < D && j < D, colv = j < D;
+    const int T = prm.W;
+    const size_t base = (size_t)s * T;
+    const int ii = i < j ? i : j, jj = i < j ? j : i;
+    const int tri = in ? ii * D - (ii * (ii - 1)) / 2 + (jj - ii) : 0;  // offset of (min, max) in the packed upper triangle
+    auto a2_of = [&](int c) {
+        if (!prm.use_diff || c >= D) return 0.f;
+        const float a = prm.a_diff * (((ch.pris_mask >> c) & 1u) ? prm.a_diff_pris : 1.f);
+        return a * a;
+    };
+    const float a2i = a2_of(i), a2j = a2_of(j);
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+    const int jc = colv ? j : 0;  // padded lanes read column 0 (their values are never used)
+
+    // ---- forward elimination
+    float G = 0.f, y_row = 0.f;
+    float xp = 0.f, xc = x[(base + 0) * D + jc], xn = T > 1 ? x[(base + 1) * D + jc] : 0.f;
+    float Mij = blocks[(base + 0) * (NT + D) + tri], bj = blocks[(base + 0) * (NT + D) + NT + jc];
+    float vj = xv ? xv[(base + 0) * D + jc] : 0.f;
+    for (int t = 0; t < T; ++t) {
+        // request the operands of step t+1 now
+        float nM = 0.f, nb = 0.f, nx2 = 0.f, nv = 0.f;
+        if (t + 1 < T) {
+            nM = blocks[(base + t + 1) * (NT + D) + tri];
+            nb = blocks[(base + t + 1) * (NT + D) + NT + jc];
+            if (xv) nv = xv[(base + t + 1) * D + jc];
+        }
+        if (t + 2 < T) nx2 = x[(base + t + 2) * D + jc];
+
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        float A = in ? Mij : (i == j ? 1.f : 0.f);
+        if (in && i == j) A += ((has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f)) * a2j + (vq ? beta2 : 0.f) + prm.lm_lambda;
+        float b = colv ? bj : 0.f;
+        if (colv) {
+            if (has_next) b = CPPF_FMA(a2j, wrap_pi(xn - xc), b);
+            if (has_prev) b = CPPF_FMA(-a2j, wrap_pi(xc - xp), b);
+            if (vq && xv) b = CPPF_FMA(-beta2, wrap_pi(xc - vj), b);
+        }
+        float ycol = b;
+        if (has_prev) {
+            A = CPPF_FMA(-(a2i * a2j), G, A);  // D' = A - E G E   (padding: a2 = 0)
+            float pr = G * y_row;              // G_ij y_i, summed over i -> (G y)_j in every lane of column j
+            pr += __shfl_xor(pr, 8, 64);
+            pr += __shfl_xor(pr, 16, 64);
+            pr += __shfl_xor(pr, 32, 64);
+            ycol = CPPF_FMA(a2j, pr, b);  // y = b - E (G y_prev)
+        }
+        // in-place Gauss-Jordan inverse (SPD: no pivoting; pivots floored like the Cholesky pivots of the per-lane kernel)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float pv = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), k * 9)), prm.lm_lambda);
+            const float pinv = 1.f / pv;
+            const float rk = __shfl(A, k * 8 + j, 64);        // A_kj
+            const float ck = __shfl(A, (lane & 56) + k, 64);  // A_ik
+            float nvl = CPPF_FMA(-(ck * pinv), rk, A);
+            nvl = (i == k) ? rk * pinv : nvl;
+            nvl = (j == k) ? -(ck * pinv) : nvl;
+            nvl = (i == k && j == k) ? pinv : nvl;
+            A = nvl;
+        }
+        G = A;
+        if (in && i <= j) workG[(base + t) * NT + tri] = G;
+        if (i == 0 && colv) worky[(base + t) * D + j] = ycol;
+        y_row = __shfl(ycol, j * 8 + i, 64);  // lane (i,j) takes y_i from column i
+        xp = xc, xc = xn, xn = nx2;
+        Mij = nM, bj = nb, vj = nv;
+    }
+    // ---- back substitution: delta_t = G_t (y_t + a2 .* delta_{t+1})
+    float dl = 0.f;  // delta_{t+1}, column-replicated
+    float Gn = in ? workG[(base + T - 1) * NT + tri] : (i == j ? 1.f : 0.f);
+    float yn = colv ? worky[(base + T - 1) * D + j] : 0.f;
+    float xr = (in && j == 0) ? x[(base + T - 1) * D + i] : 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float Gt = Gn, yt = yn, xt = xr;
+        if (t > 0) {
+            Gn = in ? workG[(base + t - 1) * NT + tri] : (i == j ? 1.f : 0.f);
+            yn = colv ? worky[(base + t - 1) * D + j] : 0.f;
+            xr = (in && j == 0) ? x[(base + t - 1) * D + i] : 0.f;
+        }
+        const float rhs = (t + 1 < T) ? CPPF_FMA(a2j, dl, yt) : yt;
+        float pr = Gt * rhs;  // G_ij rhs_j, summed over j -> delta_i in every lane of row i
+        pr += __shfl_xor(pr, 1, 64);
+        pr += __shfl_xor(pr, 2, 64);
+        pr += __shfl_xor(pr, 4, 64);
+        if (in && j == 0) x_out[(base + t) * D + i] = xt + pr;  // optimization.py:113: x + delta_x
+        dl = __shfl(pr, j * 8 + i, 64);
+    }
+}
+
 // ---- dp_search (cppflow/search.py:100-191) -----------------------------------------------------------------------------------
 // costs[b,t] = min_a { max(mjac(a->b,t-1), costs[a,t-1]) + ext[b,t] }, first minimal a recorded; one launch per timestep
 // (the recurrence is sequential in t; each step is a k x k (min,max) product).  The reference materialises
@@ -1793,9 +1899,23 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     CPPF_DISPATCH_D(robot->desc.ndof,
                     hipLaunchKernelGGL((full_blocks_kernel<D>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st,
                                        robot->chain, robot->coll, prm, x_in, target, work_blocks));
-    CPPF_DISPATCH_D(robot->desc.ndof,
-                    hipLaunchKernelGGL((full_solve_kernel<D>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,
-                                       robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out));
+    // Trajectories are eliminated one per wavefront (8 x 8 lane tile) up to 8 joints, one per lane beyond.  With the pose
+    // block the d x d blocks are J^T J + a small diagonal (rank 6 of 7, cond ~1e7): the per-lane kernel's Cholesky with
+    // floored pivots copes with that better than the explicit Gauss-Jordan inverse, so it keeps that case.
+    switch (prm.use_pose ? 0 : robot->desc.ndof) {
+#define CPPF_WAVE_CASE(DD)                                                                                          \
+    case DD:                                                                                                        \
+        hipLaunchKernelGGL((full_solve_wave_kernel<DD>), dim3((unsigned)S), dim3(64), 0, st, robot->chain, prm, x_in, \
+                           virtual_configs, work_blocks, work_G, work_y, x_out);                                    \
+        break;
+        CPPF_WAVE_CASE(3) CPPF_WAVE_CASE(4) CPPF_WAVE_CASE(5) CPPF_WAVE_CASE(6) CPPF_WAVE_CASE(7) CPPF_WAVE_CASE(8)
+#undef CPPF_WAVE_CASE
+        default:
+            CPPF_DISPATCH_D(robot->desc.ndof,
+                            hipLaunchKernelGGL((full_solve_kernel<D>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,
+                                               robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y,
+                                               x_out));
+    }
     return check_launch(robot);
 }
 
