@@ -487,3 +487,48 @@ def test_seed_summary_matches_oracle_pieces(robots):
     assert np.abs(got[:, 2:4] - want[:, 2:4]).max() < 1e-3
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
+
+
+def test_entry_points_are_hip_graph_capturable(robots):
+    """No entry point allocates, frees or synchronises, so a sequence of launches can be captured into a HIP graph (here:
+    the reference's per-iteration cadence -- five K = 1 { step ; clamp } launches ping-ponging two buffers, then the collision
+    masks) and replayed; the replay reproduces the eager result bit for bit."""
+    rb = robots["panda"]
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    S, W = 64, 64
+    x0, target = H.lm_problem("panda", S, W, seed=41)
+    x_in, tgt = dev(x0), dev(target)
+    bufs = [torch.empty_like(x_in), torch.empty_like(x_in)]
+    packed = torch.empty(rb.PACKED_BYTES_PER_ROW * S * W, dtype=torch.uint8, device=DEV)
+    plans = [rb.lm_launch_plan(src, tgt, 1e-6, 3.5, 0.35, n_steps=1, x_out=dst,
+                               packed_out=packed if last else None)
+             for src, dst, last in ((x_in, bufs[0], False), (bufs[0], bufs[1], False), (bufs[1], bufs[0], False),
+                                    (bufs[0], bufs[1], False), (bufs[1], bufs[0], True))]  # fmt: skip
+
+    def run():
+        for p in plans:
+            p.launch()
+
+    run()
+    torch.cuda.synchronize()
+    eager_x, eager_packed = bufs[0].clone(), packed.clone()
+    bufs[0].zero_(), bufs[1].zero_(), packed.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()  # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    bufs[0].zero_(), bufs[1].zero_(), packed.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bufs[0], eager_x) and torch.equal(packed, eager_packed)
+    want = H.oracle64("panda").lm_steps(x0, H.stacked(target, S), 5)
+    ok = np.abs(want - x0).max(axis=1) < 0.5
+    assert np.abs(host(eager_x) - want)[ok].max() < 2e-2
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
