@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--seeds", type=int, default=1024, help="seeds per GPU")
     ap.add_argument("--waypoints", type=int, default=256)
     ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps alternate between")
     ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
@@ -204,6 +205,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    saved_stdout_fd = None
     # CPPF_BENCH_FORCE_DIST=1 initialises the RCCL process group even for one rank (rehearses the N > 1 code path)
     force_dist = os.environ.get("CPPF_BENCH_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
@@ -212,6 +214,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")  # the tiny collective should not queue behind a full-chip kernel
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a version banner on stdout when the communicator comes up; stdout carries exactly ONE JSON line, so
+        # fd 1 points at stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
@@ -228,20 +235,26 @@ def main():
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
 
     x0, target = make_inputs(robot, S, W, device, seed=rank)
-    x_out = torch.empty_like(x0)
-    packed = torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
+    NBUF = 4  # ring depth of output buffer sets (see below)
+    x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
+    packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
+               for _ in range(NBUF)]  # fmt: skip
+    x_out, packed = x_outs[0], packeds[0]
     prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
     # per-seed summaries (8 floats per seed) are what every rank needs from every other rank each step; kept in a ring of
     # buffers so that the all-gather of step i (on the communicator's stream) overlaps the fused kernels of later steps
-    NBUF = 4  # ring depth: the collective of step i only has to be complete before step i + NBUF reuses its buffers
+    # (ring depth NBUF: the collective of step i only has to be complete before step i + NBUF reuses its buffers)
     summaries = [torch.empty((S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if collide else None
     gathered = [torch.empty((world * S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if (dist is not None and collide) else None
     works = [None] * NBUF
 
     if collide:
-        plan = robot.lm_launch_plan(x0, target, n_steps=K, x_out=x_out, packed_out=packed, **prm)
-        launch, outputs = plan.launch, plan.outputs
-        summarise = [plan.summary_launcher(sm) for sm in summaries]
+        # one pre-marshalled plan per ring slot: the launch writes that slot's [S,8] per-seed summary itself (in-kernel
+        # epilogue when W is 64 / 128 / 256, else a second reduction kernel issued by the same C call)
+        plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=sm, **prm)
+                 for xo, pk, sm in zip(x_outs, packeds, summaries)]  # fmt: skip
+        launches = [p.launch for p in plans]
+        launch, outputs = launches[0], plans[0].outputs
     else:
         pos_err = torch.empty(n, dtype=torch.float32, device=device)
 
@@ -252,15 +265,40 @@ def main():
 
     step_no = [0]
 
+    # --streams 2: consecutive steps are independent batches (own output buffers per ring slot), so they alternate between
+    # two HIP streams and one launch's tail (its last, partly filled round of workgroups) overlaps the next one's ramp-up
+    n_streams = max(1, min(args.streams, NBUF))
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else None
+    if streams is not None:
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(device))
+
+    def step_multi_stream():
+        b = step_no[0] % NBUF
+        step_no[0] += 1
+        st = streams[b % n_streams]
+        if gathered is None:
+            plans[b].launch_on(st)
+            return
+        with torch.cuda.stream(st):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
+            launches[b]()
+            works[b] = dist.all_gather_into_tensor(gathered[b], summaries[b], async_op=True)
+
     def step():
+        if streams is not None and collide:
+            return step_multi_stream()
         b = step_no[0] % NBUF
         step_no[0] += 1
         if works[b] is not None:
             works[b].wait()  # stream-side wait: the buffers of step i-2 are free again
             works[b] = None
-        launch()
         if collide:
-            summarise[b]()
+            launches[b]()
+        else:
+            launch()
         if gathered is not None:
             works[b] = dist.all_gather_into_tensor(gathered[b], summaries[b], async_op=True)
 
@@ -336,7 +374,7 @@ def main():
                 "lm_iterations_per_step": K,
                 "collision_fused": collide,
                 "obstacles": len(obstacles),
-                "per_step": "fused launch + per-seed summary reduction" + (" + async all-gather of the [S,8] summaries" if gathered is not None else ""),
+                "per_step": "one fused launch incl. the per-seed summary reduction" + (" + async all-gather of the [S,8] summaries" if gathered is not None else ""),
                 "allgather_bytes_per_rank": int(summaries[0].numel() * 4) if gathered is not None else 0,
                 "converged_frac_pos_err_lt_1e-4": conv_frac,
             },
@@ -359,7 +397,12 @@ def main():
             line["cpu_baseline_c"] = cpu_baseline_c(args.robot, obstacles, d, W, K)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
             line["gpu_over_cpu_c"] = line["value"] / line["cpu_baseline_c"]["value"]
-        print(json.dumps(line))
+        sys.stdout.flush()
+        if saved_stdout_fd is not None:
+            os.dup2(saved_stdout_fd, 1)
+        print(json.dumps(line), flush=True)
+        if saved_stdout_fd is not None:
+            os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -80,6 +80,7 @@ class LmOutputs(ctypes.Structure):
         ("ext_cost", _vp),
         ("min_self", _vp),
         ("min_env", _vp),
+        ("seed_summary", _vp),
     ]
 
 

@@ -283,6 +283,31 @@ struct CollOut {
     int self_hit, env_hit;
 };
 
+// ---- broad phase (mask-only launches) -----------------------------------------------------------------------------------------
+// A capsule's segment lies in the ball of radius h (half its length, a constant of the rigid link) about its mid point m,
+// so  dist(seg_a, seg_b) >= |m_a - m_b| - h_a - h_b  and  dist(seg_c, box) >= dist(m_c, box) - h_c.  A pair is skipped when
+// EVERY active lane of the wavefront has   |m_a - m_b|^2 > (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4)   (tabulated, rounded up).
+// The exact functions return the squared distance between two points ON the segments / box (whatever parameters the
+// fp32 arithmetic lands on), which is >= the true squared distance up to the ~1e-6 relative rounding of the final
+// difference and dot product; with the 1 cm margin the skipped test could only have said "no hit", so the masks are
+// unchanged bit for bit.  The branch is wave-uniform (ballot), so nothing diverges; consecutive lanes are consecutive
+// waypoints of one seed, which makes far pairs far for the whole wavefront on real paths.
+__device__ __forceinline__ bool cull_far(float lower2, float cull2) {
+    return __builtin_amdgcn_ballot_w64(!(lower2 > cull2)) == 0ull;
+}
+
+__device__ __forceinline__ float mid_dist2(const float (&a)[3], const float (&b)[3]) {
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return CPPF_FMA(dz, dz, CPPF_FMA(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ float point_box_dist2(const float (&m)[3], const float* __restrict__ lo,
+                                                 const float* __restrict__ hi) {
+    const float ex = m[0] - clampf(m[0], lo[0], hi[0]), ey = m[1] - clampf(m[1], lo[1], hi[1]),
+                ez = m[2] - clampf(m[2], lo[2], hi[2]);
+    return CPPF_FMA(ez, ez, CPPF_FMA(ey, ey, ex * ex));
+}
+
 template <class RB>
 __device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co, const float (&q)[RB::D],
                                                    float* __restrict__ lds, int tid, float (&R)[9], float (&p)[3]) {
@@ -342,6 +367,15 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
             }
         }
     }
+    // Broad phase of the mask-only launches (see cull_far): capsule mid points, then one bounding-sphere test per pair /
+    // per (capsule, cuboid); the exact distance is evaluated only when some lane of the wavefront is within reach.
+    float mid[L][3];
+    if constexpr (!WANT_MIN) {
+#pragma unroll
+        for (int c = 0; c < T::L; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mid[c][k] = 0.5f * (w0[c][k] + w1[c][k]);
+    }
     CollOut r;
     r.min_self = INFINITY;
     r.self_hit = 0;
@@ -349,6 +383,9 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
 #pragma unroll
         for (int pi = 0; pi < T::P; ++pi) {
             const int a = T::pair_a[pi], b = T::pair_b[pi];
+            if constexpr (!WANT_MIN) {
+                if (cull_far(mid_dist2(mid[a], mid[b]), T::pair_cull[pi])) continue;
+            }
             const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
             if constexpr (WANT_MIN) {
                 const float v = __builtin_sqrtf(d2) - (T::cap_r[a] + T::cap_r[b]);
@@ -366,6 +403,9 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
             float me = INFINITY;
 #pragma unroll
             for (int c = 0; c < T::L; ++c) {
+                if constexpr (!WANT_MIN) {
+                    if (cull_far(point_box_dist2(mid[c], co.obs_lo[o], co.obs_hi[o]), T::cap_cull[c])) continue;
+                }
                 const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
                     const float v = __builtin_sqrtf(d2) - T::cap_r[c];
@@ -406,6 +446,12 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
             float a0[3], a1[3], b0[3], b1[3];
             lds_capsule(lds, tid, a, a0, a1);
             lds_capsule(lds, tid, b, b0, b1);
+            if constexpr (!WANT_MIN) {
+                float ma[3], mb[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ma[k] = 0.5f * (a0[k] + a1[k]), mb[k] = 0.5f * (b0[k] + b1[k]);
+                if (cull_far(mid_dist2(ma, mb), co.pair_cull[pi])) continue;
+            }
             const float d2 = seg_seg_dist2(a0, a1, b0, b1);
             if constexpr (WANT_MIN) {
                 const float v = __builtin_sqrtf(d2) - (co.cap_r[a] + co.cap_r[b]);
@@ -424,6 +470,12 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
             for (int c = 0; c < co.ncaps; ++c) {
                 float w0[3], w1[3];
                 lds_capsule(lds, tid, c, w0, w1);
+                if constexpr (!WANT_MIN) {
+                    float m[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) m[k] = 0.5f * (w0[k] + w1[k]);
+                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), co.cap_cull[c])) continue;
+                }
                 const float d2 = seg_box_dist2(w0, w1, co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
                     const float v = __builtin_sqrtf(d2) - co.cap_r[c];
@@ -482,18 +534,106 @@ __device__ __forceinline__ void load_target(const float* __restrict__ target, in
     quat_to_mat(t[3], t[4], t[5], t[6], Rt);
 }
 
-// COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances
-template <class RB, int COLL>
-__global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
-                                                          const float* __restrict__ x_in,
-                                                          const float* __restrict__ target, const cppf_lm_outputs out) {
-    extern __shared__ float lds[];
+// What one row hands to the in-kernel per-seed summary (block_seed_summary)
+struct RowSummary {
+    float pos_err = 0.f, rot_err = 0.f, cost = 0.f;
+    int self_hit = 0, env_hit = 0, jl = 0;
+};
+
+// DPP reduction of a NON-NEGATIVE value over the 64 lanes of a wavefront into lane 63 (other lanes end up with partial
+// results).  Lanes without a source in a DPP step read the identity 0 (`old` operand), valid for max and for sums here
+// because every reduced quantity is >= 0.  No LDS traffic (ds_bpermute butterflies cost ~50 LDS-pipe ops per wave).
+template <int CTRL>
+__device__ __forceinline__ float dpp_or_zero(float x) {  // lanes without a source lane read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    const float s1 = dpp_or_zero<0x111>(v), s2 = dpp_or_zero<0x112>(v), s3 = dpp_or_zero<0x113>(v);  // row_shr:1,2,3
+    v = op(op(v, s1), op(s2, s3));         // the 4 lanes ending here (within a row of 16)
+    v = op(v, dpp_or_zero<0x114>(v));      // row_shr:4   -> 8 lanes
+    v = op(v, dpp_or_zero<0x118>(v));      // row_shr:8   -> lane 15 of each row holds its row
+    v = op(v, dpp_or_zero<0x142>(v));      // row_bcast:15 -> lanes 31 / 63 hold rows 0-1 / 2-3
+    v = op(v, dpp_or_zero<0x143>(v));      // row_bcast:31 -> lane 63 holds all four rows
+    return v;
+}
+
+// Per-seed summary inside the fused launch (same 8 numbers, bit for bit, as seed_summary_kernel; every reduction is a max
+// or a sum of small integers / multiples of 100, so the order does not matter).  Requires W in {64, 128, 256}: a workgroup
+// then covers whole seeds and a seed is 1, 2 or 4 whole wavefronts.  Joint changes need the NEXT waypoint's final q:
+// lane + 1 through DPP wave_shl:1, the first lane of the next wavefront through LDS.
+template <class RB>
+__device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t row, bool active, const float (&q)[RB::D],
+                                                   const RowSummary& rs, float* __restrict__ out) {
     constexpr int D = RB::D;
-    const RB rb{ch, co};
-    const int tid = threadIdx.x;
-    const size_t row = (size_t)blockIdx.x * kBlock + tid;
-    if (row >= (size_t)prm.n) return;
-    float q[D], Rt[9], tt[3];
+    __shared__ float s_q[kBlock / 64][D];
+    __shared__ float s_red[kBlock / 64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float rad2deg = 57.29577951308232087680f;
+    const int wps = W >> 6;  // wavefronts per seed: 1, 2 or 4
+    if (wps > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s_q[wave][j] = q[j];
+        }
+        __syncthreads();
+    }
+    const bool seed_ends_here = ((wave + 1) & (wps - 1)) == 0;  // this wavefront holds the seed's last waypoints
+    const bool has_next = active && !(lane == 63 && seed_ends_here);
+    const int nw = wave + 1 < kBlock / 64 ? wave + 1 : wave;
+    float mrev = 0.f, mpri = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float qn = dpp_or_zero<0x130>(q[j]);  // wave_shl:1 -- lane i reads lane i + 1
+        qn = (lane == 63) ? s_q[nw][j] : qn;  // (stale but unused when wps == 1: has_next is false there)
+        const float dq = qn - q[j];
+        const bool pr = rb.pris(j);
+        const float a = pr ? fabsf(100.f * dq) : fabsf(rad2deg * wrap_pi(dq));
+        mpri = fmaxf(mpri, pr ? a : 0.f);
+        mrev = fmaxf(mrev, pr ? 0.f : a);
+    }
+    float v[8] = {100.f * rs.pos_err, rad2deg * rs.rot_err, has_next ? mrev : 0.f, has_next ? mpri : 0.f,
+                  (float)rs.self_hit, (float)rs.env_hit, (float)rs.jl, rs.cost};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = active ? v[k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_reduce_to_lane63<true>(v[k]);
+#pragma unroll
+    for (int k = 4; k < 8; ++k) v[k] = wave_reduce_to_lane63<false>(v[k]);
+    float* o = out + ((uint32_t)row >> (31 - __builtin_clz((uint32_t)W))) * 8;  // seed = row / W, W a power of two
+    if (wps == 1) {
+        if (active && lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = v[k];
+        }
+        return;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (active && lane == 63 && seed_ends_here) {
+        for (int i = 1; i < wps; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], s_red[wave - i][k]);
+#pragma unroll
+            for (int k = 4; k < 8; ++k) v[k] += s_red[wave - i][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = v[k];
+    }
+}
+
+// one row of the fused launch: K LM iterations, then metrics / collision stage
+template <class RB, int COLL>
+__device__ __forceinline__ void lm_fused_row(const RB& rb, const CollK& co, const LmK& prm, const float* __restrict__ x_in,
+                                             const float* __restrict__ target, const cppf_lm_outputs& out, float* lds,
+                                             int tid, size_t row, float (&q)[RB::D], RowSummary& rs) {
+    constexpr int D = RB::D;
+    float Rt[9], tt[3];
     load_x<D>(x_in, row, q);
     load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
 
@@ -523,28 +663,53 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
     }
     if (out.x_out) store_x<D>(out.x_out, row, q);
 
+    const bool want_metrics = out.pos_err_m || out.rot_err_rad || out.seed_summary;
     if constexpr (COLL != 0) {
         float R[9], p[3];
-        const bool do_self = out.self_mask || out.min_self || out.ext_cost;
-        const bool do_env = out.env_mask || out.min_env || out.ext_cost;
+        const bool do_self = out.self_mask || out.min_self || out.ext_cost || out.seed_summary;
+        const bool do_env = out.env_mask || out.min_env || out.ext_cost || out.seed_summary;
         const CollOut c = collide_row<RB, COLL == 2>(rb, co, q, lds, tid, R, p, do_self, do_env);
-        if (out.pos_err_m || out.rot_err_rad) {
-            float pe, re;
+        if (want_metrics) {
             fk_fixed_ee(rb, R, p);
-            pose_metrics(Rt, tt, R, p, pe, re);
-            if (out.pos_err_m) out.pos_err_m[row] = pe;
-            if (out.rot_err_rad) out.rot_err_rad[row] = re;
+            pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
+            if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
+            if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
         }
-        write_coll_outputs(row, c, jlim_hit<D>(co, q), out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost,
-                           out.min_self, out.min_env);
+        rs.jl = jlim_hit<D>(co, q);
+        rs.self_hit = c.self_hit, rs.env_hit = c.env_hit;
+        rs.cost = 100.f * (float)rs.jl + 1000.f * (float)c.env_hit + 1000.f * (float)c.self_hit;
+        write_coll_outputs(row, c, rs.jl, out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost, out.min_self,
+                           out.min_env);
     } else {
-        if (out.pos_err_m || out.rot_err_rad) {
-            float R[9], p[3], pe, re;
+        if (want_metrics) {
+            float R[9], p[3];
             fk_ee<RB>(rb, q, R, p);
-            pose_metrics(Rt, tt, R, p, pe, re);
-            if (out.pos_err_m) out.pos_err_m[row] = pe;
-            if (out.rot_err_rad) out.rot_err_rad[row] = re;
+            pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
+            if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
+            if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
         }
+    }
+}
+
+// COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
+// out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
+template <class RB, int COLL>
+__global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+                                                          const float* __restrict__ x_in,
+                                                          const float* __restrict__ target, const cppf_lm_outputs out) {
+    extern __shared__ float lds[];
+    constexpr int D = RB::D;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    const bool active = row < (size_t)prm.n;
+    float q[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = 0.f;
+    RowSummary rs;
+    if (active) lm_fused_row<RB, COLL>(rb, co, prm, x_in, target, out, lds, tid, row, q, rs);
+    if constexpr (COLL != 0) {
+        if (out.seed_summary) block_seed_summary<RB>(rb, prm.W, row, active, q, rs, out.seed_summary);
     }
 }
 
@@ -1253,21 +1418,6 @@ __global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, co
 // mjacs[k,k,T-1] (1 GB at k = 1024, T = 256); here every entry lives in a register for one compare.
 // Work arrays are time-major so that a step reads two contiguous [k,d] slabs: qT[t][a][j], costsT[t][a], memoT[t][b].
 
-// torch.remainder(x, 2pi) - pi for x = dq + pi, exactly as fmodf does it for |x| < 4 pi (one exact +-2pi step), fmodf beyond
-__device__ __forceinline__ float wrap_pi_bounded(float dq) {
-    const float pi = 3.14159265358979323846f, p2 = 2.f * pi;
-    const float x = dq + pi;
-    float r;
-    if (__builtin_expect(fabsf(x) < 2.f * p2, 1)) {
-        r = x >= p2 ? x - p2 : x;  // exact (Sterbenz)
-        r = r <= -p2 ? r + p2 : r;
-    } else {
-        r = __builtin_fmodf(x, p2);
-    }
-    if (r < 0.f) r += p2;
-    return r - pi;
-}
-
 __global__ __launch_bounds__(256) void dp_transpose_kernel(const float* __restrict__ q, const float* __restrict__ ext, int k,
                                                            int T, int d, float* __restrict__ qT, float* __restrict__ costsT) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1313,7 +1463,7 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
             for (int j = 0; j < D; ++j) {
                 float dq = qb[i][j] - qa[j];
                 if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-                m = fmaxf(m, fabsf(wrap_pi_bounded(dq)));
+                m = fmaxf(m, fabsf(wrap_pi(dq)));
             }
             const float v = fmaxf(m, c) + eb[i];  // search.py:157-158
             if (v < best[i]) {
@@ -1455,6 +1605,23 @@ float sqrt_threshold(float r) {
     while (std::sqrt(y) >= r) y = std::nextafterf(y, 0.f);
     while (std::sqrt(y) < r) y = std::nextafterf(y, INFINITY);
     return y;
+}
+
+// broad-phase thresholds (see cull_far): (reach + 1 cm)^2 (1 + 1e-4), rounded up to fp32
+double cap_half_length(const cppf_robot_desc& d, int c) {
+    double s = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double v = (double)d.cap_p1[c][k] - (double)d.cap_p0[c][k];
+        s += v * v;
+    }
+    return 0.5 * std::sqrt(s);
+}
+
+float cull_threshold(double reach) {
+    const double y = (reach + 0.01) * (reach + 0.01) * (1.0 + 1e-4);
+    float f = (float)y;
+    if ((double)f < y) f = std::nextafterf(f, INFINITY);
+    return f;
 }
 
 // does a description equal a generated compile-time table exactly?
@@ -1611,6 +1778,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.cap_r[c] = desc->cap_r[c];
         co.cap_link[c] = (int8_t)desc->cap_link[c];
         co.cap_thr[c] = sqrt_threshold(desc->cap_r[c]);
+        co.cap_cull[c] = cull_threshold(cap_half_length(*desc, c) + (double)desc->cap_r[c]);
     }
     // cap_begin[l+1] = first capsule whose link >= l
     for (int l = -1; l <= d; ++l) {
@@ -1623,6 +1791,9 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.pair_a[p] = (uint8_t)desc->pairs[p][0];
         co.pair_b[p] = (uint8_t)desc->pairs[p][1];
         co.pair_thr[p] = sqrt_threshold(desc->cap_r[desc->pairs[p][0]] + desc->cap_r[desc->pairs[p][1]]);
+        const int a = desc->pairs[p][0], b = desc->pairs[p][1];
+        co.pair_cull[p] = cull_threshold(cap_half_length(*desc, a) + cap_half_length(*desc, b) + (double)desc->cap_r[a] +
+                                         (double)desc->cap_r[b]);
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
     rb->static_id = find_static_robot(*desc);
@@ -1737,8 +1908,20 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     prm.clamp = params->clamp;
     prm.n = (int)n;
     prm.W = W;
-    const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self || out->min_env;
+    const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self ||
+                      out->min_env || out->seed_summary;
     hipStream_t st = (hipStream_t)stream;
+    // per-seed summary: fused into the launch when a workgroup holds whole seeds, else the separate reduction afterwards
+    cppf_lm_outputs outk = *out;
+    float* const summary_dst = out->seed_summary;
+    const bool summary_after = out->seed_summary && !(W == 64 || W == 128 || W == 256);
+    if (summary_after) {
+        CPPF_REQUIRE(out->x_out && out->pos_err_m && out->rot_err_rad && out->self_mask && out->env_mask &&
+                         out->jlim_mask && out->ext_cost,
+                     "seed_summary with W not in {64, 128, 256} needs x_out, pos_err_m, rot_err_rad, the three masks and ext_cost");
+        outk.seed_summary = nullptr;
+    }
+    out = &outk;
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
     if (coll && (out->min_self || out->min_env)) {
 #define CPPF_BODY                                                                                                 \
@@ -1759,7 +1942,11 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     }
-    return check_launch(robot);
+    if (int rc = check_launch(robot)) return rc;
+    if (summary_after)
+        return cppf_seed_summary(robot, outk.x_out, S, W, outk.ext_cost, outk.pos_err_m, outk.rot_err_rad, outk.self_mask,
+                                 outk.env_mask, outk.jlim_mask, summary_dst, stream);
+    return CPPF_OK;
 }
 
 int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,

@@ -37,6 +37,8 @@ struct CollK {
     int8_t cap_link[CPPF_MAX_CAPSULES];   // moving link of each capsule (-1 = base)
     float pair_thr[CPPF_MAX_PAIRS];       // smallest y with sqrt_rn(y) >= r_a + r_b:  sqrt(d2) - (r_a+r_b) < 0  <=>  d2 < y
     float cap_thr[CPPF_MAX_CAPSULES];     // the same for r alone (capsule vs cuboid)
+    float pair_cull[CPPF_MAX_PAIRS];      // broad phase: (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4), h = half length
+    float cap_cull[CPPF_MAX_CAPSULES];    // broad phase: (h + r + 1 cm)^2 (1 + 1e-4)
     uint8_t pair_a[CPPF_MAX_PAIRS];
     uint8_t pair_b[CPPF_MAX_PAIRS];
     float obs_lo[CPPF_MAX_OBSTACLES][3];  // world-frame box corners
@@ -357,12 +359,20 @@ __device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float 
     return __builtin_sqrtf(seg_box_dist2(P0, P1, lo, hi));
 }
 
-// torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153)
+// torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153).  For |dq + pi| < 4 pi -- every difference of
+// two in-limit joint values -- fmodf is one exact +-2 pi step (Sterbenz), spelled out here; beyond that the fmodf expansion.
 __device__ __forceinline__ float wrap_pi(float dq) {
-    const float pi = 3.14159265358979323846f;
-    float m = __builtin_fmodf(dq + pi, 2.f * pi);
-    if (m < 0.f) m += 2.f * pi;
-    return m - pi;
+    const float pi = 3.14159265358979323846f, p2 = 2.f * pi;
+    const float x = dq + pi;
+    float r;
+    if (__builtin_expect(fabsf(x) < 2.f * p2, 1)) {
+        r = x >= p2 ? x - p2 : x;
+        r = r <= -p2 ? r + p2 : r;
+    } else {
+        r = __builtin_fmodf(x, p2);
+    }
+    if (r < 0.f) r += p2;
+    return r - pi;
 }
 
 }  // namespace cppf

@@ -52,6 +52,16 @@ def sqrt_threshold(r) -> np.float32:
     return y
 
 
+def cull_threshold(reach: float) -> np.float32:
+    """Broad-phase threshold on a squared mid-point distance: (reach + 1 cm)^2 (1 + 1e-4), rounded up to fp32 (reach = half
+    lengths + radii).  Conservative by construction -- see cull_far in csrc/cppflow_hip.hip."""
+    y = (float(reach) + 0.01) ** 2 * (1.0 + 1e-4)
+    f = np.float32(y)
+    if float(f) < y:
+        f = np.nextafter(f, np.float32(np.inf))
+    return f
+
+
 def emit_robot(name: str, ch: CanonicalChain) -> str:
     d, L, P = ch.ndof, ch.n_capsules, ch.n_pairs
     cname = "".join(p.capitalize() for p in name.split("_"))
@@ -76,6 +86,11 @@ def emit_robot(name: str, ch: CanonicalChain) -> str:
     cap_thr = [sqrt_threshold(r) for r in r32] if L else [0]
     s.append(f"    static constexpr float pair_thr[{Pm}] = {_arr(pair_thr)};  // sqrt thresholds of r_a + r_b")
     s.append(f"    static constexpr float cap_thr[{Lm}] = {_arr(cap_thr)};  // sqrt thresholds of r")
+    half = 0.5 * np.linalg.norm(ch.cap_p1.astype(np.float32).astype(np.float64) - ch.cap_p0.astype(np.float32).astype(np.float64), axis=-1) if L else []
+    pair_cull = [cull_threshold(half[a] + half[b] + float(r32[a]) + float(r32[b])) for a, b in ch.pairs] if P else [0]
+    cap_cull = [cull_threshold(half[c] + float(r32[c])) for c in range(L)] if L else [0]
+    s.append(f"    static constexpr float pair_cull[{Pm}] = {_arr(pair_cull)};  // broad phase, pairs")
+    s.append(f"    static constexpr float cap_cull[{Lm}] = {_arr(cap_cull)};  // broad phase, capsule vs cuboid")
     s.append(f"    static constexpr int pair_a[{Pm}] = {{" + ", ".join(str(int(v)) for v in (ch.pairs[:, 0] if P else [0])) + "};")
     s.append(f"    static constexpr int pair_b[{Pm}] = {{" + ", ".join(str(int(v)) for v in (ch.pairs[:, 1] if P else [0])) + "};")
     s.append("};")

@@ -260,6 +260,7 @@ class Robot:
         want_min_dists: bool = False,
         x_out: Optional[torch.Tensor] = None,
         packed_out: Optional[torch.Tensor] = None,
+        summary_out: Optional[torch.Tensor] = None,
     ) -> Dict[str, torch.Tensor]:
         """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
         (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7].
@@ -267,7 +268,10 @@ class Robot:
         `x_out` (may be `x` itself) and `packed_out` let a caller reuse buffers: `packed_out` is a uint8 tensor of
         `PACKED_BYTES_PER_ROW * n` bytes that receives ext_cost | pos_err_m | rot_err_rad (fp32 [n] each) then
         self_mask | env_mask | jlim_mask (u8 [n] each) back to back -- the single buffer one RCCL all-gather ships to
-        every rank; it implies want_errors and want_collisions."""
+        every rank; it implies want_errors and want_collisions.  `summary_out` (fp32 [S,8], fields
+        SEED_SUMMARY_FIELDS) receives the per-seed reduction of `seed_summary`, computed inside the same launch when
+        W is 64, 128 or 256 and by a second kernel otherwise (which then needs the per-row outputs, i.e. `packed_out` or
+        want_errors + want_collisions)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
@@ -308,6 +312,10 @@ class Robot:
                 res["min_self"] = torch.empty(n, dtype=torch.float32, device=dev)
                 res["min_env"] = torch.empty(n, dtype=torch.float32, device=dev)
                 out.min_self, out.min_env = res["min_self"].data_ptr(), res["min_env"].data_ptr()
+        if summary_out is not None:
+            _check_summary_buffer(summary_out, n // W, dev)
+            out.seed_summary = summary_out.data_ptr()
+            res["seed_summary"] = summary_out
         prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
         _hip.check(
             _hip.lib().cppf_lm_pose_steps(
@@ -319,10 +327,11 @@ class Robot:
 
     def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
                        alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
-                       clamp: bool = True) -> "LmLaunchPlan":  # fmt: skip
+                       clamp: bool = True, summary_out: Optional[torch.Tensor] = None) -> "LmLaunchPlan":  # fmt: skip
         """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
         holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation."""
-        return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp)
+        return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
+                            summary_out)
 
     def collision_masks(
         self, q: torch.Tensor, want_min_dists: bool = False, only: Optional[Sequence[str]] = None
@@ -473,14 +482,22 @@ class Robot:
         return out
 
 
+def _check_summary_buffer(t: torch.Tensor, S: int, dev) -> None:
+    assert t.shape == (S, 8) and t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and t.device == dev, (
+        f"summary_out must be a contiguous fp32 [{S}, 8] tensor on {dev}"
+    )
+
+
 class LmLaunchPlan:
-    def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp):
+    def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
+                 summary_out=None):  # fmt: skip
         x = robot._x2d(x)
         x_out = robot._x2d(x_out, "x_out")
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
         assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0 and x_out.shape == x.shape
         self._keep = (robot, x, target, x_out, packed_out)  # the plan owns references to every buffer it points at
+        self._summary_keep = summary_out
         self.outputs: Dict[str, torch.Tensor] = {"x": x_out}
         out = _hip.LmOutputs()
         out.x_out = x_out.data_ptr()
@@ -494,6 +511,10 @@ class LmLaunchPlan:
             for k, v in views.items():
                 setattr(out, k, v.data_ptr())
             self.outputs.update(views)
+        if summary_out is not None:
+            _check_summary_buffer(summary_out, n // W, x.device)
+            out.seed_summary = summary_out.data_ptr()
+            self.outputs["seed_summary"] = summary_out
         self._out = out
         self._prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
         self._fn = _hip.lib().cppf_lm_pose_steps
@@ -505,6 +526,19 @@ class LmLaunchPlan:
         rc = self._fn(*self._args, torch.cuda.current_stream(self._device).cuda_stream)
         if rc:
             _hip.check(rc)
+
+    def launch_on(self, stream: "torch.cuda.Stream") -> None:
+        """`launch()` on an explicit HIP stream: independent batches in flight on two streams overlap one launch's tail with
+        the next one's ramp-up (each batch needs its own output buffers)."""
+        rc = self._fn(*self._args, stream.cuda_stream)
+        if rc:
+            _hip.check(rc)
+
+    def set_summary_out(self, summary_out: torch.Tensor) -> None:
+        """Point the next launches' per-seed summary at another [S,8] buffer (a ring of buffers in flight on the wire)."""
+        _check_summary_buffer(summary_out, self._args[3], self._device)
+        self._out.seed_summary = summary_out.data_ptr()
+        self.outputs["seed_summary"] = summary_out
 
     def summary_launcher(self, out: torch.Tensor):
         """A zero-allocation callable that reduces this plan's per-row outputs into `out` [S,8] (`Robot.seed_summary`)."""

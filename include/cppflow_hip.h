@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 1
+#define CPPF_ABI_VERSION 2
 
 #define CPPF_MAX_DOF 16
 #define CPPF_MAX_CAPSULES 24
@@ -82,6 +82,10 @@ typedef struct cppf_lm_outputs {
     float* ext_cost;      /* [n]  100*jlim + 1000*env + 1000*self        (search.py:14-15, 146-150) */
     float* min_self;      /* [n]  min over pairs of the signed distance (+inf when no pairs) */
     float* min_env;       /* [n]  min over obstacles and capsules       (+inf when no obstacles) */
+    float* seed_summary;  /* [S,8] the reduction of cppf_seed_summary over each seed's W rows, produced by the same launch
+                           * when W is 64, 128 or 256 (a 256-row workgroup then holds whole seeds); for any other W the entry point runs the
+                           * separate reduction kernel afterwards, which needs x_out, pos_err_m, rot_err_rad, the three masks
+                           * and ext_cost to be non-NULL.  Implies the collision stage. */
 } cppf_lm_outputs;
 
 typedef struct cppf_robot cppf_robot; /* opaque: host copy of the description + launch state for one device */

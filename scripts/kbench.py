@@ -37,6 +37,11 @@ def main():
             for coll in (False, True):
                 cases.append((f"{name} lm K={K} coll={int(coll)}", (lambda rb=rb, x0=x0, t=target, xo=xo, pk=packed, K=K, coll=coll:
                               rb.lm_pose_steps(x0, t, 1e-6, 3.5, 0.35, n_steps=K, x_out=xo, packed_out=pk if coll else None, want_errors=not coll)), K))
+        sm = torch.empty((args.seeds, 8), dtype=torch.float32, device=dev)
+        plan = rb.lm_launch_plan(x0, target, 1e-6, 3.5, 0.35, n_steps=10, x_out=xo, packed_out=packed)
+        plan_s = rb.lm_launch_plan(x0, target, 1e-6, 3.5, 0.35, n_steps=10, x_out=xo, packed_out=packed, summary_out=sm)
+        cases.append((f"{name} plan K=10 coll=1", plan.launch, 10))
+        cases.append((f"{name} plan K=10 coll=1 +summary", plan_s.launch, 10))
         cases.append((f"{name} collision_masks", (lambda rb=rb, q3=q3: rb.collision_masks(q3)), 0))
         cases.append((f"{name} fk", (lambda rb=rb, x0=x0: rb.forward_kinematics(x0)), 0))
         from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from cppflow_amd import _hip
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -487,6 +488,44 @@ def test_seed_summary_matches_oracle_pieces(robots):
     assert np.abs(got[:, 2:4] - want[:, 2:4]).max() < 1e-3
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+@pytest.mark.parametrize("generic", [False, True])
+def test_in_launch_seed_summary_equals_separate_reduction(robots, name, generic):
+    """cppf_lm_outputs.seed_summary: the fused launch's own per-seed epilogue (W = 64, 128, 256: whole seeds per workgroup,
+    partially filled last workgroups, seeds spanning 1 / 2 / 4 wavefronts) and the fall-back (any other W)
+    both equal cppf_seed_summary over the same launch's per-row outputs bit for bit -- every reduction in it is a max or an
+    exact sum.  Also without any per-row output buffer (the summary alone implies the collision stage)."""
+    from cppflow_amd.problems_synthetic import obstacle_arrays
+
+    rb = robots[name]
+    obs = H.PANDA_2CUBES if name == "panda" else obstacle_arrays([(0.7, 0.1, 0.8, 0.3, 0.3, 0.3)])
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    _hip.lib().cppf_debug_force_generic(int(generic))
+    try:
+        for S, W in ((5, 1), (9, 2), (7, 32), (5, 64), (3, 128), (3, 256), (4, 100), (2, 300)):
+            x0, target = H.lm_problem(name, S, W, seed=100 + W)
+            x0[: W // 2] = 0.0  # a stretch of colliding / limit-hugging rows so that the counts are not all zero
+            packed = torch.empty(rb.PACKED_BYTES_PER_ROW * S * W, dtype=torch.uint8, device=DEV)
+            fused = torch.full((S, 8), -1.0, dtype=torch.float32, device=DEV)
+            r = rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=2, packed_out=packed, summary_out=fused)
+            want = rb.seed_summary(r["x"], packed, S, W)
+            assert torch.equal(fused, want), (S, W, fused, want)
+            if W in (64, 128, 256):
+                alone = torch.full((S, 8), -1.0, dtype=torch.float32, device=DEV)
+                r2 = rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=2, summary_out=alone)
+                assert torch.equal(alone, want) and torch.equal(r2["x"], r["x"]), (S, W)
+            else:
+                with pytest.raises(AssertionError, match="seed_summary"):
+                    rb.lm_pose_steps(dev(x0), dev(target), 1e-6, 3.5, 0.35, n_steps=2,
+                                     summary_out=torch.empty((S, 8), dtype=torch.float32, device=DEV))  # fmt: skip
+        assert float(want[:, 4:].sum()) >= 0
+    finally:
+        _hip.lib().cppf_debug_force_generic(0)
+        rb.set_obstacles([], [])
+        rb.set_joint_limit_padding(None, None)
 
 
 def test_entry_points_are_hip_graph_capturable(robots):
