@@ -11,8 +11,11 @@ seeds: weak scaling, seeds sharded, no data-path collective other than that all-
 
 Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two
 cuboids of panda__2cubes -- the configuration the metric is quoted on ("1024 seeds x 256 waypoints x 7-DoF at 1 MI355X").
-Inputs are synthetic and already resident in HBM when the timed region starts: per waypoint q* ~ U(limits),
-target = FK(q*), seeds x0 = clamp(q* + 0.1 randn)  (the construction of the reference's tests/optimization_test.py:82,136-137).
+Inputs are already resident in HBM when the timed region starts: the target path is the named reference
+problem's (panda__2cubes resampled to 256 waypoints; committed fixture), the seeds are synthetic -- per seed an IK branch
+tracking the path, x0 = clamp(q*_s + 0.1 randn) (the construction of the reference's tests/optimization_test.py:82).
+`--inputs random` switches to the 8d fall-back (independent q* ~ U(limits) per waypoint, tests/optimization_test.py:136-137),
+which is the worst case for the wave-uniform collision broad phase.
 
 Prints ONE JSON line (rank 0).
 """
@@ -76,6 +79,61 @@ def make_inputs(robot, S, W, device, seed):
     x0 = q_star[None] + 0.1 * torch.randn((S, W, robot.ndof), generator=g2)
     x0 = torch.minimum(torch.maximum(x0, lo), hi).reshape(S * W, robot.ndof).contiguous()
     return x0.to(device), target.contiguous()
+
+
+PROBLEM_PATHS = {  # tests/golden/reference_paths.npz: the target paths of the problems BASELINE.json's configs name
+    ("panda", 64): "panda__1cube_first64",
+    ("fetch", 256): "fetch__hello_first256",
+    ("panda", 256): "panda__2cubes_resampled256",
+}
+
+
+def make_inputs_problem(robot, S, W, device, seed):
+    """SURVEY.md 8(d) inputs: the target path of the reference problem the configuration names (committed fixture; the 12-DoF
+    chain has no reference problem: target = FK of a smooth random walk q*_{t+1} = clamp(q*_t + 0.02 randn)) and, per seed, a
+    distinct IK branch q*_s that tracks the path (waypoint 0 solved by damped LM from a U(limits) start, every later waypoint
+    warm-started from its predecessor -- what IKFlow + dp_search hand to the optimiser), then x0 = clamp(q*_s + 0.1 randn)
+    (the construction of the reference's tests/optimization_test.py:82).  Returns (x0 [S*W,d], target [W,7], description)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lo = torch.tensor([l for l, _ in robot.actuated_joints_limits], dtype=torch.float32)
+    hi = torch.tensor([u for _, u in robot.actuated_joints_limits], dtype=torch.float32)
+    d = robot.ndof
+    key = PROBLEM_PATHS.get((robot.name, W))
+    if key is not None:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "reference_paths.npz"))
+        target = torch.tensor(z[key], dtype=torch.float32, device=device).contiguous()
+        what = f"target path = {key} (reference problem, tests/golden/reference_paths.npz)"
+    else:
+        q = torch.empty((W, d), dtype=torch.float32)
+        q[0] = lo + (hi - lo) * torch.rand(d, generator=g)
+        steps = 0.02 * torch.randn((W, d), generator=g)
+        for t in range(1, W):
+            q[t] = torch.minimum(torch.maximum(q[t - 1] + steps[t], lo), hi)
+        target = robot.forward_kinematics(q.to(device)).contiguous()
+        what = "target path = FK of a smooth random walk (q*_{t+1} = clamp(q*_t + 0.02 randn))"
+    lo_d, hi_d = lo.to(device), hi.to(device)
+    branch = torch.empty((S, W, d), dtype=torch.float32, device=device)
+    # waypoint 0: damped LM from random starts, re-drawing the seeds that did not reach the pose (up to 12 rounds)
+    x = torch.empty((S, d), dtype=torch.float32, device=device)
+    todo = torch.ones(S, dtype=torch.bool, device=device)
+    for _ in range(12):
+        start = (lo + (hi - lo) * (0.1 + 0.8 * torch.rand((S, d), generator=g))).to(device).contiguous()
+        r = robot.lm_pose_steps(start, target[0:1], 1e-2, 3.5, 0.35, n_steps=60)
+        r = robot.lm_pose_steps(r["x"], target[0:1], 1e-6, 3.5, 0.35, n_steps=10, want_errors=True)
+        ok = (r["pos_err_m"] < 1e-4) & (r["rot_err_rad"] < 1.75e-3)
+        take = todo & ok
+        x[take] = r["x"][take]
+        todo &= ~ok
+        if not bool(todo.any()):
+            break
+    x[todo] = r["x"][todo]
+    x = x.contiguous()
+    for w in range(W):
+        x = robot.lm_pose_steps(x, target[w : w + 1].contiguous(), 1e-6, 3.5, 0.35, n_steps=8)["x"]
+        branch[:, w] = x
+    noise = 0.1 * torch.randn((S, W, d), generator=g)
+    x0 = torch.minimum(torch.maximum(branch + noise.to(device), lo_d), hi_d).reshape(S * W, d).contiguous()
+    return x0, target, what + "; seeds = per-seed IK branch tracking the path + 0.1 randn"
 
 
 def _cpu_inputs(chain, W, d, S_cpu, seed=0):
@@ -182,6 +240,9 @@ def main():
     ap.add_argument("--waypoints", type=int, default=256)
     ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps alternate between")
+    ap.add_argument("--inputs", choices=["problem", "random"], default="problem",
+                    help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); "
+                    "random: independent random configurations per waypoint (the 8d fall-back, worst case for the broad phase)")  # fmt: skip
     ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
@@ -234,7 +295,11 @@ def main():
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
 
-    x0, target = make_inputs(robot, S, W, device, seed=rank)
+    if args.inputs == "problem":
+        x0, target, inputs_desc = make_inputs_problem(robot, S, W, device, seed=rank)
+    else:
+        x0, target = make_inputs(robot, S, W, device, seed=rank)
+        inputs_desc = "per waypoint q* ~ U(limits), target = FK(q*), seeds = clamp(q* + 0.1 randn) (SURVEY 8d fall-back inputs)"
     NBUF = 4  # ring depth of output buffer sets (see below)
     x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
     packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
@@ -367,6 +432,8 @@ def main():
             "config": {
                 "workload": f"{args.robot}{'__2cubes geometry' if obstacles else ''}, {S} seeds/GPU x {W} waypoints x {d}-DoF, K={K} fused LM "
                 f"iterations per launch" + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
+                "inputs": inputs_desc,
+                "streams": n_streams,
                 "robot": args.robot,
                 "seeds_per_gpu": S,
                 "waypoints": W,

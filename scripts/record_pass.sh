@@ -13,6 +13,8 @@ timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"
 echo "== bench, one stream"
 timeout -k 10 300 python bench.py --no-cpu-baseline --streams 1 > "$OUT/bench_streams1.json" 2>> "$OUT/bench.err"
+echo "== bench, random inputs (SURVEY 8d fall-back; worst case for the broad phase)"
+timeout -k 10 300 python bench.py --no-cpu-baseline --inputs random > "$OUT/bench_random_inputs.json" 2>> "$OUT/bench.err"
 echo "== bench, one-rank RCCL group"
 CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > "$OUT/bench_dist1.json" 2>> "$OUT/bench.err"
 for c in C2 C3 C5; do
@@ -23,15 +25,19 @@ echo "== kbench"
 timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
 echo "== rocprofv3 pmc FETCH_SIZE"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
 echo "== rocprofv3 pmc WRITE_SIZE"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
 echo "== rocprofv3 pmc SQ_INSTS_VALU SQ_WAVES"
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES -d "$OUT/pmc_valu" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d "$OUT/pmc_valu" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu_stderr.txt"
 cd "$ROOT"
-find "$OUT" -name "*.csv" | head -30
+if [ -x build_var/valu_rate ]; then
+    echo "== VALU issue-rate calibration (hipcc --offload-arch=gfx950 -O3 scripts/ubench/valu_rate.hip -o build_var/valu_rate)"
+    timeout -k 5 120 ./build_var/valu_rate > "$OUT/valu_issue_rate_calibration.txt" 2>&1
+fi
 # keep the merge small: drop anything big that is not a csv / json / txt summary
-find "$OUT" -type f -size +8M -delete
+find "$OUT" -type f -size +30M -delete
+find "$OUT" -type f | xargs ls -la | awk '{print $5, $9}'
 echo "== done"

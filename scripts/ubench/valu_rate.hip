@@ -10,6 +10,8 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b) {
     float v0 = threadIdx.x, v1 = v0 + 1, v2 = v0 + 2, v3 = v0 + 3, v4 = v0 + 4, v5 = v0 + 5, v6 = v0 + 6, v7 = v0 + 7;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f p0 = {v0, v1}, p1 = {v2, v3}, p2 = {v4, v5}, p3 = {v6, v7}, pa = {a, a}, pb = {b, b};
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {
             REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -31,9 +33,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
             REP16(asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
                                "v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %1, %1, %2, %3\n"
                                : "+v"(v0), "+v"(v1) : "v"(a), "v"(b));)
+        } else if (MODE == 5) {  // packed fp32: 4 independent v_pk_fma_f32 on aligned register pairs (2 FMAs per lane each)
+            REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                               "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa), "v"(pb));)
+        } else if (MODE == 6) {  // packed fp32, one dependent chain
+            REP16(asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
+                               "v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
+                               : "+v"(p0) : "v"(pa), "v"(pb));)
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
 
 template <int MODE>
@@ -55,11 +65,11 @@ int main() {
     float* d;
     hipMalloc(&d, 256 * 256 * 8 * 256 * sizeof(float));
     const int iters = 2000;
-    const char* names[5] = {"indep fma (vop3 regs)", "1 dependent chain", "indep fmaak literal", "indep fmac (vop2)", "2 dependent chains"};
+    const char* names[7] = {"indep fma (vop3 regs)", "1 dependent chain", "indep fmaak literal", "indep fmac (vop2)", "2 dependent chains", "indep v_pk_fma_f32", "dependent v_pk_fma_f32"};
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = 256 * wps;  // one 256-thread block = 1 wave per SIMD on a CU
-        double t[5] = {run<0>(blocks, iters, d), run<1>(blocks, iters, d), run<2>(blocks, iters, d), run<3>(blocks, iters, d), run<4>(blocks, iters, d)};
-        for (int m = 0; m < 5; ++m) {
+        double t[7] = {run<0>(blocks, iters, d), run<1>(blocks, iters, d), run<2>(blocks, iters, d), run<3>(blocks, iters, d), run<4>(blocks, iters, d), run<5>(blocks, iters, d), run<6>(blocks, iters, d)};
+        for (int m = 0; m < 7; ++m) {
             const double winstr_per_simd = (double)iters * 128 * wps;  // 16*8 instr per iteration per wave
             printf("waves/SIMD %d  %-24s  %8.1f us   %.3f wave-instr/ns/SIMD (cycles/instr @2.4GHz: %.2f)\n", wps, names[m],
                    t[m] * 1e6, winstr_per_simd / (t[m] * 1e9), t[m] * 2.4e9 / winstr_per_simd);
