@@ -3,7 +3,7 @@
  * refinement hot path (pose-only Levenberg-Marquardt step + batched self / environment collision masks).
  *
  * The reference has no FFI for this path (it is pure Python over torch + the un-vendored `jrl` package); the drop-in
- * boundary is therefore a set of Python call signatures, mirrored by cppflow_amd/*.py, each of which lands on exactly
+ * boundary is therefore a set of Python call signatures, mirrored by the modules of cppflow_amd/, each of which lands on exactly
  * one entry point below.  Every entry point cites the reference interface it replaces (paths under /root/reference).
  *
  * Conventions

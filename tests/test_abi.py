@@ -10,6 +10,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "cppflow_hip.h")
 
 
+def build_c_client(out_dir: str) -> str:
+    """gcc -std=c99 of tests/c_client/abi_client.c against include/cppflow_hip.h, the in-tree library and the HIP runtime's C
+    API (no hipcc, no C++): proof that the boundary is a C ABI.  Returns the executable's path."""
+    import subprocess
+
+    from cppflow_amd import _hip, build
+
+    build.build()
+    exe = os.path.join(out_dir, "abi_client")
+    libdir = os.path.dirname(_hip.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror=implicit-function-declaration", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_client", "abi_client.c"),
+           "-o", exe, "-L" + libdir, "-lcppflow_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib"]  # fmt: skip
+    run = subprocess.run(cmd, capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    return exe
+
+
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -79,3 +98,18 @@ def test_generated_robot_tables_are_current():
     from cppflow_amd import gen_robots
 
     assert open(gen_robots.OUT).read() == gen_robots.generate()
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/cppflow_hip.h parses as C99 and as C++17 on its own, and the C99 client of tests/c_client/ compiles and
+    links against the in-tree library (it is run on the GPU by tests/test_gpu_c_client.py)."""
+    import subprocess
+
+    for lang, std in (("c", "-std=c99"), ("c++", "-std=c++17")):
+        run = subprocess.run(["gcc", "-x", lang, std, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", HEADER],
+                             capture_output=True, text=True)  # fmt: skip
+        assert run.returncode == 0, run.stderr
+    exe = build_c_client(str(tmp_path))
+    assert os.access(exe, os.X_OK)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "cppf_lm_pose_steps" in nm and "cppf_robot_create" in nm
