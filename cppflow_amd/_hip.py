@@ -111,6 +111,7 @@ SIGNATURES = {
     ),
     "cppf_pose_error_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "cppf_seed_validity": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cppf_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cppf_seed_summary": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cppf_lm_full_step": (
         ctypes.c_int,

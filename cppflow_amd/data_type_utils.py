@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import yaml
 
+from cppflow_amd.config import ENV_COLLISIONS_IGNORED, SELF_COLLISIONS_IGNORED
 from cppflow_amd.data_types import DEFAULT_CONSTRAINTS, Constraints, Plan, Problem
 from cppflow_amd.robots import Robot, get_robot
 
@@ -205,24 +206,43 @@ def resample_path(path: np.ndarray, n: int) -> np.ndarray:
     return out
 
 
-def plan_from_qpath(qpath: torch.Tensor, problem: Problem) -> Plan:
-    """Evaluate a joint-space path against its problem (cppflow/data_type_utils.py:244-276): FK, pose errors, maximum
-    joint changes, capsule collisions (the reference also runs klampt's exact meshes here), the validity verdict."""
-    from cppflow_amd.evaluation_utils import seed_metrics_are_below_threshold
-
+def plans_from_qpaths(qpaths: torch.Tensor, problem: Problem) -> List[Plan]:
+    """Evaluate S joint-space paths [S,T,d] against one problem in three launches -- FK of every waypoint, the capsule
+    collision masks, and the per-path `Plan` metrics (cppf_plan_metrics) -- instead of the reference's per-path host
+    evaluation (cppflow/data_type_utils.py:244-276).  Collisions are the capsule masks of the hot path (the reference
+    re-checks the final path with klampt's meshes here, which is out of scope)."""
     rb = problem.robot
-    assert qpath.shape == (problem.n_timesteps, rb.ndof), tuple(qpath.shape)
-    q = qpath.contiguous()
-    pose_path = rb.forward_kinematics(q)
-    pe, re = rb.pose_error_metrics(q, problem.target_path)
-    metrics = rb.seed_validity(q, problem.target_path)[0].cpu()
+    assert qpaths.dim() == 3 and qpaths.shape[1:] == (problem.n_timesteps, rb.ndof), tuple(qpaths.shape)
+    S, T, d = qpaths.shape
+    q = qpaths.contiguous()
+    flat = q.view(S * T, d)
+    pose = rb.forward_kinematics(flat).view(S, T, 7)
+    pe, re = rb.pose_error_metrics(flat, problem.target_path)
     problem.bind_obstacles()
-    masks = rb.collision_masks(q.unsqueeze(0), only=("self", "env"))
-    self_c, env_c = masks["self_mask"][0], masks["env_mask"][0]
-    ok, _ = seed_metrics_are_below_threshold(problem.constraints, metrics)
-    return Plan(
-        q_path=q, pose_path=pose_path, target_path=problem.target_path, positional_errors_cm=100 * pe,
-        rotational_errors_deg=torch.rad2deg(re), mjac_deg=float(metrics[2]), mjac_cm=float(metrics[3]),
-        self_colliding_per_ts=self_c, env_colliding_per_ts=env_c,
-        is_valid=bool(ok and not bool(self_c.any()) and not bool(env_c.any())),
-    )  # fmt: skip
+    masks = rb.collision_masks(q, only=("self", "env"))
+    self_c, env_c = masks["self_mask"], masks["env_mask"]
+    if SELF_COLLISIONS_IGNORED:
+        self_c = torch.zeros_like(self_c)
+    if ENV_COLLISIONS_IGNORED:
+        env_c = torch.zeros_like(env_c)
+    metrics = rb.plan_metrics(flat, problem.target_path, self_c.reshape(-1), env_c.reshape(-1),
+                              problem.initial_configuration).cpu()  # fmt: skip
+    rev, pris = rb.split_configs_to_revolute_and_prismatic(flat)
+    rev, pris = rev.view(S, T, -1), pris.view(S, T, -1)
+    pe, re = pe.view(S, T), re.view(S, T)
+    return [
+        Plan(
+            q_path=q[s], q_path_revolute=rev[s], q_path_prismatic=pris[s], pose_path=pose[s], target_path=problem.target_path,
+            robot_joint_limits=rb.actuated_joints_limits, self_colliding_per_ts=self_c[s].bool(),
+            env_colliding_per_ts=env_c[s].bool(), positional_errors=pe[s], rotational_errors=re[s],
+            provided_initial_configuration=problem.initial_configuration, constraints=problem.constraints, metrics=metrics[s],
+        )  # fmt: skip
+        for s in range(S)
+    ]
+
+
+def plan_from_qpath(qpath: torch.Tensor, problem: Problem) -> Plan:
+    """One path [T,d] -> Plan (cppflow/data_type_utils.py:244-276)."""
+    assert isinstance(qpath, torch.Tensor), f"qpath must be a torch.Tensor, got {type(qpath)}"
+    assert qpath.shape == (problem.n_timesteps, problem.robot.ndof), tuple(qpath.shape)
+    return plans_from_qpaths(qpath.unsqueeze(0), problem)[0]

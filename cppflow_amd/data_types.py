@@ -1,12 +1,18 @@
 """Host containers of the reference's `cppflow/data_types.py` that the hot path reads: `Constraints` (`:53-62`),
-`PlannerSettings` (`:65-83`), `TimingData` (`:27-50`), `Problem` (`:377-484`).  `Plan` (reporting) is out of scope."""
+`PlannerSettings` (`:65-83`), `TimingData` (`:27-50`), `Problem` (`:377-484`), and `Plan` / `PlanNp` (`:86-366`) whose scalar
+metrics come from one device reduction for all candidate paths (`cppf_plan_metrics`)."""
 
 from dataclasses import dataclass, field
-from typing import List, Optional
+from time import time
+from typing import List, Optional, Tuple
 
 import torch
 
-from cppflow_amd.config import DEFAULT_RERUN_MJAC_THRESHOLD_CM, DEFAULT_RERUN_MJAC_THRESHOLD_DEG
+from cppflow_amd.config import (
+    DEFAULT_RERUN_MJAC_THRESHOLD_CM,
+    DEFAULT_RERUN_MJAC_THRESHOLD_DEG,
+    SUCCESS_THRESHOLD_initial_q_norm_dist,
+)
 
 
 @dataclass
@@ -58,36 +64,228 @@ class PlannerSettings:
         assert self.latent_vector_scale > 0.0
 
 
+_PLAN_METRIC_INDEX = {name: i for i, name in enumerate((
+    "max_pos_err_cm", "mean_pos_err_cm", "max_rot_err_deg", "mean_rot_err_deg", "mjac_deg", "mjac_cm", "path_length_rad",
+    "path_length_m", "n_joint_limit_violations", "n_self_colliding", "n_env_colliding", "initial_q_norm_dist"))}  # fmt: skip
+
+
 @dataclass
 class Plan:
-    """What a planner returns (a reduced form of cppflow/data_types.py:86-264: the path, its error metrics and the
-    validity verdict; the printing / data-frame plumbing of the reference is not reproduced)."""
+    """A joint-space path evaluated against its problem: the fields and read-only metrics of the reference's `Plan`
+    (cppflow/data_types.py:86-350), same names and units.
+
+    The scalar metrics are not recomputed on the host: `metrics` is one row of `Robot.plan_metrics` (cppf_plan_metrics --
+    every candidate path of a planning call is evaluated in one launch, `data_type_utils.plans_from_qpaths`), copied to
+    the host once.  A Plan built by hand without `metrics` falls back to the torch expressions of
+    `cppflow_amd.evaluation_utils`, which is what the reference does for every property access."""
 
     q_path: torch.Tensor  # [T, d]
+    q_path_revolute: torch.Tensor  # [T, n_revolute]
+    q_path_prismatic: torch.Tensor  # [T, n_prismatic]
     pose_path: torch.Tensor  # [T, 7]
     target_path: torch.Tensor  # [T, 7]
-    positional_errors_cm: torch.Tensor  # [T]
-    rotational_errors_deg: torch.Tensor  # [T]
-    mjac_deg: float
-    mjac_cm: float
-    self_colliding_per_ts: torch.Tensor  # bool [T] (capsules)
-    env_colliding_per_ts: torch.Tensor  # bool [T] (capsules)
-    is_valid: bool
+    robot_joint_limits: List[Tuple[float, float]]
+    self_colliding_per_ts: torch.Tensor  # bool [T]
+    env_colliding_per_ts: torch.Tensor  # bool [T]
+    positional_errors: torch.Tensor  # [T] metres
+    rotational_errors: torch.Tensor  # [T] radians
+    provided_initial_configuration: Optional[torch.Tensor]
+    constraints: Constraints
+    metrics: Optional[torch.Tensor] = None  # host fp32 [>= 12], columns Robot.PLAN_METRIC_FIELDS
+
+    def __post_init__(self):
+        T, d = self.target_path.shape[0], len(self.robot_joint_limits)
+        assert isinstance(self.q_path, torch.Tensor) and self.q_path.shape == (T, d), (
+            f"q_path is {tuple(self.q_path.shape)}, the problem needs {(T, d)}"
+        )
+        for name in ("q_path_revolute", "q_path_prismatic", "pose_path", "target_path"):
+            assert isinstance(getattr(self, name), torch.Tensor), name
+        assert self.positional_errors.numel() == T and self.rotational_errors.numel() == T
+        if self.metrics is not None:
+            self.metrics = self.metrics.detach().to("cpu", torch.float32).reshape(-1)
+            assert self.metrics.numel() >= len(_PLAN_METRIC_INDEX)
+
+    def _metric(self, name: str, fallback) -> float:
+        if self.metrics is not None:
+            return float(self.metrics[_PLAN_METRIC_INDEX[name]])
+        return float(fallback())
+
+    # ---- path length (data_types.py:141-153) ----
+    @property
+    def path_length_rad(self) -> float:
+        from cppflow_amd.evaluation_utils import angular_changes
+
+        return self._metric("path_length_rad", lambda: angular_changes(self.q_path_revolute).abs().sum())
 
     @property
-    def max_positional_error_cm(self) -> float:
-        return float(self.positional_errors_cm.max())
+    def path_length_m(self) -> float:
+        from cppflow_amd.evaluation_utils import prismatic_changes
+
+        if not self.is_a_prismatic_joint:
+            return 0.0
+        return self._metric("path_length_m", lambda: prismatic_changes(self.q_path_prismatic).abs().sum())
+
+    @property
+    def is_a_prismatic_joint(self) -> bool:
+        return self.q_path_prismatic.numel() > 0
+
+    # ---- pose errors (data_types.py:155-186) ----
+    @property
+    def rotational_errors_deg(self) -> torch.Tensor:
+        return torch.rad2deg(self.rotational_errors)
+
+    @property
+    def positional_errors_cm(self) -> torch.Tensor:
+        return 100 * self.positional_errors
+
+    @property
+    def positional_errors_mm(self) -> torch.Tensor:
+        return 1000 * self.positional_errors
 
     @property
     def max_rotational_error_deg(self) -> float:
-        return float(self.rotational_errors_deg.max())
+        return self._metric("max_rot_err_deg", lambda: self.rotational_errors_deg.max())
+
+    @property
+    def mean_rotational_error_deg(self) -> float:
+        return self._metric("mean_rot_err_deg", lambda: self.rotational_errors_deg.mean())
+
+    @property
+    def max_positional_error_cm(self) -> float:
+        return self._metric("max_pos_err_cm", lambda: self.positional_errors_cm.max())
+
+    @property
+    def mean_positional_error_cm(self) -> float:
+        return self._metric("mean_pos_err_cm", lambda: self.positional_errors_cm.mean())
+
+    @property
+    def max_positional_error_mm(self) -> float:
+        return 10.0 * self.max_positional_error_cm
+
+    @property
+    def mean_positional_error_mm(self) -> float:
+        return 10.0 * self.mean_positional_error_cm
+
+    # ---- maximum joint changes (data_types.py:188-210) ----
+    @property
+    def mjac_per_timestep_deg(self) -> torch.Tensor:
+        from cppflow_amd.evaluation_utils import calculate_per_timestep_mjac_deg
+
+        return calculate_per_timestep_mjac_deg(self.q_path_revolute)
+
+    @property
+    def mjac_per_timestep_cm(self) -> torch.Tensor:
+        from cppflow_amd.evaluation_utils import calculate_per_timestep_mjac_cm
+
+        if not self.is_a_prismatic_joint:
+            return torch.zeros(self.target_path.shape[0] - 1, device=self.q_path.device, dtype=self.q_path.dtype)
+        return calculate_per_timestep_mjac_cm(self.q_path_prismatic)
+
+    @property
+    def mjac_deg(self) -> float:
+        return self._metric("mjac_deg", lambda: self.mjac_per_timestep_deg.max())
+
+    @property
+    def mjac_cm(self) -> float:
+        if not self.is_a_prismatic_joint:
+            return 0.0
+        return self._metric("mjac_cm", lambda: self.mjac_per_timestep_cm.max())
+
+    # ---- validity (data_types.py:212-264) ----
+    @property
+    def joint_limits_violated(self) -> bool:
+        from cppflow_amd.evaluation_utils import joint_limits_exceeded
+
+        if self.metrics is not None:
+            return float(self.metrics[_PLAN_METRIC_INDEX["n_joint_limit_violations"]]) > 0
+        return bool(joint_limits_exceeded(self.robot_joint_limits, self.q_path)[0])
+
+    @property
+    def initial_q_norm_dist(self) -> float:
+        if self.provided_initial_configuration is None:
+            return 0.0
+        q0 = self.provided_initial_configuration.reshape(-1).to(self.q_path.device)
+        return self._metric("initial_q_norm_dist", lambda: torch.linalg.vector_norm(q0 - self.q_path[0]))
+
+    def validity_flags(self) -> dict:
+        """Every term of the verdict by name (what `is_valid_(verbose=True)` and `__str__` of the reference print)."""
+        c = self.constraints
+        return {
+            "mjac_deg": self.mjac_deg < c.max_allowed_mjac_deg,
+            "mjac_cm": self.mjac_cm < c.max_allowed_mjac_cm,
+            "max_positional_error": self.max_positional_error_cm < c.max_allowed_position_error_cm,
+            "max_rotational_error": self.max_rotational_error_deg < c.max_allowed_rotation_error_deg,
+            "joint_limits": not self.joint_limits_violated,
+            "self_collisions": int(self.self_colliding_per_ts.sum()) == 0,
+            "env_collisions": int(self.env_colliding_per_ts.sum()) == 0,
+            "initial_configuration": self.initial_q_norm_dist < SUCCESS_THRESHOLD_initial_q_norm_dist,
+        }
+
+    def is_valid_(self, verbose: bool = False):
+        flags = self.validity_flags()
+        verdict = all(flags.values())
+        if not verbose:
+            return verdict
+        return verdict, "".join(f"{k}: {v}\n" for k, v in [("is_valid_", verdict), *flags.items()])
+
+    @property
+    def is_valid(self) -> bool:
+        return self.is_valid_(verbose=False)
+
+    def append_to_results_df(self, df_wrapped: dict) -> None:
+        """One row of the reference's results table (data_types.py:120-139; column order of its header comment); the time
+        spent in here is excluded from the table's clock as the reference does."""
+        t_enter = time()
+        n = max(self.self_colliding_per_ts.numel(), 1)
+        row = [0, self.is_valid, self.mean_positional_error_mm, self.max_positional_error_mm, self.mean_rotational_error_deg,
+               self.max_rotational_error_deg, self.mjac_deg, self.mjac_cm, float(self.self_colliding_per_ts.sum()) / n,
+               float(self.env_colliding_per_ts.sum()) / n, self.path_length_rad, self.path_length_m]  # fmt: skip
+        df_wrapped["t0"] += time() - t_enter
+        row[0] = time() - df_wrapped["t0"]
+        df_wrapped["df"].loc[len(df_wrapped["df"])] = row
 
     def __str__(self) -> str:
-        return (
-            f"<Plan T={self.q_path.shape[0]} valid={self.is_valid} max_pos_err={self.max_positional_error_cm:.5f} cm "
-            f"max_rot_err={self.max_rotational_error_deg:.5f} deg mjac={self.mjac_deg:.3f} deg / {self.mjac_cm:.3f} cm "
-            f"self_coll={int(self.self_colliding_per_ts.sum())} env_coll={int(self.env_colliding_per_ts.sum())}>"
-        )
+        c, flags = self.constraints, self.validity_flags()
+        r = lambda v: round(float(v), 5)  # noqa: E731
+        lines = [
+            "Plan {",
+            f"  is_valid:                        {self.is_valid}",
+            f"  mjac < {c.max_allowed_mjac_deg} deg:                  {flags['mjac_deg']}",
+            f"  mjac < {c.max_allowed_mjac_cm} cm:                   {flags['mjac_cm']}",
+            f"  max positional error < {10 * c.max_allowed_position_error_cm} mm:   {flags['max_positional_error']}",
+            f"  max rotational error < {c.max_allowed_rotation_error_deg} deg:  {flags['max_rotational_error']}",
+            f"  joint limits in bounds:          {flags['joint_limits']}",
+            f"  close-to-initial-configuration:  {flags['initial_configuration']}",
+            f"  # self collisions:               {int(self.self_colliding_per_ts.sum())}",
+            f"  # env. collisions:               {int(self.env_colliding_per_ts.sum())}",
+            "  .",
+            f"  mjac:                  {r(self.mjac_deg)} deg",
+            f"  mjac:                  {r(self.mjac_cm)} cm",
+            f"  ave positional error:  {r(self.mean_positional_error_mm)} mm",
+            f"  max positional error:  {r(self.max_positional_error_mm)} mm",
+            f"  ave rotational error:  {r(self.mean_rotational_error_deg)} deg",
+            f"  max rotational error:  {r(self.max_rotational_error_deg)} deg",
+            f"  q_initial norm dist:   {r(self.initial_q_norm_dist)}",
+            "  .",
+            f"  trajectory length:     {r(self.path_length_rad)} rad",
+            f"  trajectory length:     {r(self.path_length_m)} m",
+            "}",
+        ]
+        return "\n".join(lines)
+
+
+class PlanNp:
+    """Read-through view of a Plan whose tensor attributes come back as numpy arrays (cppflow/data_types.py:352-366)."""
+
+    def __init__(self, plan: Plan):
+        object.__setattr__(self, "plan", plan)
+
+    def __getattr__(self, attr):
+        plan = object.__getattribute__(self, "plan")
+        if not hasattr(plan, attr):
+            raise AttributeError(f"'{attr}' is not an attribute of Plan")
+        value = getattr(plan, attr)
+        return value.detach().cpu().numpy() if isinstance(value, torch.Tensor) else value
 
 
 @dataclass

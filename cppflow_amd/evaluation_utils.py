@@ -61,6 +61,31 @@ def calculate_pose_error_cm_deg(robot, x: torch.Tensor, target_path: torch.Tenso
     return 100 * pos_m, torch.rad2deg(rot_rad)
 
 
+def positional_errors(path_1: torch.Tensor, path_2: torch.Tensor) -> torch.Tensor:
+    """||t_1 - t_2||_2 per row of two pose paths [n,7] (cppflow/evaluation_utils.py:134-136)."""
+    return torch.linalg.vector_norm(path_1[:, 0:3] - path_2[:, 0:3], dim=1)
+
+
+def rotational_errors(path_1: torch.Tensor, path_2: torch.Tensor) -> torch.Tensor:
+    """Geodesic distance per row between the quaternions of two pose paths [n,7] (cppflow/evaluation_utils.py:139-141); the
+    formula is the one the reference quotes in-tree (cppflow/data_types.py:408-411), folded to [0, pi].  Pose paths that
+    come from joint configurations should use `Robot.pose_error_metrics` instead (one launch, no quaternion round trip)."""
+    eps = 1e-7
+    dot = torch.clip((path_1[:, 3:7] * path_2[:, 3:7]).sum(dim=1), -1.0, 1.0)
+    dist = 2.0 * torch.acos(torch.clamp(dot, -1.0 + eps, 1.0 - eps))
+    return torch.abs(torch.remainder(dist + math.pi, 2.0 * math.pi) - math.pi)
+
+
+def calculate_pose_error_mm_deg_and_mjac_cm_deg(robot, x: torch.Tensor, target_path: torch.Tensor):
+    """(position error [n] mm, rotation error [n] deg, mjac deg, mjac cm) of one config path
+    (cppflow/evaluation_utils.py:119-131).  As in the reference, the last value is 100 * max |x_prismatic| -- the largest
+    prismatic joint VALUE, not its change (`Plan.mjac_cm` is the change)."""
+    pos_m, rot_rad = robot.pose_error_metrics(x, target_path)
+    rev, pris = robot.split_configs_to_revolute_and_prismatic(x)
+    mjac_cm = float(100 * pris.abs().max()) if pris.numel() > 0 else 0.0
+    return 1000 * pos_m, torch.rad2deg(rot_rad), calculate_mjac_deg(rev), mjac_cm
+
+
 def errors_are_below_threshold(
     max_allowed_position_error_cm: float,
     max_allowed_rotation_error_deg: float,

@@ -386,6 +386,9 @@ class Robot:
         )
         return pe, re
 
+    PLAN_METRIC_FIELDS = ("max_pos_err_cm", "mean_pos_err_cm", "max_rot_err_deg", "mean_rot_err_deg", "mjac_deg", "mjac_cm",
+                          "path_length_rad", "path_length_m", "n_joint_limit_violations", "n_self_colliding",
+                          "n_env_colliding", "initial_q_norm_dist")  # fmt: skip
     SEED_SUMMARY_FIELDS = ("max_pos_err_cm", "max_rot_err_deg", "mjac_rev_deg", "mjac_pris_cm", "n_self_colliding",
                            "n_env_colliding", "n_jlim", "sum_ext_cost")  # fmt: skip
 
@@ -466,6 +469,36 @@ class Robot:
             )  # fmt: skip
         )
         return best_path, best_idx, costsT
+
+    def plan_metrics(self, x: torch.Tensor, target: torch.Tensor, self_mask: Optional[torch.Tensor] = None,
+                     env_mask: Optional[torch.Tensor] = None, q_init: Optional[torch.Tensor] = None) -> torch.Tensor:  # fmt: skip
+        """[S,16] `Plan` metrics (cppflow/data_types.py:140-264) of S paths in one launch; columns PLAN_METRIC_FIELDS.
+        x [S*W,d] (or [S,W,d]); masks are per-row uint8 / bool tensors of the same rows (optional); q_init [d] or [1,d]."""
+        x = self._x2d(x.reshape(-1, self.ndof) if x.dim() == 3 else x)
+        target = _require_device_tensor(target, "target_path")
+        n, W = x.shape[0], target.shape[0]
+        assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0
+        ptrs = []
+        for m, nm in ((self_mask, "self_mask"), (env_mask, "env_mask")):
+            if m is None:
+                ptrs.append(None)
+                continue
+            assert m.is_cuda and m.numel() == n and m.dtype in (torch.uint8, torch.bool), f"{nm} must be uint8 / bool [{n}]"
+            m = m.contiguous()
+            ptrs.append(m)
+        qi = None
+        if q_init is not None:
+            qi = _require_device_tensor(q_init, "q_init").reshape(-1).contiguous()
+            assert qi.numel() == self.ndof, tuple(q_init.shape)
+        out = torch.empty((n // W, 16), dtype=torch.float32, device=x.device)
+        _hip.check(
+            _hip.lib().cppf_plan_metrics(
+                self._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W,
+                ptrs[0].data_ptr() if ptrs[0] is not None else None, ptrs[1].data_ptr() if ptrs[1] is not None else None,
+                qi.data_ptr() if qi is not None else None, out.data_ptr(), _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return out
 
     def seed_validity(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """[S,4]: per seed max position error (cm), max rotation error (deg), mjac revolute (deg), mjac prismatic (cm)."""

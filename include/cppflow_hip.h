@@ -154,6 +154,19 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
 int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
                        void* stream);
 
+/* Plan metrics of S joint-space paths at once -- the properties of `Plan` (cppflow/data_types.py:140-264), which the
+ * reference evaluates one path at a time on the host: x [S*W,d], target [W,7] -> out [S,16] =
+ *   [0] max, [1] mean positional error (cm)            (data_types.py:166-186, evaluation_utils.py:134-136)
+ *   [2] max, [3] mean rotational error (deg)           (data_types.py:156-164, evaluation_utils.py:139-141)
+ *   [4] mjac of the revolute joints (deg), [5] of the prismatic joints (cm)  (data_types.py:189-210, evaluation_utils.py:83-99)
+ *   [6] path length of the revolute joints (rad), [7] of the prismatic joints (m)      (data_types.py:141-149)
+ *   [8] number of (waypoint, joint) entries outside the joint limits       (evaluation_utils.py:16-27)
+ *   [9] number of self-colliding, [10] of environment-colliding waypoints (sums of the given masks; 0 for a NULL mask)
+ *   [11] ||q_init - q_path[0]||_2, 0 when q_init (DEVICE [d]) is NULL       (data_types.py:217-221)   [12..15] 0
+ * self_mask / env_mask [S*W] are the outputs of cppf_collision_masks / cppf_lm_pose_steps for the same x (may be NULL). */
+int cppf_plan_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, const uint8_t* self_mask,
+                      const uint8_t* env_mask, const float* q_init, float* out, void* stream);
+
 /* Per-seed reduction of the per-row outputs of cppf_lm_pose_steps (no FK is repeated): out [S,8] =
  *   max position error (cm), max rotation error (deg), max |revolute joint change| (deg), max |prismatic joint change| (cm)
  *   -- the four quantities x_is_valid thresholds (cppflow/optimization_utils.py:861-884, evaluation_utils.py:29-75) --

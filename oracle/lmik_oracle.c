@@ -19,6 +19,7 @@
  *   orc_ext_cost         <- cppflow/search.py:14-15,146-150         100*jlim + 1000*env + 1000*self
  *   orc_angular_changes  <- cppflow/evaluation_utils.py:144-154
  *   orc_seed_validity    <- cppflow/optimization_utils.py:845-884 + cppflow/evaluation_utils.py:29-75
+ *   orc_plan_metrics     <- cppflow/data_types.py:140-264 (Plan properties) + cppflow/evaluation_utils.py:16-27, 83-99
  *
  * THIRD-PARTY ARITHMETIC.  Forward kinematics, the geometric Jacobian, capsule distances and the quaternion helpers
  * are methods of `jrl` 0.1.2 @ ef4c2f6eb1ba84395ff0bb01d5b7713854df6908 (reference pyproject.toml:12,
@@ -895,6 +896,66 @@ void orc_seed_validity(const void* h, const double* x, const double* target, int
         out[s * 4 + 1] = mr;
         out[s * 4 + 2] = mrev;
         out[s * 4 + 3] = mpri;
+    }
+    free(pe);
+    free(re);
+}
+
+/* Plan metrics of S joint-space paths at once (cppflow/data_types.py:140-264 `Plan` properties, evaluated for every seed):
+ * x[S*W,d], target[S*W,7], optional per-row collision flags and an optional initial configuration q_init[d] ->
+ * out[S,16] = { max / mean positional error (cm), max / mean rotational error (deg)   (data_types.py:156-186),
+ *               mjac revolute (deg), mjac prismatic (cm)                              (:189-210, evaluation_utils.py:83-99),
+ *               path length revolute (rad), prismatic (m)                            (:141-149),
+ *               # (waypoint, joint) entries outside the joint limits                 (evaluation_utils.py:16-27),
+ *               # self-colliding, # env-colliding waypoints                           (:245-246),
+ *               ||q_init - q_path[0]||_2 (0 without q_init)                          (:217-221),  0, 0, 0, 0 } */
+void orc_plan_metrics(const void* h, const double* x, const double* target, int S, int W, const unsigned char* self_mask,
+                      const unsigned char* env_mask, const double* q_init, double* out /*[S,16]*/) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof;
+    const REAL rad2deg = RC(57.29577951308232087680);
+    double* pe = (double*)malloc(sizeof(double) * (size_t)W);
+    double* re = (double*)malloc(sizeof(double) * (size_t)W);
+    for (int s = 0; s < S; ++s) {
+        const double* xs = x + (size_t)s * W * d;
+        orc_pose_metrics(h, xs, target + (size_t)s * W * 7, W, pe, re);
+        REAL mp = 0, sp = 0, mr = 0, sr = 0, mrev = 0, mpri = 0, lrad = 0, lm = 0, njl = 0, ns = 0, ne = 0, qd = 0;
+        for (int w = 0; w < W; ++w) {
+            const REAL a = (REAL)100 * (REAL)pe[w], b = rad2deg * (REAL)re[w];
+            if (a > mp) mp = a;
+            if (b > mr) mr = b;
+            sp += a;
+            sr += b;
+            for (int j = 0; j < d; ++j) {
+                const REAL q = (REAL)xs[(size_t)w * d + j];
+                njl += (REAL)((q < (REAL)rb->lo[j]) + ((REAL)rb->hi[j] < q));
+            }
+            if (self_mask) ns += (REAL)self_mask[(size_t)s * W + w];
+            if (env_mask) ne += (REAL)env_mask[(size_t)s * W + w];
+        }
+        for (int w = 0; w + 1 < W; ++w)
+            for (int j = 0; j < d; ++j) {
+                const REAL dq = (REAL)xs[(size_t)(w + 1) * d + j] - (REAL)xs[(size_t)w * d + j];
+                if (rb->jtype[j] == 0) {
+                    const REAL v = FABS(wrap_pi(dq));
+                    if (rad2deg * v > mrev) mrev = rad2deg * v;
+                    lrad += v;
+                } else {
+                    const REAL v = FABS(dq);
+                    if ((REAL)100 * v > mpri) mpri = (REAL)100 * v;
+                    lm += v;
+                }
+            }
+        if (q_init) {
+            for (int j = 0; j < d; ++j) {
+                const REAL dq = (REAL)q_init[j] - (REAL)xs[j];
+                qd += dq * dq;
+            }
+            qd = SQRT(qd);
+        }
+        double* o = out + (size_t)s * 16;
+        o[0] = mp, o[1] = sp / (REAL)W, o[2] = mr, o[3] = sr / (REAL)W, o[4] = mrev, o[5] = mpri, o[6] = lrad, o[7] = lm;
+        o[8] = njl, o[9] = ns, o[10] = ne, o[11] = qd, o[12] = o[13] = o[14] = o[15] = 0;
     }
     free(pe);
     free(re);

@@ -86,6 +86,8 @@ def _lib(f32: bool):
         ]  # fmt: skip
         lib.orc_angular_changes.argtypes = [_dp, ctypes.c_int, ctypes.c_int, _dp]
         lib.orc_seed_validity.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp]
+        lib.orc_plan_metrics.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, _dp]
         lib.orc_self_dists_grads.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp]
         lib.orc_env_dists_grads.argtypes = [ctypes.c_void_p, _dp, ctypes.c_int, _dp, _dp, _dp, _dp]
         lib.orc_lm_full_step.restype = ctypes.c_int
@@ -260,6 +262,21 @@ class Oracle:
         assert x.shape[0] == S * W and target.shape == (S * W, 7)
         out = np.empty((S, 4))
         self.lib.orc_seed_validity(self.h, _p(x), _p(target), S, W, _p(out))
+        return out
+
+    def plan_metrics(self, x, target, S, W, self_mask=None, env_mask=None, q_init=None):
+        """[S,16] Plan metrics of S paths (cppflow/data_types.py:140-264); field order = cppflow_amd.robots.PLAN_METRIC_FIELDS."""
+        x, target = self._x(x), _d(target)
+        assert x.shape[0] == S * W and target.shape == (S * W, 7)
+        out = np.empty((S, 16))
+        sm = None if self_mask is None else np.ascontiguousarray(self_mask, dtype=np.uint8).reshape(-1)
+        em = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8).reshape(-1)
+        qi = None if q_init is None else _d(np.asarray(q_init).reshape(-1))
+        self.lib.orc_plan_metrics(
+            self.h, _p(x), _p(target), S, W, None if sm is None else sm.ctypes.data_as(ctypes.c_void_p),
+            None if em is None else em.ctypes.data_as(ctypes.c_void_p), None if qi is None else qi.ctypes.data_as(ctypes.c_void_p),
+            _p(out),
+        )  # fmt: skip
         return out
 
     def dp_search(self, q, ext_cost, prismatic_scaling=5.0):

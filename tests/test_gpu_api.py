@@ -571,3 +571,61 @@ def test_entry_points_are_hip_graph_capturable(robots):
     assert np.abs(host(eager_x) - want)[ok].max() < 2e-2
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch", "chain12"])
+def test_plan_metrics_match_oracle(robots, name):
+    """cppf_plan_metrics (one wavefront per path) vs orc_plan_metrics (cppflow/data_types.py:140-264 restated): maxima and
+    counts to fp32 rounding of the per-row errors, means and lengths to the rounding of a 64-lane tree sum."""
+    rb, ch, orc = robots[name], H.chain(name), H.oracle64(name)
+    rng = np.random.RandomState(8)
+    for S, W in ((7, 59), (3, 200), (4, 1)):
+        base = rng.uniform(ch.lo, ch.hi, size=(S, 1, ch.ndof))
+        x = np.clip(base + np.cumsum(0.03 * rng.randn(S, W, ch.ndof), axis=1), ch.lo - 0.01, ch.hi + 0.01)
+        x = H.f32(x.reshape(S * W, ch.ndof))
+        target = H.f32(orc.fk(H.f32(x[:W] + 0.002)))
+        sm, em = rng.rand(S * W) < 0.1, rng.rand(S * W) < 0.3
+        q_init = H.f32(x[0] + 0.03)
+        want = orc.plan_metrics(x, H.stacked(target, S), S, W, sm, em, q_init)
+        got = host(rb.plan_metrics(dev(x), dev(target), torch.tensor(sm, device=DEV), torch.tensor(em, device=DEV),
+                                   dev(q_init)))  # fmt: skip
+        assert got.shape == (S, 16)
+        np.testing.assert_allclose(got[:, [0, 1]], want[:, [0, 1]], rtol=2e-3, atol=2e-4)  # cm; fp32 FK noise ~1e-6 m
+        np.testing.assert_allclose(got[:, [2, 3]], want[:, [2, 3]], rtol=2e-3, atol=2.6e-2)  # deg; acos-clamp floor region
+        np.testing.assert_allclose(got[:, 4:8], want[:, 4:8], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(got[:, 8:11], want[:, 8:11])
+        np.testing.assert_allclose(got[:, 11], want[:, 11], rtol=1e-6)
+        assert np.all(got[:, 12:] == 0)
+        none = host(rb.plan_metrics(dev(x), dev(target)))
+        assert np.all(none[:, 9:12] == 0) and np.array_equal(none[:, :9], got[:, :9])
+        sv = host(rb.seed_validity(dev(x), dev(target)))
+        assert np.array_equal(sv, got[:, [0, 2, 4, 5]])  # the same maxima as cppf_seed_validity, bit for bit
+
+
+def test_plans_from_qpaths_batch_equals_single(robots):
+    """plans_from_qpaths: every candidate path of a problem evaluated in one go; each Plan equals plan_from_qpath of that
+    path alone and its device-side scalars equal the torch fall-backs of the Plan container."""
+    from cppflow_amd.data_type_utils import plan_from_qpath, plans_from_qpaths, problem_from_arrays
+    from cppflow_amd.data_types import Plan
+
+    rb = robots["fetch"]
+    S, W = 6, 40
+    x0, target = H.lm_problem("fetch", S, W, seed=12)
+    problem = problem_from_arrays(rb, H.f32(target), [(0.9, 0.0, 0.6, 0.3, 0.3, 0.3)], device=DEV)
+    r = rb.lm_pose_steps(dev(x0), problem.target_path, 1e-6, 3.5, 0.35, n_steps=15)
+    q = r["x"].view(S, W, -1)
+    plans = plans_from_qpaths(q, problem)
+    assert len(plans) == S
+    for s in (0, S - 1):
+        one = plan_from_qpath(q[s], problem)
+        assert torch.equal(one.metrics, plans[s].metrics) and torch.equal(one.pose_path, plans[s].pose_path)
+        assert one.is_valid == plans[s].is_valid
+        fields = {k: getattr(one, k) for k in ("q_path", "q_path_revolute", "q_path_prismatic", "pose_path", "target_path",
+                  "robot_joint_limits", "self_colliding_per_ts", "env_colliding_per_ts", "positional_errors",
+                  "rotational_errors", "provided_initial_configuration", "constraints")}  # fmt: skip
+        torch_only = Plan(**fields)
+        for name in ("max_positional_error_cm", "mean_positional_error_cm", "max_rotational_error_deg", "mean_rotational_error_deg",
+                     "mjac_deg", "mjac_cm", "path_length_rad", "path_length_m"):  # fmt: skip
+            assert getattr(one, name) == pytest.approx(getattr(torch_only, name), rel=1e-4, abs=1e-6), name
+        assert one.joint_limits_violated == torch_only.joint_limits_violated and "Plan {" in str(one)
+    rb.set_obstacles([], [])

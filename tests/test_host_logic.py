@@ -217,3 +217,80 @@ def test_seed_shard_and_packed_layout():
     assert packed[:4].view(torch.float32).item() == 1.5 and packed[8 * n : 8 * n + 4].view(torch.float32).item() == 2.5
     assert packed[14 * n].item() == 7 and pe.sum().item() == 0 and sm.sum().item() == 0 and em.sum().item() == 0
     assert Robot.PACKED_BYTES_PER_ROW == PACKED_BYTES_PER_ROW
+
+
+def test_plan_container_mirrors_the_reference_properties():
+    """`Plan` (cppflow/data_types.py:86-350): with a metrics row (as cppf_plan_metrics produces) every scalar property is
+    read from it; without one the torch fall-backs give the same numbers; the verdict is the reference's conjunction."""
+    from cppflow_amd.config import SUCCESS_THRESHOLD_initial_q_norm_dist
+    from cppflow_amd.data_types import DEFAULT_CONSTRAINTS, Plan, PlanNp
+    from cppflow_amd.evaluation_utils import angular_changes
+
+    torch.manual_seed(0)
+    T = 12
+    limits = [(0.0, 0.4)] + [(-3.0, 3.0)] * 3
+    q = torch.cat([torch.linspace(0.1, 0.12, T)[:, None], 0.3 + 0.01 * torch.randn(T, 3).cumsum(0)], dim=1)
+    pos, rot = 1e-5 * torch.rand(T), 1e-4 * torch.rand(T)
+    kw = dict(q_path=q, q_path_revolute=q[:, 1:], q_path_prismatic=q[:, :1], pose_path=torch.zeros(T, 7),
+              target_path=torch.zeros(T, 7), robot_joint_limits=limits, self_colliding_per_ts=torch.zeros(T, dtype=torch.bool),
+              env_colliding_per_ts=torch.zeros(T, dtype=torch.bool), positional_errors=pos, rotational_errors=rot,
+              provided_initial_configuration=q[0:1] + 0.01, constraints=DEFAULT_CONSTRAINTS)  # fmt: skip
+    host = Plan(**kw)
+    row = torch.tensor([host.max_positional_error_cm, host.mean_positional_error_cm, host.max_rotational_error_deg,
+                        host.mean_rotational_error_deg, host.mjac_deg, host.mjac_cm, host.path_length_rad, host.path_length_m,
+                        0.0, 0.0, 0.0, host.initial_q_norm_dist, 0, 0, 0, 0])  # fmt: skip
+    dev = Plan(**kw, metrics=row)
+    for name in ("max_positional_error_cm", "max_positional_error_mm", "mean_positional_error_mm", "mean_rotational_error_deg",
+                 "max_rotational_error_deg", "mjac_deg", "mjac_cm", "path_length_rad", "path_length_m", "initial_q_norm_dist"):  # fmt: skip
+        assert getattr(dev, name) == pytest.approx(getattr(host, name), rel=1e-6), name
+    assert host.path_length_rad == pytest.approx(float(angular_changes(q[:, 1:]).abs().sum()))
+    assert host.max_positional_error_mm == pytest.approx(10 * host.max_positional_error_cm)
+    assert host.is_valid and dev.is_valid and not host.joint_limits_violated
+    assert abs(host.initial_q_norm_dist - 0.02) < 1e-6 < SUCCESS_THRESHOLD_initial_q_norm_dist
+    verdict, text = host.is_valid_(verbose=True)
+    assert verdict and "self_collisions: True" in text and "Plan {" in str(host) and "trajectory length" in str(host)
+    # each term of the conjunction can veto (data_types.py:232-244)
+    bad = dict(kw)
+    bad["self_colliding_per_ts"] = torch.tensor([True] + [False] * (T - 1))
+    assert not Plan(**bad).is_valid
+    bad = dict(kw)
+    bad["provided_initial_configuration"] = q[0:1] + 0.2
+    assert not Plan(**bad).is_valid
+    bad = dict(kw)
+    bad["q_path"] = q.clone()
+    bad["q_path"][3, 0] = 0.5  # above the prismatic limit
+    assert Plan(**bad).joint_limits_violated and not Plan(**bad).is_valid
+    row_bad = row.clone()
+    row_bad[8] = 1.0
+    assert Plan(**kw, metrics=row_bad).joint_limits_violated
+    bad = dict(kw)
+    bad["positional_errors"] = pos + 1.0
+    assert not Plan(**bad).is_valid
+    # no prismatic joints: lengths / mjac in cm are 0 (data_types.py:146-149, 199-210)
+    rev_only = dict(kw, q_path=q[:, 1:], q_path_prismatic=q[:, :0], robot_joint_limits=limits[1:], provided_initial_configuration=None)
+    p = Plan(**rev_only)
+    assert p.mjac_cm == 0.0 and p.path_length_m == 0.0 and p.initial_q_norm_dist == 0.0 and p.mjac_per_timestep_cm.shape == (T - 1,)
+    # numpy view and the results-table row (data_types.py:120-139, 352-366)
+    view = PlanNp(host)
+    assert isinstance(view.q_path, np.ndarray) and view.mjac_deg == host.mjac_deg
+    with pytest.raises(AttributeError):
+        view.no_such_field
+    import pandas as pd
+    import time as _time
+
+    df = {"df": pd.DataFrame(columns=list("abcdefghijkl")), "t0": _time.time()}
+    host.append_to_results_df(df)
+    assert len(df["df"]) == 1 and bool(df["df"].iloc[0, 1]) is True and df["df"].iloc[0, 10] == pytest.approx(host.path_length_rad)
+
+
+def test_pose_path_error_helpers():
+    """positional_errors / rotational_errors on pose paths (cppflow/evaluation_utils.py:134-141)."""
+    from cppflow_amd.evaluation_utils import positional_errors, rotational_errors
+
+    a = torch.tensor([[0.0, 0, 0, 1, 0, 0, 0], [1.0, 2, 3, 1, 0, 0, 0]])
+    half = math.sqrt(0.5)
+    b = torch.tensor([[0.0, 3, 4, 1, 0, 0, 0], [1.0, 2, 3, half, half, 0, 0]])
+    assert torch.allclose(positional_errors(a, b), torch.tensor([5.0, 0.0]))
+    r = rotational_errors(a, b)
+    assert abs(float(r[1]) - math.pi / 2) < 1e-5 and float(r[0]) < 1e-3
+    assert abs(float(rotational_errors(a[1:], -b[1:])[0]) - math.pi / 2) < 1e-5  # q and -q are the same rotation

@@ -335,3 +335,39 @@ def test_canonical_rewrite_is_exact_for_random_chains(ndof, seed):
     rb = ref_torch.TorchRobot(spec, dtype=torch.float64)
     np.testing.assert_allclose(rb.jacobian(torch.tensor(q)).numpy(), J, atol=5e-7)
     np.testing.assert_allclose(rb.self_collision_distances(torch.tensor(q)).numpy(), o.self_dists(q), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["fetch", "panda"])
+def test_plan_metrics_oracle_equals_the_reference_property_formulas(name):
+    """orc_plan_metrics vs the `Plan` property formulas of cppflow/data_types.py:140-264, written out with numpy on top
+    of the oracle's own per-row pose errors, and vs the reference's angular_changes wrap-around known answers
+    (tests/evaluation_utils_test.py:17-124: a step across +-pi counts as the short way round)."""
+    ch, orc = H.chain(name), H.oracle64(name)
+    rng = np.random.RandomState(3)
+    S, W, d = 5, 23, ch.ndof
+    base = rng.uniform(ch.lo, ch.hi, size=(S, 1, d))
+    x = np.clip(base + np.cumsum(0.05 * rng.randn(S, W, d), axis=1), ch.lo - 0.01, ch.hi + 0.01).reshape(S * W, d)
+    rev = [j for j in range(d) if ch.jtype[j] == 0]
+    x.reshape(S, W, d)[0, 3, rev[-1]] = 3.1  # wrap-around: 3.1 -> -3.1 is a 0.083 rad step
+    x.reshape(S, W, d)[0, 4, rev[-1]] = -3.1
+    x = H.f32(x)
+    target = H.stacked(orc.fk(x[:W] + 0.01), S)
+    self_mask = rng.rand(S * W) < 0.1
+    env_mask = rng.rand(S * W) < 0.2
+    q_init = H.f32(x[0] + 0.05)
+    got = orc.plan_metrics(x, target, S, W, self_mask, env_mask, q_init)
+    pe, re = orc.pose_metrics(x, target)
+    for s in range(S):
+        xs = x[s * W : (s + 1) * W]
+        dq = xs[1:] - xs[:-1]
+        ang = np.abs(np.remainder(dq[:, rev] + np.pi, 2 * np.pi) - np.pi)  # evaluation_utils.py:144-154
+        pris = [j for j in range(d) if ch.jtype[j] == 1]
+        sl = slice(s * W, (s + 1) * W)
+        want = [100 * pe[sl].max(), 100 * pe[sl].mean(), np.rad2deg(re[sl]).max(), np.rad2deg(re[sl]).mean(),
+                np.rad2deg(ang.max()), 100 * np.abs(dq[:, pris]).max() if pris else 0.0, ang.sum(),
+                np.abs(dq[:, pris]).sum() if pris else 0.0, ((xs < ch.lo) | (ch.hi < xs)).sum(), self_mask[sl].sum(),
+                env_mask[sl].sum(), np.linalg.norm(q_init - xs[0])]  # fmt: skip
+        np.testing.assert_allclose(got[s, :12], want, rtol=1e-9, atol=1e-12)
+    assert abs(np.abs(np.remainder((-3.1 - 3.1) + np.pi, 2 * np.pi) - np.pi) - (2 * np.pi - 6.2)) < 1e-12
+    assert got[0, 6] < 0.05 * 3 * W * d  # the +-pi crossing did not add 6.2 rad to the path length
+    assert got[:, 8].sum() > 0 and np.all(got[:, 12:] == 0)
