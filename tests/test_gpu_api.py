@@ -629,3 +629,40 @@ def test_plans_from_qpaths_batch_equals_single(robots):
             assert getattr(one, name) == pytest.approx(getattr(torch_only, name), rel=1e-4, abs=1e-6), name
         assert one.joint_limits_violated == torch_only.joint_limits_violated and "Plan {" in str(one)
     rb.set_obstacles([], [])
+
+
+def test_large_batch_indexing(robots):
+    """16.8 M rows (16 384 seeds x 1 024 waypoints, 470 MB of x): every index is past 2^24 somewhere and the J / e outputs are
+    past 2^31 BYTES; the first and last rows must equal the same rows run alone, bit for bit (rows are independent), and
+    the in-launch per-seed summary must equal the separate reduction."""
+    rb = robots["panda"]
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    S, W, d = 16384, 1024, rb.ndof
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lo = torch.tensor([l for l, _ in rb.actuated_joints_limits], device=DEV)
+    hi = torch.tensor([u for _, u in rb.actuated_joints_limits], device=DEV)
+    q_star = lo + (hi - lo) * torch.rand((W, d), generator=g, device=DEV)
+    target = rb.forward_kinematics(q_star)
+    x0 = torch.empty((S, W, d), dtype=torch.float32, device=DEV)
+    x0.normal_(0.0, 0.1, generator=g)
+    x0 += q_star[None]
+    x0 = torch.minimum(torch.maximum(x0, lo), hi).view(S * W, d)
+    n = S * W
+    packed = torch.empty(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=DEV)
+    summary = torch.empty((S, 8), dtype=torch.float32, device=DEV)
+    r = rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=3, packed_out=packed, summary_out=summary, return_residual=True)
+    assert r["J"].numel() * 4 > 2**31 and bool(torch.isfinite(r["x"]).all())
+    for sl in (slice(0, 2 * W), slice(n - 2 * W, n)):
+        pk = torch.empty(rb.PACKED_BYTES_PER_ROW * 2 * W, dtype=torch.uint8, device=DEV)
+        a = rb.lm_pose_steps(x0[sl].contiguous(), target, 1e-6, 3.5, 0.35, n_steps=3, packed_out=pk, return_residual=True)
+        for key in ("x", "J", "e", "ext_cost", "pos_err_m", "rot_err_rad", "self_mask", "env_mask", "jlim_mask"):
+            assert torch.equal(a[key], r[key][sl]), key
+    assert torch.equal(summary, rb.seed_summary(r["x"], packed, S, W))
+    masks = rb.collision_masks(r["x"].view(S, W, d))
+    assert torch.equal(masks["ext_cost"].view(-1), r["ext_cost"])
+    del r, packed, x0, masks
+    torch.cuda.empty_cache()
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
