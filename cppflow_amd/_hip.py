@@ -93,6 +93,7 @@ SIGNATURES = {
     "cppf_robot_ndof": (ctypes.c_int, [_vp]),
     "cppf_robot_specialization": (ctypes.c_int, [_vp]),
     "cppf_debug_force_generic": (None, [ctypes.c_int]),
+    "cppf_debug_set_pcr_max_rows": (None, [ctypes.c_int]),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_forward_kinematics": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),

@@ -1482,6 +1482,208 @@ __global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, co
     }
 }
 
+// Parallel-in-time form for few trajectories (the planner's cadence is ONE, cppflow/optimization.py:128): the two kernels
+// above walk the T waypoints one after the other (2 T dependent block steps, ~1.4 us each), which leaves the chip idle when
+// S is small.  Parallel cyclic reduction eliminates in ceil(log2 T) levels instead: one lane per waypoint, one workgroup per
+// trajectory.  With A block-tridiagonal and symmetric, at stride s row t couples to t - s through L_t (and to t + s through
+// L_{t+s}^T); one level replaces
+//     alpha = -L_t D_{t-s}^-1 ,  gamma = -L_{t+s}^T D_{t+s}^-1
+//     D_t <- D_t + alpha L_t^T + gamma L_{t+s} ,   y_t <- y_t + alpha y_{t-s} + gamma y_{t+s} ,   L_t <- alpha L_{t-s}
+// which doubles the stride; after the last level delta_t = D_t^-1 y_t.  O(T log T d^3) work instead of O(T d^3), all of it
+// parallel.  State lives in the caller's workspace (D_t packed | y_t in work_blocks, L_t dense in work_G) and is exchanged
+// between the lanes of the workgroup through L1 / L2 (workgroup-scope fences of __syncthreads).  Used without the pose block
+// (diagonal blocks = (cnt a^2 + lambda) I + collision terms: well conditioned, the Schur complements stay SPD).
+template <int D, int BS>
+__global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                            const float* __restrict__ xv, float* blocks, float* workL,
+                                                            float* __restrict__ x_out) {
+    constexpr int NT = D * (D + 1) / 2, SB = NT + D, DD = D * D;
+    const int s = blockIdx.x, t = threadIdx.x, T = prm.W;
+    const bool act = t < T;
+    const size_t base = (size_t)s * T;
+    float a2[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float a = prm.use_diff ? prm.a_diff * (((ch.pris_mask >> j) & 1u) ? prm.a_diff_pris : 1.f) : 0.f;
+        a2[j] = a * a;
+    }
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+
+    // ---- assemble row t in place: D_t = M_t + (cnt a^2 + [vq] beta^2 + lambda) I,  y_t = m_t + analytic J^T r terms
+    if (act) {
+        float* blk = blocks + (base + t) * SB;
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        float xc[D], xo[D], b[D];
+        load_x<D>(x, base + t, xc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) b[j] = blk[NT + j];
+        if (has_next) {
+            load_x<D>(x, base + t + 1, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(a2[j], wrap_pi(xo[j] - xc[j]), b[j]);
+        }
+        if (has_prev) {
+            load_x<D>(x, base + t - 1, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xo[j]), b[j]);
+        }
+        if (vq && xv) {
+            load_x<D>(xv, base + t, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, wrap_pi(xc[j] - xo[j]), b[j]);
+        }
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            blk[k] += cnt * a2[i] + (vq ? beta2 : 0.f) + prm.lm_lambda;  // diagonal entry (i, i) of the packed upper triangle
+            k += D - i;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) blk[NT + j] = b[j];
+        float* Lt = workL + (base + t) * DD;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Lt[i * D + j] = (i == j && has_prev) ? -a2[i] : 0.f;  // E = -diag(a^2)
+    }
+    __syncthreads();
+
+    auto load_sym = [&](const float* src, float (&M)[D][D]) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+                const float v = src[k++];
+                M[i][j] = v;
+                M[j][i] = v;
+            }
+    };
+
+    for (int st = 1; st < T; st <<= 1) {
+        float nD[D][D], ny[D], nL[D][D];
+        if (act) {
+            const float* own = blocks + (base + t) * SB;
+            load_sym(own, nD);
+#pragma unroll
+            for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
+            const int tm = t - st, tp = t + st;
+            if (tm >= 0) {
+                float Dn[D][D], P[D][D], Lt[D][D], Lm[D][D], ym[D];
+                const float* nb = blocks + (base + tm) * SB;
+                load_sym(nb, Dn);
+                spd_inverse<D>(Dn, prm.lm_lambda, P);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Lt[i][j] = workL[(base + t) * DD + i * D + j];
+                        Lm[i][j] = workL[(base + tm) * DD + i * D + j];
+                    }
+#pragma unroll
+                for (int j = 0; j < D; ++j) ym[j] = nb[NT + j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    float al[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc = CPPF_FMA(Lt[i][k], P[k][j], acc);
+                        al[j] = -acc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float accD = nD[i][j], accL = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            accD = CPPF_FMA(al[k], Lt[j][k], accD);  // alpha L_t^T
+                            accL = CPPF_FMA(al[k], Lm[k][j], accL);  // alpha L_{t-s}
+                        }
+                        nD[i][j] = accD;
+                        nL[i][j] = accL;
+                    }
+                    float accy = ny[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) accy = CPPF_FMA(al[k], ym[k], accy);
+                    ny[i] = accy;
+                }
+            }
+            if (tp < T) {
+                float Dn[D][D], P[D][D], Lp[D][D], yp[D];
+                const float* nb = blocks + (base + tp) * SB;
+                load_sym(nb, Dn);
+                spd_inverse<D>(Dn, prm.lm_lambda, P);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Lp[i][j] = workL[(base + tp) * DD + i * D + j];
+#pragma unroll
+                for (int j = 0; j < D; ++j) yp[j] = nb[NT + j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    float ga[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc = CPPF_FMA(Lp[k][i], P[k][j], acc);  // L_{t+s}^T D_{t+s}^-1
+                        ga[j] = -acc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float accD = nD[i][j];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) accD = CPPF_FMA(ga[k], Lp[k][j], accD);  // gamma L_{t+s}
+                        nD[i][j] = accD;
+                    }
+                    float accy = ny[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) accy = CPPF_FMA(ga[k], yp[k], accy);
+                    ny[i] = accy;
+                }
+            }
+        }
+        __syncthreads();  // every lane has read its neighbours' old state
+        if (act) {
+            float* own = blocks + (base + t) * SB;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) own[k++] = 0.5f * (nD[i][j] + nD[j][i]);  // symmetric in exact arithmetic
+#pragma unroll
+            for (int j = 0; j < D; ++j) own[NT + j] = ny[j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) workL[(base + t) * DD + i * D + j] = nL[i][j];
+        }
+        __syncthreads();
+    }
+    if (act) {
+        float Dn[D][D], P[D][D], xr[D];
+        const float* own = blocks + (base + t) * SB;
+        load_sym(own, Dn);
+        spd_inverse<D>(Dn, prm.lm_lambda, P);
+        load_x<D>(x, base + t, xr);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = CPPF_FMA(P[i][k], own[NT + k], acc);
+            xr[i] += acc;  // optimization.py:113: x + delta_x
+        }
+        store_x<D>(x_out, base + t, xr);
+    }
+}
+
 // ---- dp_search (cppflow/search.py:100-191) -----------------------------------------------------------------------------------
 // costs[b,t] = min_a { max(mjac(a->b,t-1), costs[a,t-1]) + ext[b,t] }, first minimal a recorded; one launch per timestep
 // (the recurrence is sequential in t; each step is a k x k (min,max) product).  The reference materialises
@@ -1753,6 +1955,7 @@ int find_static_robot(const cppf_robot_desc& d) {
     }
 
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
+int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows (measured crossover)
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -1878,6 +2081,8 @@ int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof :
 int cppf_robot_specialization(const cppf_robot* robot) { return robot ? robot->static_id : CPPF_ERR_INVALID; }
 
 void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
+
+void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n; }
 
 int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
     CPPF_REQUIRE(robot, "robot handle is NULL");
@@ -2173,6 +2378,26 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     // Trajectories are eliminated one per wavefront (8 x 8 lane tile) up to 8 joints, one per lane beyond.  With the pose
     // block the d x d blocks are J^T J + a small diagonal (rank 6 of 7, cond ~1e7): the per-lane kernel's Cholesky with
     // floored pivots copes with that better than the explicit Gauss-Jordan inverse, so it keeps that case.
+    // Up to ~128k rows (the planner's cadence is one trajectory): parallel cyclic reduction, one workgroup per trajectory, one
+    // lane per waypoint; beyond that its O(T log T) work and traffic lose against the waypoint-after-waypoint kernels
+    if (!prm.use_pose && W <= 512 && n <= (size_t)(g_pcr_max_rows > 0 ? g_pcr_max_rows : 0) && robot->desc.ndof >= 3 &&
+        robot->desc.ndof <= 8) {
+        switch (robot->desc.ndof) {
+#define CPPF_PCR_CASE(DD)                                                                                              \
+    case DD:                                                                                                           \
+        if (W <= 256)                                                                                                  \
+            hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 256>), dim3((unsigned)S), dim3(256), 0, st, robot->chain, prm, \
+                               x_in, virtual_configs, work_blocks, work_G, x_out);                                     \
+        else                                                                                                           \
+            hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 512>), dim3((unsigned)S), dim3(512), 0, st, robot->chain, prm, \
+                               x_in, virtual_configs, work_blocks, work_G, x_out);                                     \
+        break;
+            CPPF_PCR_CASE(3) CPPF_PCR_CASE(4) CPPF_PCR_CASE(5) CPPF_PCR_CASE(6) CPPF_PCR_CASE(7) CPPF_PCR_CASE(8)
+#undef CPPF_PCR_CASE
+            default: break;
+        }
+        return check_launch(robot);
+    }
     switch (prm.use_pose ? 0 : robot->desc.ndof) {
 #define CPPF_WAVE_CASE(DD)                                                                                          \
     case DD:                                                                                                        \

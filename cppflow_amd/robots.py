@@ -437,7 +437,7 @@ class Robot:
         nt = d * (d + 1) // 2
         dev = x.device
         blocks = torch.empty(n * (nt + d), dtype=torch.float32, device=dev)
-        G = torch.empty(n * nt, dtype=torch.float32, device=dev)
+        G = torch.empty(n * d * d, dtype=torch.float32, device=dev)  # L_t (dense) in the parallel-in-time form, G_t (packed) else
         y = torch.empty(n * d, dtype=torch.float32, device=dev)
         if x_out is None:
             x_out = torch.empty_like(x)

@@ -102,6 +102,10 @@ int cppf_robot_ndof(const cppf_robot* robot);
 int cppf_robot_specialization(const cppf_robot* robot);
 /* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
 void cppf_debug_force_generic(int on);
+/* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
+ * trajectory) when S*W <= n rows (and W <= 512, d <= 8, no pose block), waypoint after waypoint (one wavefront per
+ * trajectory) otherwise; default 131072, the measured crossover (process-wide). */
+void cppf_debug_set_pcr_max_rows(int n);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
  * cuboids [O,6] = (-sx/2,-sy/2,-sz/2, sx/2,sy/2,sz/2); Rt [O,12] = rotation row-major (9) then translation (3), HOST
@@ -192,7 +196,7 @@ typedef struct cppf_full_params {
  * implemented): one coupled LM step for each of S trajectories x_in [S*W, d] (the reference: one trajectory, :128).
  * target [W,7]; virtual_configs [S*W, d] or NULL (= x_in, which is what the loop sets at optimization.py:253).
  * Obstacles are those of cppf_set_obstacles.  The normal matrix is never formed densely: it is block-tridiagonal and is
- * eliminated per trajectory.  Workspace (device): work_blocks [S*W * (d(d+1)/2 + d)], work_G [S*W * d(d+1)/2],
+ * eliminated per trajectory.  Workspace (device): work_blocks [S*W * (d(d+1)/2 + d)], work_G [S*W * d*d],
  * work_y [S*W * d] floats.  x_out [S*W, d] must not alias x_in. */
 int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* target, const float* virtual_configs, int S,
                       int W, const cppf_full_params* params, float* work_blocks, float* work_G, float* work_y,

@@ -379,6 +379,13 @@ def test_coupled_lm_step_matches_dense_reference_order_oracle(robots, name, vari
     xv = H.f32(x + 0.01 * rng.randn(*x.shape)) if variant == "everything" else None
     pm.virtual_configs = dev(xv) if xv is not None else torch.tensor([])
     got = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
+    # the other elimination order (waypoint after waypoint instead of parallel cyclic reduction over the waypoints) must
+    # land on the same step
+    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    try:
+        sequential = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
+    finally:
+        _hip.lib().cppf_debug_set_pcr_max_rows(131072)
     want, r = H.oracle64(name).lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi, return_residual=True)
     n_fixed = (6 * T if pm.use_pose else 0) + ((T - 1) * rb.ndof if pm.use_differencing else 0) + (8 * rb.ndof if pm.use_virtual_configs else 0)
     if variant != "pose_only":
@@ -402,6 +409,40 @@ def test_coupled_lm_step_matches_dense_reference_order_oracle(robots, name, vari
             assert np.abs(want - batched)[ok].max() < 5e-3  # dual-form kernel vs the dense fp64 formulation
     else:
         assert np.abs(got - want).max() < 2e-4 + 2e-3 * step, (np.abs(got - want).max(), step)
+        assert np.abs(sequential - want).max() < 2e-4 + 2e-3 * step, (np.abs(sequential - want).max(), step)
+    rb.set_obstacles([], [])
+
+
+@pytest.mark.parametrize("name,T", [("panda", 256), ("fetch", 300), ("panda", 1), ("panda", 2), ("fetch_arm", 59)])
+def test_coupled_step_parallel_in_time_equals_sequential_elimination(robots, name, T):
+    """cppf_lm_full_step at the reference's cadence (one trajectory, optimization.py:128) runs parallel cyclic reduction over
+    the waypoints; at full path lengths (beyond what the dense oracle handles in seconds) it must agree with the
+    waypoint-after-waypoint elimination of the same system, and with the oracle on the short path."""
+    rb, ch = robots[name], H.chain(name)
+    rng = np.random.RandomState(T)
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T_ for _, T_ in obs])
+    pm = _full_params()
+    pm.virtual_configs = torch.tensor([])
+    S = 2
+    base = np.clip(rng.uniform(ch.lo, ch.hi)[None, :] * 0.5 + np.cumsum(0.03 * rng.randn(T, rb.ndof), axis=0), ch.lo, ch.hi)
+    x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, rb.ndof), ch.lo, ch.hi).reshape(S * T, rb.ndof))
+    target = H.f32(H.oracle64(name).fk(H.f32(base)))
+    if 2 * pm.n_virtual_configs >= T:
+        pm = _full_params(use_virtual_configs=False)
+        pm.virtual_configs = torch.tensor([])
+    pcr = host(rb.lm_full_step(dev(x), dev(target), pm))
+    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    try:
+        seq = host(rb.lm_full_step(dev(x), dev(target), pm))
+    finally:
+        _hip.lib().cppf_debug_set_pcr_max_rows(131072)
+    step = np.abs(seq - x).max()
+    assert np.isfinite(pcr).all() and np.abs(pcr - seq).max() < 1e-5 + 1e-3 * step, (np.abs(pcr - seq).max(), step)
+    if T <= 64:
+        lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
+        want = H.oracle64(name).lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi)
+        assert np.abs(pcr - want).max() < 2e-4 + 2e-3 * step
     rb.set_obstacles([], [])
 
 
