@@ -21,9 +21,8 @@ import torch
 
 from cppflow_amd.config import ENV_COLLISIONS_IGNORED, SELF_COLLISIONS_IGNORED
 from cppflow_amd.data_types import Constraints, Problem
-from cppflow_amd.evaluation_utils import angular_changes
 from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, OptimizationParameters
-from cppflow_amd.optimization_utils import clamp_to_joint_limits, x_is_valid
+from cppflow_amd.optimization_utils import clamp_to_joint_limits, evaluate_seeds, x_is_valid
 from cppflow_amd.utils import make_text_green_or_red
 
 
@@ -148,13 +147,6 @@ def run_lm_alternating_loss(
     params_diff = OptimizationParameters(**params_diff.__dict__)
     params_pose = OptimizationParameters(**params_pose.__dict__)
 
-    def calc_TL(qpath):
-        rev, _ = robot.split_configs_to_revolute_and_prismatic(qpath)
-        if opt_problem.parallel_count > 1:  # per-seed joint changes: do not difference across trajectory boundaries
-            rev = rev.view(opt_problem.parallel_count, W, -1)
-            return float(torch.stack([angular_changes(r).abs().sum() for r in rev]).sum().item())
-        return angular_changes(rev).abs().sum().item()
-
     tls_post_differencing = []
     last_valid, last_valid_idx, valid_seed_idx = None, -1, 0
     pose_pos_valid, pose_rot_valid = True, False  # the reference's initial values (:218-219): lead with a pose step
@@ -177,7 +169,10 @@ def run_lm_alternating_loss(
         opt_state.x = clamp_to_joint_limits(robot, x_new)  # :259
         opt_state.n_steps += 1
 
-        tl_new = calc_TL(opt_state.x)
+        # one evaluation of every trajectory per iteration: validity maxima, collision counts and the TL measure (the summed
+        # revolute path length, :221-227) come back in a single [S,16] host tensor
+        seed_metrics = evaluate_seeds(opt_problem.problem, target, opt_state.x, opt_problem.parallel_count)
+        tl_new = float(seed_metrics[:, 6].sum())
         printc(f"  tl: {tl_new}")
         stop_now = False
         if took_differencing:  # :275-297
@@ -192,7 +187,8 @@ def run_lm_alternating_loss(
             break
 
         x_sol, seed_idx, flags = x_is_valid(
-            opt_problem.problem, opt_problem.constraints, target, opt_state.x, opt_problem.parallel_count, verbosity=verbosity
+            opt_problem.problem, opt_problem.constraints, target, opt_state.x, opt_problem.parallel_count, verbosity=verbosity,
+            seed_metrics=seed_metrics,
         )
         pose_pos_valid, pose_rot_valid = flags[0], flags[1]
         if x_sol is not None:

@@ -48,6 +48,24 @@ def clamp_to_joint_limits(robot, x: torch.Tensor, verbosity: int = 0) -> torch.T
     return robot.clamp_to_joint_limits(x)
 
 
+def evaluate_seeds(problem, target_path: torch.Tensor, x: torch.Tensor, parallel_count: int) -> torch.Tensor:
+    """Everything the loop control needs to know about `parallel_count` trajectories, as one host tensor [S,16]
+    (columns `Robot.PLAN_METRIC_FIELDS`): the x_is_valid maxima, the collision counts and the revolute path length
+    (= the loop's TL measure, cppflow/optimization.py:221-227).  Two launches (capsule masks of every seed, per-seed
+    reduction) and ONE device-to-host copy per LM iteration instead of the reference's per-quantity `.item()` syncs."""
+    W = problem.n_timesteps
+    assert x.shape[0] == W * parallel_count, f"x has {x.shape[0]} rows, expected {W} * {parallel_count}"
+    target = target_path[:W] if target_path.shape[0] != W else target_path
+    robot = problem.robot
+    self_m = env_m = None
+    if not (SELF_COLLISIONS_IGNORED and ENV_COLLISIONS_IGNORED):
+        problem.bind_obstacles()
+        masks = robot.collision_masks(x.view(parallel_count, W, -1), only=("self", "env"))
+        self_m = None if SELF_COLLISIONS_IGNORED else masks["self_mask"].view(-1)
+        env_m = None if ENV_COLLISIONS_IGNORED else masks["env_mask"].view(-1)
+    return robot.plan_metrics(x, target, self_m, env_m).cpu()
+
+
 def x_is_valid(
     problem,
     constraints,
@@ -56,43 +74,39 @@ def x_is_valid(
     parallel_count: int,
     results_df=None,
     verbosity: int = 0,
+    seed_metrics: Optional[torch.Tensor] = None,
 ):
     """First seed (in order) whose trajectory satisfies every constraint: returns `(x_i, i, flags)` or
     `(None, None, flags)` with flags = (pose_pos_valid, pose_rot_valid, mjac_rev_valid, mjac_pris_valid,
     is_a_self_collision, is_a_env_collision) of the last seed examined -- the contract of
-    cppflow/optimization_utils.py:836-923.
+    cppflow/optimization_utils.py:836-923 (collision flags stay None for seeds that fail a threshold, as there).
 
-    One launch produces the four per-seed maxima for all seeds (`Robot.seed_validity`); seeds that pass them are then
-    collision-checked.  The reference does that last step with klampt's exact meshes (`:889-900`), which is outside this
-    build; the capsule masks of cppflow/collision_detection.py:72-86 are used instead (conservative: capsules bound the
-    links)."""
+    The decision is taken on the host from `evaluate_seeds` (pass `seed_metrics` to reuse one already computed for this x).
+    The reference does the collision part with klampt's exact meshes (`:889-900`), which is outside this build; the capsule
+    masks of cppflow/collision_detection.py:72-86 are used instead (conservative: capsules bound the links)."""
     assert results_df is None, "results_df logging is dead code in the reference (data_types.py:420-421) and unsupported"
     W = problem.n_timesteps
     assert x.shape[0] == W * parallel_count, f"x has {x.shape[0]} rows, expected {W} * {parallel_count}"
-    target = target_path_stacked[:W] if target_path_stacked.shape[0] != W else target_path_stacked
-    metrics = problem.robot.seed_validity(x, target).cpu()  # [S, 4]: one small D2H copy
+    m = seed_metrics if seed_metrics is not None else evaluate_seeds(problem, target_path_stacked, x, parallel_count)
+    assert m.shape[0] == parallel_count and m.shape[1] >= 12
     is_a_self_collision: Optional[bool] = None
     is_a_env_collision: Optional[bool] = None
     flags = (False, False, False, False)
     for i in range(parallel_count):
-        all_valid, flags = seed_metrics_are_below_threshold(constraints, metrics[i])
+        all_valid, flags = seed_metrics_are_below_threshold(constraints, (m[i, 0], m[i, 2], m[i, 4], m[i, 5]))
         if not all_valid:
             continue
-        x_i = x[i * W : (i + 1) * W, :]
-        if not (SELF_COLLISIONS_IGNORED and ENV_COLLISIONS_IGNORED):
-            problem.bind_obstacles()
-            masks = problem.robot.collision_masks(x_i.unsqueeze(0), only=("self", "env"))
-            if not SELF_COLLISIONS_IGNORED:
-                is_a_self_collision = bool(masks["self_mask"].any().item())
-                if is_a_self_collision:
-                    continue
-            if not ENV_COLLISIONS_IGNORED:
-                is_a_env_collision = bool(masks["env_mask"].any().item())
-                if is_a_env_collision:
-                    continue
+        if not SELF_COLLISIONS_IGNORED:
+            is_a_self_collision = float(m[i, 9]) > 0
+            if is_a_self_collision:
+                continue
+        if not ENV_COLLISIONS_IGNORED:
+            is_a_env_collision = float(m[i, 10]) > 0
+            if is_a_env_collision:
+                continue
         if verbosity > 1:
             print("x_is_valid() |", make_text_green_or_red("x is valid", True))
-        return x_i, i, (*flags, is_a_self_collision, is_a_env_collision)
+        return x[i * W : (i + 1) * W, :], i, (*flags, is_a_self_collision, is_a_env_collision)
     if verbosity > 1:
         print("x_is_valid() |", make_text_green_or_red("x is invalid", False))
     return None, None, (*flags, is_a_self_collision, is_a_env_collision)
