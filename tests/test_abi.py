@@ -113,3 +113,11 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
     assert os.access(exe, os.X_OK)
     nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
     assert "cppf_lm_pose_steps" in nm and "cppf_robot_create" in nm
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build(): compiles (or finds up to date) the HIP library and the oracle, checks the ABI version."""
+    import importlib
+
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
