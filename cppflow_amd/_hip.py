@@ -112,6 +112,9 @@ SIGNATURES = {
     ),
     "cppf_pose_error_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp]),
     "cppf_seed_validity": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    "cppf_self_collision_distances_jacobian": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "cppf_env_collision_distances_jacobian": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f),
+                                                             _vp, _vp, _vp]),
     "cppf_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cppf_seed_summary": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cppf_lm_full_step": (

@@ -1080,6 +1080,88 @@ __device__ __forceinline__ void rank1(float (&M)[D * (D + 1) / 2], float (&m)[D]
     }
 }
 
+// Robot.self_collision_distances_jacobian(x) / Robot.env_collision_distances_jacobian(x, cuboid, Tcuboid) (jrl; call sites
+// cppflow/optimization_utils.py:670, 710): d(distance)/dq per pair / per capsule with the closest points held fixed on their
+// links,  n . (dc1/dq - dc2/dq)  (0 where the segments touch: the direction is undefined).  Same FK, closest-point and
+// gradient code as the coupled step (full_blocks_kernel), which only ever needs the colliding ones.
+template <int D, bool ENV>
+__global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK ch, const CollK co, int n,
+                                                                    const float* __restrict__ x, float blo0, float blo1,
+                                                                    float blo2, float bhi0, float bhi1, float bhi2,
+                                                                    float* __restrict__ jac, float* __restrict__ dists) {
+    extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3];
+    load_x<D>(x, row, q);
+    frame_identity(R, p);
+    for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, rb.pris(j), q[j]);
+        for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
+            float w0[3], w1[3];
+            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
+            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lds[(c * 6 + k) * kBlock + tid] = w0[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+            }
+        }
+    }
+    const int count = ENV ? co.ncaps : co.npairs;
+    for (int e = 0; e < count; ++e) {
+        float nrm[3] = {0.f, 0.f, 0.f}, g[D], sd, radius;
+#pragma unroll
+        for (int j = 0; j < D; ++j) g[j] = 0.f;
+        if constexpr (ENV) {
+            const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
+            float w0[3], w1[3], cs[3], cb[3];
+            lds_capsule(lds, tid, e, w0, w1);
+            sd = seg_box_closest(w0, w1, lo, hi, cs, cb);
+            radius = co.cap_r[e];
+            if (sd > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
+            }
+            point_grad<RB>(rb, co.cap_link[e], nrm, cs, ax, og, 1.f, g);
+        } else {
+            const int a = co.pair_a[e], b = co.pair_b[e];
+            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            radius = co.cap_r[a] + co.cap_r[b];
+            if (sd > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
+            }
+            point_grad<RB>(rb, co.cap_link[a], nrm, c1, ax, og, 1.f, g);
+            point_grad<RB>(rb, co.cap_link[b], nrm, c2, ax, og, -1.f, g);
+        }
+        float* o = jac + (row * count + e) * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = g[j];
+        if (dists) dists[row * count + e] = sd - radius;
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
                                                              const float* __restrict__ x,
@@ -2281,6 +2363,43 @@ int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n,
     CPPF_DISPATCH_D(robot->desc.ndof,
                     hipLaunchKernelGGL((distances_kernel<D, true>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
                                        st, robot->chain, robot->coll, n, x, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2],
+                                       dists));
+    return check_launch(robot);
+}
+
+int cppf_self_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, float* jac, float* dists,
+                                           void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    if (n == 0 || robot->coll.npairs == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && jac, "x / jac is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((distance_jacobians_kernel<D, false>), dim3(grid_for(n)), dim3(kBlock),
+                                       robot->lds_bytes, st, robot->chain, robot->coll, n, x, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, jac,
+                                       dists));
+    return check_launch(robot);
+}
+
+int cppf_env_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, const float* cuboid,
+                                          const float* Rt, float* jac, float* dists, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(n >= 0, "n < 0");
+    CPPF_REQUIRE(cuboid && Rt, "cuboid / Rt is NULL");
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k)
+        CPPF_REQUIRE(std::fabs(Rt[k] - I[k]) < 1e-8f, "only axis-aligned cuboids are supported (R must be I)");
+    if (n == 0 || robot->coll.ncaps == 0) return CPPF_OK;
+    CPPF_REQUIRE(x && jac, "x / jac is NULL");
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = Rt[9 + k] + cuboid[k];
+        hi[k] = Rt[9 + k] + cuboid[3 + k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof,
+                    hipLaunchKernelGGL((distance_jacobians_kernel<D, true>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes,
+                                       st, robot->chain, robot->coll, n, x, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], jac,
                                        dists));
     return check_launch(robot);
 }

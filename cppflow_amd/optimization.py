@@ -22,7 +22,7 @@ import torch
 from cppflow_amd.config import ENV_COLLISIONS_IGNORED, SELF_COLLISIONS_IGNORED
 from cppflow_amd.data_types import Constraints, Problem
 from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, OptimizationParameters
-from cppflow_amd.optimization_utils import clamp_to_joint_limits, evaluate_seeds, x_is_valid
+from cppflow_amd.optimization_utils import LmResidualFns, clamp_to_joint_limits, evaluate_seeds, x_is_valid
 from cppflow_amd.utils import make_text_green_or_red
 
 
@@ -104,11 +104,19 @@ def levenberg_marquardt_full(
     residuals of whole trajectories, solved as a block-tridiagonal system per trajectory on the device
     (`cppf_lm_full_step`).  Unlike the reference (`assert parallel_count == 1`, :128) any number of seeds is accepted:
     opt_state.x is [parallel_count * W, ndof] and every trajectory is smoothed independently in the same launch."""
-    assert not return_residual, "the dense residual / Jacobian are never formed on the device"
     opt_problem.problem.bind_obstacles()
-    return opt_problem.robot.lm_full_step(
+    x_new = opt_problem.robot.lm_full_step(
         opt_state.x, _unstacked_target(opt_problem), opt_params, virtual_configs=opt_params.virtual_configs
     )
+    if not return_residual:
+        return x_new
+    # inspection path: the dense (J, r) the reference would have factored (the step above never forms them)
+    assert opt_problem.parallel_count == 1, "the dense residual / Jacobian are defined for one trajectory (:128)"
+    jacobian, residual = LmResidualFns.get_r_and_J(
+        opt_params, opt_problem.robot, opt_state.x, _unstacked_target(opt_problem),
+        Tcuboids=opt_problem.problem.obstacles_Tcuboids, cuboids=opt_problem.problem.obstacles_cuboids,
+    )  # fmt: skip
+    return x_new, jacobian, residual
 
 
 def run_lm_alternating_loss(

@@ -1,14 +1,17 @@
 """Hot-path helpers with the reference's names and argument meaning (`cppflow/optimization_utils.py`):
-`get_6d_pose_errors` (`:802-820`), `clamp_to_joint_limits` (`:823-833`), `x_is_valid` (`:836-923`), and the two row-mask
-helpers (`:31-60`).  Each compute call is one kernel launch through the C ABI.
+`get_6d_pose_errors` (`:802-820`), `clamp_to_joint_limits` (`:823-833`), `x_is_valid` (`:836-923`), the two row-mask
+helpers (`:224-250`) and the dense residual / Jacobian builder `LmResidualFns.get_r_and_J` (`:252-731`) with its
+`LmResidual` / `LmJacobian` containers.  Each compute call is one kernel launch through the C ABI.
 """
 
-from typing import Optional, Tuple
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from cppflow_amd.config import ENV_COLLISIONS_IGNORED, SELF_COLLISIONS_IGNORED
-from cppflow_amd.evaluation_utils import seed_metrics_are_below_threshold
+from cppflow_amd.evaluation_utils import angular_changes, seed_metrics_are_below_threshold
 from cppflow_amd.lm_hyper_parameters import OptimizationParameters  # noqa: F401  (re-exported like the reference)
 from cppflow_amd.utils import make_text_green_or_red
 
@@ -26,6 +29,180 @@ def _get_rotation_and_position_row_mask(n: int) -> Tuple[torch.Tensor, torch.Ten
     """Masks over the 6n rows of a stacked pose residual laid out [rot3, pos3] per config: (rotation, position)."""
     rot = torch.tensor([True, True, True, False, False, False]).tile(n)
     return rot, torch.logical_not(rot)
+
+
+_PARTS = ("pose", "differencing", "virtual_configs", "self_collisions", "env_collisions")
+
+
+@dataclass
+class LmResidual:
+    """The stacked residual of one trajectory, by part, in the reference's stacking order (cppflow/optimization_utils.py:
+    31-125): each part is a column [m_i, 1] or None.  `times` stands in for the reference's ten time_* fields."""
+
+    pose: Optional[torch.Tensor] = None
+    differencing: Optional[torch.Tensor] = None
+    virtual_configs: Optional[torch.Tensor] = None
+    self_collisions: Optional[torch.Tensor] = None
+    env_collisions: Optional[torch.Tensor] = None
+    pose_invalid_row_idxs: Optional[torch.Tensor] = None
+    differencing_invalid_row_idxs: Optional[torch.Tensor] = None
+    times: Dict[str, float] = field(default_factory=dict)
+
+    def total_time(self) -> float:
+        return float(sum(self.times.values()))
+
+    def get_r(self) -> torch.Tensor:
+        return torch.cat([getattr(self, k) for k in _PARTS if getattr(self, k) is not None], dim=0)
+
+    def verify_J(self, J: "LmJacobian") -> None:
+        for k in _PARTS:
+            r_k, J_k = getattr(self, k), getattr(J, k)
+            if r_k is not None and r_k.numel() > 0:
+                assert J_k is not None and J_k.shape[0] == r_k.shape[0], f"{k}: residual / Jacobian row mismatch"
+
+
+@dataclass
+class LmJacobian:
+    """The matching Jacobian parts, each [m_i, n * ndof] or None (cppflow/optimization_utils.py:127-221)."""
+
+    pose: Optional[torch.Tensor] = None
+    differencing: Optional[torch.Tensor] = None
+    virtual_configs: Optional[torch.Tensor] = None
+    self_collisions: Optional[torch.Tensor] = None
+    env_collisions: Optional[torch.Tensor] = None
+    pose_invalid_row_idxs: Optional[torch.Tensor] = None
+    differencing_invalid_row_idxs: Optional[torch.Tensor] = None
+    times: Dict[str, float] = field(default_factory=dict)
+
+    def total_time(self) -> float:
+        return float(sum(self.times.values()))
+
+    def get_J(self) -> torch.Tensor:
+        return torch.cat([getattr(self, k) for k in _PARTS if getattr(self, k) is not None], dim=0)
+
+    def verify_r(self, r: LmResidual) -> None:
+        r.verify_J(self)
+
+
+class LmResidualFns:
+    """Dense residual and Jacobian of ONE trajectory, as `levenberg_marquardt_full` of the reference stacks them
+    (cppflow/optimization_utils.py:252-731).  This is the inspection / test path: the production step
+    (`Robot.lm_full_step`, cppf_lm_full_step) never forms these matrices -- it accumulates the waypoint-local blocks of
+    J^T J and J^T r on the device and eliminates the block-tridiagonal system.  Here every per-row quantity still comes
+    from the HIP kernels (pose errors, geometric Jacobian, capsule distances and their Jacobians); only the placement
+    into the dense [m, n*ndof] layout is torch indexing.  Sign conventions are the reference's (differencing rows: +1 at
+    (t, j), -1 at (t+1, j); virtual-config blocks -I)."""
+
+    @staticmethod
+    def _get_residual_pose(robot, x: torch.Tensor, target_path: torch.Tensor):
+        e, current = get_6d_pose_errors(robot, x, target_path)
+        return e.reshape(6 * x.shape[0], 1), current
+
+    @staticmethod
+    def _get_jacobian_pose(robot, x: torch.Tensor) -> torch.Tensor:
+        n, d = x.shape
+        J = torch.zeros((6 * n, d * n), dtype=x.dtype, device=x.device)
+        idx = torch.arange(n, device=x.device)
+        J.view(n, 6, n, d)[idx, :, idx, :] = robot.jacobian(x)
+        return J
+
+    @staticmethod
+    def _get_residual_differencing(robot, x: torch.Tensor) -> torch.Tensor:
+        return angular_changes(x).reshape((x.shape[0] - 1) * robot.ndof, 1)
+
+    @staticmethod
+    def _get_jacobian_differencing(robot, x: torch.Tensor) -> torch.Tensor:
+        n, d = x.shape
+        m = d * (n - 1)
+        J = torch.zeros((m, d * n), dtype=x.dtype, device=x.device)
+        k = torch.arange(m, device=x.device)
+        J[k, k] = 1.0
+        J[k, k + d] = -1.0
+        return J
+
+    @staticmethod
+    def _virtual_rows(pms, n: int, d: int, device) -> torch.Tensor:
+        """Indices of the configs that have a virtual twin: the first and the last n_virtual_configs waypoints."""
+        nv = pms.n_virtual_configs
+        return torch.cat([torch.arange(nv, device=device), torch.arange(n - nv, n, device=device)])
+
+    @staticmethod
+    def _get_residual_virtual_joints(pms, robot, x: torch.Tensor) -> torch.Tensor:
+        assert x.shape == pms.virtual_configs.shape
+        n, d = x.shape
+        assert 2 * pms.n_virtual_configs < n, f"{2 * pms.n_virtual_configs} virtual configs for {n} configs"
+        rows = LmResidualFns._virtual_rows(pms, n, d, x.device)
+        diff = x[rows] - pms.virtual_configs.to(x.device)[rows]
+        return (torch.remainder(diff + math.pi, 2 * math.pi) - math.pi).reshape(-1, 1)  # angular_subtraction
+
+    @staticmethod
+    def _get_jacobian_virtual_configs(pms, robot, x: torch.Tensor) -> torch.Tensor:
+        n, d = x.shape
+        rows = LmResidualFns._virtual_rows(pms, n, d, x.device)
+        J = torch.zeros((rows.numel() * d, n * d), dtype=x.dtype, device=x.device)
+        r = torch.arange(rows.numel() * d, device=x.device)
+        J[r, (rows[:, None] * d + torch.arange(d, device=x.device)[None, :]).reshape(-1)] = -1.0
+        return J
+
+    @staticmethod
+    def _collision_rows(dist: torch.Tensor, jac: torch.Tensor, alpha: float):
+        """Active rows of one distance family: r = -alpha * dist where that is > 0 (row-major over (config, pair)),
+        J = alpha * d(dist)/dq placed in the config's column block."""
+        n, P = dist.shape
+        d = jac.shape[2]
+        r_all = (-alpha * dist).reshape(-1)
+        active = torch.nonzero(r_all > 0).reshape(-1)
+        r = r_all[active].reshape(-1, 1)
+        if active.numel() == 0:
+            return r, None
+        cfg = torch.div(active, P, rounding_mode="floor")
+        J = torch.zeros((active.numel(), n * d), dtype=dist.dtype, device=dist.device)
+        cols = cfg[:, None] * d + torch.arange(d, device=dist.device)[None, :]
+        J[torch.arange(active.numel(), device=dist.device)[:, None], cols] = alpha * jac.reshape(n * P, d)[active]
+        return r, J
+
+    @staticmethod
+    def get_r_and_J(pms, robot, x: torch.Tensor, target_path: torch.Tensor, Tcuboids: Optional[List] = None,
+                    cuboids: Optional[List] = None) -> Tuple[LmJacobian, LmResidual]:  # fmt: skip
+        assert not pms.pose_do_scale_down_satisfied and not pms.differencing_do_ignore_satisfied, "option not implemented"
+        assert not pms.differencing_do_scale_satisfied, "option not implemented"
+        n, d = x.shape
+        residual, jacobian = LmResidual(), LmJacobian()
+        if pms.use_pose:
+            r_pose, _ = LmResidualFns._get_residual_pose(robot, x, target_path)
+            J_pose = LmResidualFns._get_jacobian_pose(robot, x)
+            scale = torch.tensor([pms.alpha_rotation] * 3 + [pms.alpha_position] * 3, dtype=x.dtype, device=x.device).repeat(n)
+            residual.pose, jacobian.pose = r_pose * scale[:, None], J_pose * scale[:, None]
+        if pms.use_differencing:
+            r_diff = LmResidualFns._get_residual_differencing(robot, x)
+            J_diff = LmResidualFns._get_jacobian_differencing(robot, x)
+            if robot.has_prismatic_joints:
+                _, pris_rows = _get_prismatic_and_revolute_row_mask(robot, r_diff.shape[0])
+                r_diff[pris_rows] *= pms.alpha_differencing_prismatic_scaling
+                J_diff[pris_rows] *= pms.alpha_differencing_prismatic_scaling
+            residual.differencing = pms.alpha_differencing * r_diff
+            jacobian.differencing = pms.alpha_differencing * J_diff
+        if pms.use_virtual_configs:
+            beta = pms.alpha_virtual_configs * pms.alpha_differencing
+            residual.virtual_configs = beta * LmResidualFns._get_residual_virtual_joints(pms, robot, x)
+            jacobian.virtual_configs = beta * LmResidualFns._get_jacobian_virtual_configs(pms, robot, x)
+        if pms.use_self_collisions:
+            jac, dist = robot.self_collision_distances_jacobian(x, return_distances=True)
+            residual.self_collisions, jacobian.self_collisions = LmResidualFns._collision_rows(
+                dist, jac, pms.alpha_self_collision
+            )
+        if pms.use_env_collisions and Tcuboids is not None and len(Tcuboids) > 0:
+            rs, Js = [], []
+            for Tcuboid, cuboid in zip(Tcuboids, cuboids):
+                jac, dist = robot.env_collision_distances_jacobian(x, cuboid, Tcuboid, return_distances=True)
+                r_o, J_o = LmResidualFns._collision_rows(dist, jac, pms.alpha_env_collision)
+                if J_o is not None:
+                    rs.append(r_o)
+                    Js.append(J_o)
+            if rs:
+                residual.env_collisions, jacobian.env_collisions = torch.cat(rs, dim=0), torch.cat(Js, dim=0)
+        jacobian.verify_r(residual)
+        return jacobian, residual
 
 
 def get_6d_pose_errors(robot, x: torch.Tensor, target_poses: torch.Tensor):

@@ -219,6 +219,35 @@ class Robot:
         )
         return d
 
+    def self_collision_distances_jacobian(self, x: torch.Tensor, return_distances: bool = False):
+        """[n, n_pairs, d] = d(self_collision_distances)/dq (jrl API; call site cppflow/optimization_utils.py:670)."""
+        x = self._x2d(x)
+        n = x.shape[0]
+        J = torch.zeros((n, self.n_collision_pairs, self.ndof), dtype=torch.float32, device=x.device)
+        dist = torch.empty((n, self.n_collision_pairs), dtype=torch.float32, device=x.device) if return_distances else None
+        _hip.check(
+            _hip.lib().cppf_self_collision_distances_jacobian(
+                self._handle(x.device), x.data_ptr(), n, J.data_ptr(), dist.data_ptr() if dist is not None else None,
+                _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return (J, dist) if return_distances else J
+
+    def env_collision_distances_jacobian(self, x: torch.Tensor, cuboid, Tcuboid, return_distances: bool = False):
+        """[n, n_capsules, d] = d(env_collision_distances)/dq for ONE cuboid (jrl API; call site optimization_utils.py:710)."""
+        x = self._x2d(x)
+        n = x.shape[0]
+        cub, rt = self._pack_obstacles([cuboid], [Tcuboid])
+        J = torch.zeros((n, self.n_capsules, self.ndof), dtype=torch.float32, device=x.device)
+        dist = torch.empty((n, self.n_capsules), dtype=torch.float32, device=x.device) if return_distances else None
+        _hip.check(
+            _hip.lib().cppf_env_collision_distances_jacobian(
+                self._handle(x.device), x.data_ptr(), n, _hip.fptr(cub[0]), _hip.fptr(rt[0]), J.data_ptr(),
+                dist.data_ptr() if dist is not None else None, _stream_ptr(x.device),
+            )  # fmt: skip
+        )
+        return (J, dist) if return_distances else J
+
     def clamp_to_joint_limits(self, x: torch.Tensor) -> torch.Tensor:
         """In place (and returned), like cppflow/optimization_utils.py:831-833."""
         x_c = self._x2d(x)

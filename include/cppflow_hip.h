@@ -148,6 +148,15 @@ int cppf_self_collision_distances(const cppf_robot* robot, const float* x, int n
 int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n, const float* cuboid, const float* Rt,
                                  float* dists, void* stream);
 
+/* Robot.self_collision_distances_jacobian(x) -> [n, n_pairs, d] and Robot.env_collision_distances_jacobian(x, cuboid,
+ * Tcuboid) -> [n, n_capsules, d] (jrl; call sites cppflow/optimization_utils.py:670, 710): d(distance)/dq with the
+ * closest points held fixed on their links.  `dists` (same leading shape, may be NULL) receives the distances the
+ * gradients belong to, so that a caller needs one launch for both. */
+int cppf_self_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, float* jac, float* dists,
+                                           void* stream);
+int cppf_env_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, const float* cuboid,
+                                          const float* Rt, float* jac, float* dists, void* stream);
+
 /* calculate_pose_error_cm_deg's two per-row terms (cppflow/evaluation_utils.py:113-116) in metres / radians */
 int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* pos_err_m,
                             float* rot_err_rad, void* stream);

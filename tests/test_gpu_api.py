@@ -707,3 +707,77 @@ def test_large_batch_indexing(robots):
     torch.cuda.empty_cache()
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_distance_jacobians_match_oracle(robots, name):
+    """Robot.self_collision_distances_jacobian / env_collision_distances_jacobian (jrl API, call sites
+    cppflow/optimization_utils.py:670, 710) vs the fp64 oracle's analytic gradients (themselves checked against finite
+    differences on the CPU); the distances returned alongside equal the standalone distance kernels bit for bit."""
+    rb, orc = robots[name], H.oracle64(name)
+    x = H.random_configs(name, 300, seed=21)
+    J, dist = rb.self_collision_distances_jacobian(dev(x), return_distances=True)
+    assert torch.equal(dist, rb.self_collision_distances(dev(x)))
+    want_d, want_g = orc.self_dists_grads(x)
+    assert J.shape == want_g.shape and np.abs(host(dist) - want_d).max() < 2e-6
+    ok = want_d > 1e-4  # touching segments have no direction; near-parallel pairs switch closest points at fp32 noise
+    assert np.abs(host(J) - want_g)[ok].max() < 2e-3 and np.median(np.abs(host(J) - want_g)[ok]) < 1e-6
+    cub, T = H.PANDA_2CUBES[0]
+    lo, hi = H.box_corners([cub], [T])
+    Je, de = rb.env_collision_distances_jacobian(dev(x), cub, T, return_distances=True)
+    assert torch.equal(de, rb.env_collision_distances(dev(x), cub, T))
+    want_d, want_g = orc.env_dists_grads(x, lo[0], hi[0])
+    assert Je.shape == want_g.shape and np.abs(host(de) - want_d).max() < 2e-6
+    ok = want_d > 1e-4
+    assert np.abs(host(Je) - want_g)[ok].max() < 2e-3 and np.median(np.abs(host(Je) - want_g)[ok]) < 1e-6
+    assert torch.equal(rb.self_collision_distances_jacobian(dev(x)), J)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_dense_residual_and_jacobian_reproduce_the_device_step(robots, name):
+    """LmResidualFns.get_r_and_J (cppflow/optimization_utils.py:486-731) builds the dense r and J of one trajectory from
+    the device's per-row quantities.  (1) r equals the oracle's stacked residual row for row; (2) the reference's own
+    dense step  x + solve(J^T J + lambda I, J^T r)  (optimization.py:95-113), evaluated in fp64 on those matrices, lands on
+    what cppf_lm_full_step computes without ever forming them; (3) the reference's differencing known answer
+    (tests/optimization_utils_test.py:590-637)."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.optimization import OptimizationProblem, OptimizationState, levenberg_marquardt_full
+    from cppflow_amd.optimization_utils import LmResidualFns
+
+    rb, ch, orc = robots[name], H.chain(name), H.oracle64(name)
+    rng = np.random.RandomState(17)
+    T = 20
+    obs = H.PANDA_2CUBES
+    lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
+    cand = H.random_configs(name, 4000, seed=11)
+    m = orc.masks(cand, lo, hi, None, None)
+    hit = cand[np.flatnonzero((m["self_mask"] | m["env_mask"]) > 0)[0]]
+    x = H.f32(np.clip(hit[None, :] + np.cumsum(0.02 * rng.randn(T, rb.ndof), axis=0), ch.lo, ch.hi))
+    target = H.f32(orc.fk(x))
+    problem = problem_from_arrays(rb, target, [(0.2, 0.3, 0.4, 0.15, 0.15, 0.15), (-0.25, 0.3, 0.75, 0.15, 0.15, 0.15)], device=DEV)
+    pm = _full_params()
+    pm.virtual_configs = dev(H.f32(x + 0.01 * rng.randn(*x.shape)))
+    opt_problem = OptimizationProblem(problem, problem.constraints, dev(x), problem.target_path, 0, 1, None)
+    x_new, jac, res = levenberg_marquardt_full(opt_problem, OptimizationState(dev(x), 0, 0.0), pm, return_residual=True)
+    J, r = host(jac.get_J()), host(res.get_r())[:, 0]
+    assert J.shape == (r.shape[0], T * rb.ndof) and res.self_collisions is not None
+    n_fixed = (T - 1) * rb.ndof + 8 * rb.ndof
+    assert r.shape[0] > n_fixed, "the case must contain active collision rows"
+    _, r_want = orc.lm_full_step(x, target, pm, 1, T, virtual_configs=host(pm.virtual_configs), boxes_lo=lo, boxes_hi=hi,
+                                 return_residual=True)  # fmt: skip
+    assert r_want.shape == r.shape and np.abs(r - r_want).max() < 2e-7
+    A = J.T @ J + pm.lm_lambda * np.eye(T * rb.ndof)
+    dense = x + np.linalg.solve(A, J.T @ r).reshape(T, rb.ndof)
+    step = np.abs(dense - x).max()
+    assert step > 1e-4 and np.abs(host(x_new) - dense).max() < 2e-4 + 2e-3 * step
+    # known answer of the reference's differencing test
+    xk = dev([[0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7],
+              [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07], [0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07]])  # fmt: skip
+    if name == "panda":
+        pk = _full_params(alpha_differencing=1.0, use_virtual_configs=False, use_self_collisions=False, use_env_collisions=False)
+        jk, rk = LmResidualFns.get_r_and_J(pk, rb, xk, rb.forward_kinematics(xk))
+        expected = [0.09, 0.18, 0.27, 0.36, 0.45, 0.54, 0.63, -0.09, -0.18, -0.27, -0.36, -0.45, -0.54, -0.63] + [0.0] * 7
+        np.testing.assert_allclose(host(rk.get_r())[:, 0], expected, atol=1e-6)
+        Jk = host(jk.get_J())
+        assert Jk.shape == (21, 28) and Jk[0, 0] == 1.0 and Jk[0, 7] == -1.0 and np.count_nonzero(Jk) == 42
+    rb.set_obstacles([], [])
