@@ -48,3 +48,14 @@ def env_colliding_configs_capsule(problem, qpath: torch.Tensor) -> torch.Tensor:
     """qpath [T, d] -> bool [T] (collision_detection.py:77-86)."""
     problem.bind_obstacles()
     return problem.robot.collision_masks(qpath.unsqueeze(0), only=("env",))["env_mask"][0]
+
+
+def env_colliding_links_capsule(problem, q: torch.Tensor) -> List[str]:
+    """Names of the links whose capsule penetrates an obstacle at configuration q [ndof]
+    (cppflow/collision_detection.py:135-145); column i of the distances belongs to the i-th capsule link."""
+    ordered_links = list(problem.robot._collision_capsules_by_link.keys())
+    hit = set()
+    for cuboid, Tcuboid in zip(problem.obstacles_cuboids, problem.obstacles_Tcuboids):
+        dists = problem.robot.env_collision_distances(q.reshape(1, -1), cuboid, Tcuboid)[0]
+        hit.update(ordered_links[i] for i in torch.nonzero(dists < 0).reshape(-1).tolist())
+    return sorted(hit)

@@ -57,6 +57,14 @@ class Robot:
         self.n_capsules: int = self.chain.n_capsules
         self.n_collision_pairs: int = self.chain.n_pairs
         self.collision_capsule_names: List[str] = list(self.chain.cap_names)
+        # jrl's ordered map link name -> capsule; column i of env_collision_distances is its i-th key
+        # (cppflow/collision_detection.py:137-142).  Values: [p0 (3), p1 (3), radius] in the link's canonical frame.
+        self._collision_capsules_by_link: Dict[str, torch.Tensor] = {}
+        for c, link_name in enumerate(self.chain.cap_names):
+            key = link_name if link_name not in self._collision_capsules_by_link else f"{link_name}#{c}"
+            self._collision_capsules_by_link[key] = torch.tensor(
+                [*self.chain.cap_p0[c], *self.chain.cap_p1[c], self.chain.cap_r[c]], dtype=torch.float32
+            )
         self._desc = _hip.chain_to_desc(self.chain)
         self._handles: Dict[int, ctypes.c_void_p] = {}
         self._obstacles: Optional[Tuple[np.ndarray, np.ndarray]] = None

@@ -781,3 +781,31 @@ def test_dense_residual_and_jacobian_reproduce_the_device_step(robots, name):
         Jk = host(jk.get_J())
         assert Jk.shape == (21, 28) and Jk[0, 0] == 1.0 and Jk[0, 7] == -1.0 and np.count_nonzero(Jk) == 42
     rb.set_obstacles([], [])
+
+
+def test_env_colliding_links_capsule(robots):
+    """env_colliding_links_capsule (cppflow/collision_detection.py:135-145): the links it names are the capsules whose
+    oracle distance to an obstacle is negative."""
+    from cppflow_amd.collision_detection import env_colliding_links_capsule
+    from cppflow_amd.data_type_utils import problem_from_arrays
+
+    rb, orc = robots["panda"], H.oracle64("panda")
+    target = H.f32(orc.fk(H.random_configs("panda", 4, seed=1)))
+    problem = problem_from_arrays(rb, target, [(0.2, 0.3, 0.4, 0.15, 0.15, 0.15), (-0.25, 0.3, 0.75, 0.15, 0.15, 0.15)], device=DEV)
+    lo, hi = H.box_corners([c for c, _ in H.PANDA_2CUBES], [T for _, T in H.PANDA_2CUBES])
+    names = list(rb._collision_capsules_by_link.keys())
+    assert len(names) == rb.n_capsules
+    cand = H.random_configs("panda", 500, seed=2)
+    n_hit = 0
+    for q in cand[:60]:
+        want = set()
+        for o in range(2):
+            d = orc.env_dists(q[None], lo[o], hi[o])[0]
+            want |= {names[i] for i in np.flatnonzero(d < -1e-6)}
+            borderline = np.abs(d) < 1e-6
+        got = set(env_colliding_links_capsule(problem, dev(q)))
+        if not borderline.any():
+            assert want <= got and len(got - want) == 0
+        n_hit += len(got) > 0
+    assert n_hit > 0
+    rb.set_obstacles([], [])

@@ -61,6 +61,17 @@ def test_robot_duck_type_surface():
         get_robot("pr2")
 
 
+def test_capsule_link_map_is_ordered_like_the_distance_columns():
+    """`robot._collision_capsules_by_link` (jrl attribute read at cppflow/collision_detection.py:137): one key per capsule, in
+    the column order of env_collision_distances."""
+    for name in ("panda", "fetch", "fetch_arm"):
+        rb = get_robot(name)
+        keys = list(rb._collision_capsules_by_link.keys())
+        assert len(keys) == rb.n_capsules == len(rb.collision_capsule_names)
+        assert [k.split("#")[0] for k in keys] == rb.collision_capsule_names
+        assert all(v.shape == (7,) and float(v[6]) > 0 for v in rb._collision_capsules_by_link.values())
+
+
 def test_no_cpu_fallback():
     """The product path fails loudly on CPU tensors instead of computing anywhere else."""
     rb = get_robot("panda")
