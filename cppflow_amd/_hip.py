@@ -115,6 +115,7 @@ SIGNATURES = {
     "cppf_self_collision_distances_jacobian": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "cppf_env_collision_distances_jacobian": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f),
                                                              _vp, _vp, _vp]),
+    "cppf_mjacs": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "cppf_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cppf_seed_summary": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cppf_lm_full_step": (

@@ -1867,6 +1867,31 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
     }
 }
 
+// _get_mjacs (cppflow/search.py:100-125): mjacs[i, j, t] = max over joints of |wrap(scale_j (q[i, t+1, j] - q[j_, t, j]))| -- the
+// [k, k, T-1] tensor the reference's dp_search materialises (1 GB at k = 1024).  cppf_dp_search never builds it; this
+// kernel exists for callers that want the tensor itself.  One lane per (i, j_, t), t fastest (coalesced writes).
+template <int D>
+__global__ __launch_bounds__(256) void mjacs_kernel(const float* __restrict__ q, int k, int T, uint32_t pris_mask, float pscale,
+                                                    float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)(T - 1);
+    const size_t total = (size_t)k * k * per;
+    if (idx >= total) return;
+    const int t = (int)(idx % per);
+    const size_t ij = idx / per;
+    const int j = (int)(ij % k), i = (int)(ij / k);
+    const float* qi = q + ((size_t)i * T + t + 1) * D;
+    const float* qj = q + ((size_t)j * T + t) * D;
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        float dq = qi[c] - qj[c];
+        if ((pris_mask >> c) & 1u) dq *= pscale;
+        m = fmaxf(m, fabsf(wrap_pi(dq)));
+    }
+    out[idx] = m;
+}
+
 // argmin over the final costs (first minimal index), walk the memo table back, gather the path
 __global__ __launch_bounds__(256) void dp_backtrace_kernel(const float* __restrict__ q, const float* __restrict__ costsT,
                                                            const int32_t* __restrict__ memoT, int k, int T, int d,
@@ -2531,6 +2556,20 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
                                                robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y,
                                                x_out));
     }
+    return check_launch(robot);
+}
+
+int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float prismatic_scaling, float* mjacs, void* stream) {
+    if (int rc = enter(robot)) return rc;
+    CPPF_REQUIRE(k >= 1 && T >= 1, "k, T must be >= 1");
+    if (T == 1) return CPPF_OK;
+    CPPF_REQUIRE(q && mjacs, "q / mjacs is NULL");
+    const size_t total = (size_t)k * k * (size_t)(T - 1);
+    CPPF_REQUIRE(total <= ((size_t)1 << 40), "k*k*(T-1) exceeds 2^40 entries");
+    CPPF_REQUIRE((total + 255) / 256 <= 0x7fffffffu, "grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    CPPF_DISPATCH_D(robot->desc.ndof, hipLaunchKernelGGL((mjacs_kernel<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                                                         st, q, k, T, robot->chain.pris_mask, prismatic_scaling, mjacs));
     return check_launch(robot);
 }
 

@@ -537,6 +537,21 @@ class Robot:
         )
         return out
 
+    def mjacs(self, q: torch.Tensor, prismatic_joint_scaling: float = 5.0) -> torch.Tensor:
+        """q [k,T,d] -> [k,k,T-1] maximum (wrapped, prismatic-scaled) joint change from candidate j at t to candidate i at
+        t+1 (cppflow/search.py:100-125).  `dp_search` does not use it -- it is the tensor the reference builds."""
+        q = _require_device_tensor(q, "q")
+        assert q.dim() == 3 and q.shape[2] == self.ndof, tuple(q.shape)
+        k, T, _ = q.shape
+        out = torch.empty((k, k, max(T - 1, 0)), dtype=torch.float32, device=q.device)
+        _hip.check(
+            _hip.lib().cppf_mjacs(
+                self._handle(q.device), q.contiguous().data_ptr(), k, T, float(prismatic_joint_scaling), out.data_ptr(),
+                _stream_ptr(q.device),
+            )
+        )
+        return out
+
     def seed_validity(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """[S,4]: per seed max position error (cm), max rotation error (deg), mjac revolute (deg), mjac prismatic (cm)."""
         x = self._x2d(x)

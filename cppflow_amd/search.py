@@ -1,9 +1,9 @@
 """Search-side consumers of the hot path (`cppflow/search.py`): the joint-limit margin mask (`:25-52`), the external cost
 `100*jlim + 1000*env + 1000*self` (`:14-15, 146-150`) and `dp_search` (`:128-191`).
 
-The mask and the cost come out of the collision kernel (one launch for all three masks and the cost).  `dp_search`
-itself is SURVEY.md 8(f) item 2 ("next"): it is kept here as the host-side torch recurrence the reference runs, working
-on the device the candidates live on instead of forcing them to the CPU (`search.py:140-141`).
+The mask and the cost come out of the collision kernel (one launch for all three masks and the cost).  `dp_search` runs on
+the device the candidates live on (`cppf_dp_search`; the reference forces them to the CPU, `search.py:140-141`) and never
+materialises the `[k,k,T-1]` mjac tensor; `_get_mjacs` still produces that tensor for callers that want it.
 """
 
 import math
@@ -68,3 +68,19 @@ def dp_search(
         )
     best_path, _, _ = robot.dp_search(q, q_costs.contiguous())
     return best_path
+
+
+def _get_mjacs(q: torch.Tensor, robot, prismatic_joint_scaling: float = 5.0) -> torch.Tensor:
+    """[k, k, T-1] maximum joint changes between every pair of candidates at consecutive timesteps
+    (cppflow/search.py:100-125)."""
+    return robot.mjacs(q, prismatic_joint_scaling)
+
+
+def dp_search_slow(problem, qpaths, use_cuda: bool = True, verbosity: int = 1) -> torch.Tensor:
+    """The reference keeps a doubly-nested Python-loop version of the dynamic programme beside the vectorised one
+    (cppflow/search.py:55-97: same costs, same first-minimal-index rule).  Both are the same recurrence, so here both
+    names run the device kernel; this entry takes the reference's arguments (a list of [T, d] paths and the problem) and
+    evaluates the masks itself."""
+    q = torch.stack(list(qpaths)).detach().contiguous()
+    cost, _, _, _ = q_costs_external(problem.robot, q, problem)
+    return dp_search(problem.robot, q, None, None, use_cuda=use_cuda, verbosity=verbosity, q_costs=cost)

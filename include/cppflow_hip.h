@@ -211,6 +211,11 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
                       int W, const cppf_full_params* params, float* work_blocks, float* work_G, float* work_y,
                       float* x_out, void* stream);
 
+/* _get_mjacs (cppflow/search.py:100-125): q [k,T,d] -> mjacs [k,k,T-1], mjacs[i,j,t] = max over joints of
+ * |wrap(s (q[i,t+1] - q[j,t]))| with s = prismatic_scaling on prismatic joints.  cppf_dp_search does not need it (it never
+ * materialises the tensor); provided for callers of the reference helper. */
+int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float prismatic_scaling, float* mjacs, void* stream);
+
 /* dp_search(robot, q, ...) of cppflow/search.py:128-191 given the external cost matrix q_costs_external [k,T]
  * (search.py:146-150, the `ext_cost` output of cppf_collision_masks / cppf_lm_pose_steps): the min-max dynamic programme
  * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,

@@ -809,3 +809,36 @@ def test_env_colliding_links_capsule(robots):
         n_hit += len(got) > 0
     assert n_hit > 0
     rb.set_obstacles([], [])
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_mjacs_and_dp_search_slow(robots, name):
+    """_get_mjacs (cppflow/search.py:100-125) against its torch definition on the same device, and the min-max recurrence
+    written with that tensor (search.py:156-159) against cppf_dp_search, which never builds it; dp_search_slow
+    (search.py:55-97) is the same recurrence and returns the same path."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.search import _get_mjacs, dp_search, dp_search_slow, q_costs_external
+
+    rb, ch = robots[name], H.chain(name)
+    rng = np.random.RandomState(4)
+    k, T, d = 23, 17, rb.ndof
+    q = dev(H.f32(rng.uniform(ch.lo, ch.hi, size=(k, T, d))))
+    got = _get_mjacs(q, rb, 5.0)
+    dqs = q[:, 1:, :].unsqueeze(1) - q[:, :-1, :].unsqueeze(0)
+    if rb.has_prismatic_joints:
+        dqs[:, :, :, rb.prismatic_joint_idxs] *= 5.0
+    want = torch.abs(torch.remainder(dqs + torch.pi, 2 * torch.pi) - torch.pi).max(dim=3).values
+    assert got.shape == (k, k, T - 1) and float((got - want).abs().max()) < 1e-6
+    target = H.f32(H.oracle64(name).fk(H.random_configs(name, T, seed=3)))
+    problem = problem_from_arrays(rb, target, [(0.2, 0.3, 0.4, 0.15, 0.15, 0.15)], device=DEV)
+    cost, _, _, _ = q_costs_external(rb, q, problem)
+    costs = torch.zeros((k, T), device=DEV)
+    costs[:, 0] = cost[:, 0]
+    for t in range(1, T):
+        costs[:, t] = torch.maximum(got[:, :, t - 1], costs[:, t - 1][None, :]).min(dim=1).values + cost[:, t]
+    _, _, table = rb.dp_search(q, cost)
+    assert torch.equal(table.T.contiguous(), costs)
+    fast = dp_search(rb, q, None, None, q_costs=cost)
+    slow = dp_search_slow(problem, [q[i] for i in range(k)], verbosity=0)
+    assert torch.equal(fast, slow)
+    rb.set_obstacles([], [])
