@@ -206,6 +206,46 @@ def resample_path(path: np.ndarray, n: int) -> np.ndarray:
     return out
 
 
+def _problem_files(problems_dir: str) -> List[str]:
+    return sorted(f[: -len(".yaml")] for f in os.listdir(problems_dir) if f.endswith(".yaml"))
+
+
+def _has_obstacles(name: str, problems_dir: str) -> bool:
+    with open(os.path.join(problems_dir, name + ".yaml"), "r") as f:
+        return len((yaml.load(f, Loader=yaml.FullLoader) or {}).get("obstacles", []) or []) > 0
+
+
+# The reference hard-codes the names of its problem files (cppflow/data_type_utils.py:24-52); here the lists are read off
+# the problems directory that ships with the package (point `problems_dir` at the reference's own directory to get its set).
+ALL_PROBLEM_FILENAMES: List[str] = _problem_files(DEFAULT_PROBLEMS_DIR)
+ALL_OBS_PROBLEM_FILENAMES: List[str] = [n for n in ALL_PROBLEM_FILENAMES if _has_obstacles(n, DEFAULT_PROBLEMS_DIR)]
+
+
+def get_problem_dict(problem_names: List[str], problems_dir: str = DEFAULT_PROBLEMS_DIR, paths_dir: str = DEFAULT_PATHS_DIR,
+                     device: Optional[str] = None) -> Dict[str, Problem]:  # fmt: skip
+    """name -> Problem (cppflow/data_type_utils.py:222-236).  Obstacle-free problems of one robot share one Robot object
+    (one device handle), which is what the reference does by hand for its Fetch problems; a problem with obstacles gets
+    its own, because obstacles are state of the robot handle."""
+    shared: Dict[str, Robot] = {}
+    out: Dict[str, Problem] = {}
+    for name in problem_names:
+        with open(os.path.join(problems_dir, name + ".yaml"), "r") as f:
+            spec = yaml.load(f, Loader=yaml.FullLoader)
+        robot = None
+        if not spec.get("obstacles"):
+            robot = shared.setdefault(spec["robot"], get_robot(spec["robot"]))
+        out[name] = problem_from_filename(None, name, robot=robot, problems_dir=problems_dir, paths_dir=paths_dir, device=device)
+    return out
+
+
+def get_all_problems(problems_dir: str = DEFAULT_PROBLEMS_DIR, paths_dir: str = DEFAULT_PATHS_DIR,
+                     device: Optional[str] = None) -> List[Problem]:  # fmt: skip
+    """Every problem of the directory, in name order (cppflow/data_type_utils.py:239-241)."""
+    names = _problem_files(problems_dir)
+    d = get_problem_dict(names, problems_dir, paths_dir, device)
+    return [d[n] for n in names]
+
+
 def plans_from_qpaths(qpaths: torch.Tensor, problem: Problem) -> List[Plan]:
     """Evaluate S joint-space paths [S,T,d] against one problem in three launches -- FK of every waypoint, the capsule
     collision masks, and the per-path `Plan` metrics (cppf_plan_metrics) -- instead of the reference's per-path host

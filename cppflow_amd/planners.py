@@ -12,7 +12,7 @@ that returns a [k,T,d] tensor (an IKFlow wrapper included) can be dropped in.
 """
 
 from time import time
-from typing import Callable, Optional, Tuple
+from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
@@ -27,6 +27,21 @@ from cppflow_amd.search import dp_search
 DEFAULT_RERUN_NEW_K = 125  # planners.py:47
 
 SeedProvider = Callable[[Problem, int], torch.Tensor]
+
+
+def add_search_path_mjac(debug_info: Dict, problem: Problem, qpath_search: torch.Tensor) -> None:
+    """Diagnostics of the searched path the reference records (cppflow/planners.py:50-73): its maximum joint changes and its
+    closest approach to a joint limit (cm for a leading prismatic joint, degrees for the rest) -- one min/max pass over
+    [T, d] on the device, one copy back."""
+    mjac_deg, mjac_cm = get_mjacs(problem.robot, qpath_search)
+    debug_info["search_path_mjac-cm"], debug_info["search_path_mjac-deg"] = mjac_cm, mjac_deg
+    limits = torch.tensor(problem.robot.actuated_joints_limits, dtype=qpath_search.dtype, device=qpath_search.device)  # [d, 2]
+    margin = torch.minimum((qpath_search - limits[:, 0]).abs().min(dim=0).values,
+                           (qpath_search - limits[:, 1]).abs().min(dim=0).values).cpu()  # fmt: skip
+    lead_prismatic = problem.robot.has_prismatic_joints  # the reference treats joint 0 as THE prismatic joint (:60)
+    debug_info["search_path_min_dist_to_jlim_cm"] = 100 * float(margin[0]) if lead_prismatic else -1
+    rest = margin[1:] if lead_prismatic else margin
+    debug_info["search_path_min_dist_to_jlim_deg"] = min(float(torch.rad2deg(rest.min())), 10000) if rest.numel() else 10000
 
 
 class LmIkSeedProvider:
@@ -60,6 +75,13 @@ class Planner:
     @property
     def robot(self):
         return self._robot
+
+    @property
+    def name(self) -> str:
+        return str(self.__class__.__name__)
+
+    def set_settings(self, settings: PlannerSettings) -> None:
+        self._cfg = settings
 
     def _run_pipeline(self, problem: Problem, **kwargs) -> Tuple[torch.Tensor, bool, TimingData, dict, tuple]:
         """Candidates -> collision masks -> dp_search (cppflow/planners.py:191-292)."""

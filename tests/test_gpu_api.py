@@ -842,3 +842,31 @@ def test_mjacs_and_dp_search_slow(robots, name):
     slow = dp_search_slow(problem, [q[i] for i in range(k)], verbosity=0)
     assert torch.equal(fast, slow)
     rb.set_obstacles([], [])
+
+
+def test_add_search_path_mjac(robots):
+    """add_search_path_mjac (cppflow/planners.py:50-73) against the same quantities computed with numpy."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.planners import add_search_path_mjac
+
+    for name in ("fetch", "panda"):
+        rb, ch = robots[name], H.chain(name)
+        rng = np.random.RandomState(2)
+        base = rng.uniform(ch.lo, ch.hi)
+        q = H.f32(np.clip(base[None] + np.cumsum(0.02 * rng.randn(30, rb.ndof), axis=0), ch.lo + 1e-3, ch.hi - 1e-3))
+        problem = problem_from_arrays(rb, H.f32(H.oracle64(name).fk(q)), device=DEV)
+        info = {}
+        add_search_path_mjac(info, problem, dev(q))
+        dq = np.diff(q, axis=0)
+        rev = [j for j in range(rb.ndof) if ch.jtype[j] == 0]
+        pris = [j for j in range(rb.ndof) if ch.jtype[j] == 1]
+        want_deg = np.rad2deg(np.abs(np.remainder(dq[:, rev] + np.pi, 2 * np.pi) - np.pi).max())
+        assert info["search_path_mjac-deg"] == pytest.approx(want_deg, rel=1e-5)
+        assert info["search_path_mjac-cm"] == pytest.approx(100 * np.abs(dq[:, pris]).max() if pris else 0.0, rel=1e-5)
+        margin = np.minimum(np.abs(q - ch.lo).min(0), np.abs(q - ch.hi).min(0))
+        if pris:
+            assert info["search_path_min_dist_to_jlim_cm"] == pytest.approx(100 * margin[0], rel=1e-4)
+            assert info["search_path_min_dist_to_jlim_deg"] == pytest.approx(np.rad2deg(margin[1:].min()), rel=1e-4)
+        else:
+            assert info["search_path_min_dist_to_jlim_cm"] == -1
+            assert info["search_path_min_dist_to_jlim_deg"] == pytest.approx(np.rad2deg(margin.min()), rel=1e-4)

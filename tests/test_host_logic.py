@@ -121,6 +121,24 @@ def test_problem_loader_formats():
         Problem(p.constraints, bad, None, p.robot, "x", "x")
 
 
+def test_problem_listing():
+    """ALL_PROBLEM_FILENAMES / get_problem_dict / get_all_problems (cppflow/data_type_utils.py:24-52, 222-241) over the
+    shipped problems directory and, when it is mounted, over the reference's own (every one of its problem files parses)."""
+    from cppflow_amd import data_type_utils as U
+
+    assert U.ALL_PROBLEM_FILENAMES == ["fetch__line", "panda__line"] and set(U.ALL_OBS_PROBLEM_FILENAMES) <= set(U.ALL_PROBLEM_FILENAMES)
+    problems = U.get_all_problems(device="cpu")
+    assert [p.full_name for p in problems] == U.ALL_PROBLEM_FILENAMES and all(p.target_path.shape[1] == 7 for p in problems)
+    ref = "/root/reference/cppflow"
+    if os.path.isdir(os.path.join(ref, "problems")):
+        theirs = U.get_all_problems(os.path.join(ref, "problems"), os.path.join(ref, "paths"), device="cpu")
+        names = {p.full_name for p in theirs}
+        assert {"panda__2cubes", "panda__1cube", "fetch__hello", "fetch_arm__s"} <= names
+        by = {p.full_name: p for p in theirs}
+        assert by["fetch__hello"].robot is by["fetch__circle"].robot or len(by["fetch__circle"].obstacles) > 0
+        assert len(by["panda__2cubes"].obstacles) == 2
+
+
 def test_offset_and_resample():
     rb = get_robot("panda")
     path = np.array([[0, 0, 0, 1, 0, 0, 0], [0.1, 0, 0, 1, 0, 0, 0], [0.3, 0, 0, 0, 1, 0, 0.0]])
