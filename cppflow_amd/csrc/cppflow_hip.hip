@@ -337,13 +337,15 @@ __device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co
 }
 
 // Robot-specialised variant: capsule ids, link ids and the pair list are compile-time, so the end points live in VGPRs
-// (static indices after unrolling) and no LDS is touched.  Same canonical operation order as the LDS variant.
-template <class RB, bool WANT_MIN>
-__device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co, const float (&q)[RB::D], float (&R)[9],
-                                                  float (&p)[3], bool do_self, bool do_env) {
+// (static indices after unrolling) and no LDS is touched.  Same canonical operation order as the LDS variant.  Two phases so
+// that a caller can retire everything else it holds (target pose, q, the frame) between them: the pair / cuboid tests then
+// run with the capsule end points as the only long-lived registers, which keeps the fused kernel at <= 128 VGPRs, i.e. all
+// four wavefronts per SIMD of a 262 144-row launch resident at once (no half-empty second round).
+template <class RB>
+__device__ __forceinline__ void capsule_fk_static(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
+                                                  float (&w0)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                  float (&w1)[(RB::Table::L > 0 ? RB::Table::L : 1)][3]) {
     using T = typename RB::Table;
-    constexpr int L = T::L > 0 ? T::L : 1;
-    float w0[L][3], w1[L][3];
     frame_identity(R, p);
 #pragma unroll
     for (int c = 0; c < T::L; ++c) {
@@ -367,15 +369,22 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
             }
         }
     }
-    // Broad phase of the mask-only launches (see cull_far): capsule mid points, then one bounding-sphere test per pair /
-    // per (capsule, cuboid); the exact distance is evaluated only when some lane of the wavefront is within reach.
-    float mid[L][3];
-    if constexpr (!WANT_MIN) {
+}
+
+__device__ __forceinline__ void capsule_mid(const float (&a0)[3], const float (&a1)[3], float (&m)[3]) {
 #pragma unroll
-        for (int c = 0; c < T::L; ++c)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) mid[c][k] = 0.5f * (w0[c][k] + w1[c][k]);
-    }
+    for (int k = 0; k < 3; ++k) m[k] = 0.5f * (a0[k] + a1[k]);
+}
+
+template <class RB, bool WANT_MIN>
+__device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
+                                                        const float (&w0)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                        const float (&w1)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                        bool do_self, bool do_env) {
+    using T = typename RB::Table;
+    // Broad phase of the mask-only launches (see cull_far): one bounding-sphere test per pair / per (capsule, cuboid) on
+    // the capsule mid points (recomputed per test: 6 adds are cheaper than 27 more live registers); the exact distance is
+    // evaluated only when some lane of the wavefront is within reach.
     CollOut r;
     r.min_self = INFINITY;
     r.self_hit = 0;
@@ -384,7 +393,10 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
         for (int pi = 0; pi < T::P; ++pi) {
             const int a = T::pair_a[pi], b = T::pair_b[pi];
             if constexpr (!WANT_MIN) {
-                if (cull_far(mid_dist2(mid[a], mid[b]), T::pair_cull[pi])) continue;
+                float ma[3], mb[3];
+                capsule_mid(w0[a], w1[a], ma);
+                capsule_mid(w0[b], w1[b], mb);
+                if (cull_far(mid_dist2(ma, mb), T::pair_cull[pi])) continue;
             }
             const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
             if constexpr (WANT_MIN) {
@@ -404,7 +416,9 @@ __device__ __forceinline__ CollOut collide_static(const RB& rb, const CollK& co,
 #pragma unroll
             for (int c = 0; c < T::L; ++c) {
                 if constexpr (!WANT_MIN) {
-                    if (cull_far(point_box_dist2(mid[c], co.obs_lo[o], co.obs_hi[o]), T::cap_cull[c])) continue;
+                    float m[3];
+                    capsule_mid(w0[c], w1[c], m);
+                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), T::cap_cull[c])) continue;
                 }
                 const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
@@ -498,7 +512,10 @@ template <class RB, bool WANT_MIN>
 __device__ __forceinline__ CollOut collide_row(const RB& rb, const CollK& co, const float (&q)[RB::D], float* lds, int tid,
                                                float (&R)[9], float (&p)[3], bool do_self, bool do_env) {
     if constexpr (RB::kStatic) {
-        return collide_static<RB, WANT_MIN>(rb, co, q, R, p, do_self, do_env);
+        constexpr int L = RB::Table::L > 0 ? RB::Table::L : 1;
+        float w0[L][3], w1[L][3];
+        capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+        return collide_tests_static<RB, WANT_MIN>(co, w0, w1, do_self, do_env);
     } else {
         fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
         return collide_from_lds<WANT_MIN>(co, lds, tid, do_self, do_env);
@@ -665,17 +682,37 @@ __device__ __forceinline__ void lm_fused_row(const RB& rb, const CollK& co, cons
 
     const bool want_metrics = out.pos_err_m || out.rot_err_rad || out.seed_summary;
     if constexpr (COLL != 0) {
-        float R[9], p[3];
         const bool do_self = out.self_mask || out.min_self || out.ext_cost || out.seed_summary;
         const bool do_env = out.env_mask || out.min_env || out.ext_cost || out.seed_summary;
-        const CollOut c = collide_row<RB, COLL == 2>(rb, co, q, lds, tid, R, p, do_self, do_env);
-        if (want_metrics) {
-            fk_fixed_ee(rb, R, p);
-            pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
-            if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
-            if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
-        }
         rs.jl = jlim_hit<D>(co, q);
+        // capsule FK first, then the pose metrics off its last-link frame (after which the target pose and the frame are
+        // dead), then the pair / cuboid tests
+        CollOut c;
+        auto metrics = [&](float (&R)[9], float (&p)[3]) {
+            if (want_metrics) {
+                fk_fixed_ee(rb, R, p);
+                pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
+                if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
+                if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
+            }
+        };
+        if constexpr (RB::kStatic) {
+            constexpr int L = RB::Table::L > 0 ? RB::Table::L : 1;
+            float w0[L][3], w1[L][3];
+            {
+                float R[9], p[3];
+                capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+                metrics(R, p);
+            }
+            c = collide_tests_static<RB, COLL == 2>(co, w0, w1, do_self, do_env);
+        } else {
+            {
+                float R[9], p[3];
+                fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
+                metrics(R, p);
+            }
+            c = collide_from_lds<COLL == 2>(co, lds, tid, do_self, do_env);
+        }
         rs.self_hit = c.self_hit, rs.env_hit = c.env_hit;
         rs.cost = 100.f * (float)rs.jl + 1000.f * (float)c.env_hit + 1000.f * (float)c.self_hit;
         write_coll_outputs(row, c, rs.jl, out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost, out.min_self,
