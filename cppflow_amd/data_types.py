@@ -2,6 +2,7 @@
 `PlannerSettings` (`:65-83`), `TimingData` (`:27-50`), `Problem` (`:377-484`), and `Plan` / `PlanNp` (`:86-366`) whose scalar
 metrics come from one device reduction for all candidate paths (`cppf_plan_metrics`)."""
 
+import math
 from dataclasses import dataclass, field
 from time import time
 from typing import List, Optional, Tuple
@@ -322,6 +323,21 @@ class Problem:
     def path_length_cumultive_positional_change_cm(self) -> float:
         p = self.target_path[:, 0:3]
         return float(torch.norm(p[1:] - p[:-1], dim=1).sum()) * 100.0
+
+    @property
+    def path_length_cumulative_rotational_change_deg(self) -> float:
+        """Summed geodesic angle between consecutive target orientations, in degrees (cppflow/data_types.py:403-420).  The
+        distance formula clamps its arc-cosine argument to 1 - 1e-7, which reports 2 acos(1 - 1e-7) ~ 1e-3 rad for
+        identical orientations; as in the reference that floor is subtracted once per such pair."""
+        from cppflow_amd.evaluation_utils import rotational_errors
+
+        eps = 1e-7
+        a, b = self.target_path[:-1], self.target_path[1:]
+        dot = (a[:, 3:7] * b[:, 3:7]).sum(dim=1)
+        n_identical = int(((dot > 1 - eps) | (dot < -1 + eps)).sum())
+        # in the path's own dtype: fp32 rounds 1 - 1e-7 to 1 - 2^-23, which makes the floor 9.8e-4 rather than 8.9e-4 rad
+        floor_rad = float(2.0 * torch.acos(torch.tensor([1.0 - eps], dtype=self.target_path.dtype)))
+        return math.degrees(float(rotational_errors(a, b).abs().sum()) - floor_rad * n_identical)
 
     def __post_init__(self):
         # unit-quaternion sanity check of cppflow/data_types.py:430-433

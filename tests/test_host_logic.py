@@ -323,3 +323,18 @@ def test_pose_path_error_helpers():
     r = rotational_errors(a, b)
     assert abs(float(r[1]) - math.pi / 2) < 1e-5 and float(r[0]) < 1e-3
     assert abs(float(rotational_errors(a[1:], -b[1:])[0]) - math.pi / 2) < 1e-5  # q and -q are the same rotation
+
+
+def test_target_path_length_known_answers():
+    """tests/problem_test.py:27-60 of the reference: a stationary path has zero length; 0.1 m + 0 + 0.1 m of translation is
+    20 cm; rotations of 5, 15 and 50 degrees about z add up to 5 + 10 + 35 = 50 degrees (4 places)."""
+    def problem(path):
+        return Problem(DEFAULT_CONSTRAINTS, torch.tensor(path, dtype=torch.float32), None, get_robot("panda"), "kat", "kat")
+
+    still = problem([[0, 0, 0, 1.0, 0, 0, 0]] * 4)
+    assert still.path_length_cumultive_positional_change_cm == pytest.approx(0.0, abs=1e-7)
+    assert still.path_length_cumulative_rotational_change_deg == pytest.approx(0.0, abs=1e-4)
+    moving = problem([[0, 0, 0, 1.0, 0, 0, 0], [0.1, 0, 0, 0.9990482, 0, 0, 0.0436194],
+                      [0.1, 0, 0, 0.9914449, 0, 0, 0.1305262], [0.2, 0, 0, 0.9063078, 0, 0, 0.4226183]])  # fmt: skip
+    assert moving.path_length_cumultive_positional_change_cm == pytest.approx(20.0, abs=1e-5)
+    assert moving.path_length_cumulative_rotational_change_deg == pytest.approx(50.0, abs=5e-4)
