@@ -870,3 +870,25 @@ def test_add_search_path_mjac(robots):
         else:
             assert info["search_path_min_dist_to_jlim_cm"] == -1
             assert info["search_path_min_dist_to_jlim_deg"] == pytest.approx(np.rad2deg(margin.min()), rel=1e-4)
+
+
+def test_search_avoids_joint_limits(robots):
+    """tests/search_test.py:59-78 of the reference (fetch_arm__s__truncated, k = 20 candidates through PlannerSearcher): the
+    path dp_search returns stays more than 1 degree away from every joint limit, because candidates inside the 1.5 degree
+    padding cost 100 (cppflow/search.py:14-21); and its cost is minimal among the candidates' own paths."""
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.data_types import PlannerSettings
+    from cppflow_amd.planners import LmIkSeedProvider, PlannerSearcher
+
+    rb = robots["fetch_arm"]
+    z = np.load(os.path.join(GOLDEN, "reference_paths.npz"))
+    problem = problem_from_arrays(rb, z["fetch_arm__s__truncated"], device=DEV)
+    searcher = PlannerSearcher(PlannerSettings(k=20, tmax_sec=30.0, anytime_mode_enabled=False, verbosity=0), rb,
+                               LmIkSeedProvider(seed=3))  # fmt: skip
+    plan = searcher.generate_plan(problem).plan
+    eps = np.deg2rad(1.0)
+    q = plan.q_path
+    for j, (l, u) in enumerate(rb.actuated_joints_limits):
+        assert not bool((q[:, j] < l + eps).any()) and not bool((q[:, j] > u - eps).any()), j
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
