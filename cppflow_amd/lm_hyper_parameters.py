@@ -1,8 +1,8 @@
 """Optimizer parameter record and the two presets of the reference (`cppflow/lm_hyper_parameters.py:14-151`).
 
-Only `ALT_LOSS_V2_1_POSE` (lambda = 1e-6, alpha_position = 3.5, alpha_rotation = 0.35) feeds this build's kernels; the
-differencing preset is carried so that `run_lm_optimization` keeps the reference's signature.  The record type is built
-from a field table: the names are the reference's (they are the API), every field is required, positional order as there.
+`ALT_LOSS_V2_1_POSE` (lambda = 1e-6, alpha_position = 3.5, alpha_rotation = 0.35) parameterises the fused pose-only launches
+(`cppf_lm_pose_steps`), `ALT_LOSS_V2_1_DIFF` the coupled step (`cppf_lm_full_step`).  The record type is built from a field
+table: the names are the reference's (they are the API), every field is required, positional order as there.
 """
 
 import warnings

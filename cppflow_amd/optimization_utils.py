@@ -107,6 +107,32 @@ class LmResidualFns:
         return J
 
     @staticmethod
+    def _scale_down_rows_from_r_J_pose_below_error(r: torch.Tensor, J: torch.Tensor, error_threshold_m: float,
+                                                   error_threshold_rad: float, scale: float,
+                                                   shift_invalid_to_threshold: bool = False):  # fmt: skip
+        """Down-weight the pose rows that already satisfy their threshold (cppflow/optimization_utils.py:287-330; pinned by
+        the known answer of tests/optimization_utils_test.py:405-456).  r [6n,1] and J are modified in place; returns
+        (r, J, rows that were NOT down-weighted).  Off in both presets: the device step does not apply it."""
+        assert r.shape[0] == J.shape[0] and r.shape[0] % 6 == 0 and r.numel() == r.shape[0] and 0.0 <= scale < 1.0
+        rot_rows, _ = _get_rotation_and_position_row_mask(r.shape[0] // 6)
+        thr = torch.where(rot_rows.to(r.device), error_threshold_rad, error_threshold_m).to(r.dtype)
+        return _down_weight_rows(r, J, thr, scale, shift_invalid_to_threshold)
+
+    @staticmethod
+    def _scale_down_rows_from_r_J_differencing_below_error(robot, r: torch.Tensor, J: torch.Tensor, mjac_threshold_m: float,
+                                                           mjac_threshold_rad: float, scale: float,
+                                                           shift_invalid_to_threshold: bool = False):  # fmt: skip
+        """The same for the differencing rows, thresholds by joint type (cppflow/optimization_utils.py:351-396; known answers
+        tests/optimization_utils_test.py:122-342).  Returns (J, r, rows not down-weighted) -- J first, as the reference."""
+        d = robot.ndof
+        n = r.shape[0] // d + 1
+        assert r.shape == ((n - 1) * d, 1) and J.shape == ((n - 1) * d, n * d) and 0.0 <= scale < 1.0
+        _, pris_rows = _get_prismatic_and_revolute_row_mask(robot, r.shape[0])
+        thr = torch.where(pris_rows.to(r.device), mjac_threshold_m, mjac_threshold_rad).to(r.dtype)
+        r, J, kept = _down_weight_rows(r, J, thr, scale, shift_invalid_to_threshold)
+        return J, r, kept
+
+    @staticmethod
     def _get_residual_differencing(robot, x: torch.Tensor) -> torch.Tensor:
         return angular_changes(x).reshape((x.shape[0] - 1) * robot.ndof, 1)
 
@@ -164,6 +190,9 @@ class LmResidualFns:
     @staticmethod
     def get_r_and_J(pms, robot, x: torch.Tensor, target_path: torch.Tensor, Tcuboids: Optional[List] = None,
                     cuboids: Optional[List] = None) -> Tuple[LmJacobian, LmResidual]:  # fmt: skip
+        # The three "satisfied" options are off in both presets; in the reference they read `pms.constraints`, a field
+        # OptimizationParameters does not have (optimization_utils.py:514-519, 562-567), so that path cannot run there either.
+        # The row operations themselves are provided above and pinned by the reference's known answers.
         assert not pms.pose_do_scale_down_satisfied and not pms.differencing_do_ignore_satisfied, "option not implemented"
         assert not pms.differencing_do_scale_satisfied, "option not implemented"
         n, d = x.shape
@@ -203,6 +232,31 @@ class LmResidualFns:
                 residual.env_collisions, jacobian.env_collisions = torch.cat(rs, dim=0), torch.cat(Js, dim=0)
         jacobian.verify_r(residual)
         return jacobian, residual
+
+
+def _down_weight_rows(r: torch.Tensor, J: torch.Tensor, thr: torch.Tensor, scale: float, shift: bool):
+    """Rows with |r| < thr are multiplied by `scale` (r and J, in place); optionally the others are moved towards zero by
+    thr.  Returns (r, J, mask of the rows left at full weight)."""
+    below = r[:, 0].abs() < thr
+    r[below] *= scale
+    J[below] *= scale
+    if shift:
+        beyond = r[:, 0].abs() > thr  # the scaled rows cannot qualify: |scale * r| < thr
+        r[beyond, 0] -= torch.sign(r[beyond, 0]) * thr[beyond]
+    return r, J, torch.logical_not(below)
+
+
+def filter_rows_from_r_J_differencing(robot, r: torch.Tensor, J: torch.Tensor, threshold_rad: float, threshold_m: float,
+                                      shift_to_threshold: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:  # fmt: skip
+    """Keep only the differencing rows whose joint change exceeds its threshold, optionally measured from the threshold
+    (cppflow/optimization_utils.py:736-768; known answers tests/optimization_utils_test.py:458-588)."""
+    assert r.shape[0] == J.shape[0] and r.shape[0] % robot.ndof == 0
+    _, pris_rows = _get_prismatic_and_revolute_row_mask(robot, r.shape[0])
+    thr = torch.where(pris_rows.to(r.device), threshold_m, threshold_rad).to(r.dtype)
+    keep = r[:, 0].abs() > thr
+    if shift_to_threshold:
+        r[keep, 0] -= torch.sign(r[keep, 0]) * thr[keep]
+    return r[keep, :], J[keep, :]
 
 
 def get_6d_pose_errors(robot, x: torch.Tensor, target_poses: torch.Tensor):

@@ -371,3 +371,52 @@ def test_plan_metrics_oracle_equals_the_reference_property_formulas(name):
     assert abs(np.abs(np.remainder((-3.1 - 3.1) + np.pi, 2 * np.pi) - np.pi) - (2 * np.pi - 6.2)) < 1e-12
     assert got[0, 6] < 0.05 * 3 * W * d  # the +-pi crossing did not add 6.2 rad to the path length
     assert got[:, 8].sum() > 0 and np.all(got[:, 12:] == 0)
+
+
+def test_row_downweight_and_filter_kats():
+    """Known answers of the reference for its three residual-row operations (pure tensor functions, no robot model values):
+    tests/optimization_utils_test.py:122-213 (differencing scale-down, Fetch: row 0 of every config is the prismatic joint),
+    :215-305 (the same with shift), :405-456 (pose scale-down), :458-588 (filter, Panda and Fetch)."""
+    import torch
+
+    from cppflow_amd.optimization_utils import LmResidualFns, filter_rows_from_r_J_differencing
+    from cppflow_amd.robots import get_robot
+
+    fetch, panda = get_robot("fetch"), get_robot("panda")
+    col = lambda v: torch.tensor(v, dtype=torch.float32).reshape(-1, 1)  # noqa: E731
+    r_in = [0.5, 0.1, 1.6, 0.1, 0.1, 0.1, 0.1, 0.1, -0.4, 1.7, -1.7, 0.1, 0.1, 0.1, 0.1, 0.1, 0.2, 0.01, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]
+    full_weight = [0, 2, 8, 9, 10]  # |0.5|, |-0.4| >= 0.25 m (prismatic rows 0, 8); |1.6|, |1.7|, |-1.7| >= 1.5 rad
+    J_expected = 0.5 * torch.ones((24, 32))
+    J_expected[full_weight] = 1.0
+    for shift, moved in ((False, {}), (True, {0: 0.25, 2: 0.1, 8: -0.15, 9: 0.2, 10: -0.2})):
+        r_expected = [moved.get(i, v if i in full_weight else v / 2) for i, v in enumerate(r_in)]
+        J, r, kept = LmResidualFns._scale_down_rows_from_r_J_differencing_below_error(
+            robot=fetch, r=col(r_in), J=torch.ones((24, 32)), mjac_threshold_m=0.25, mjac_threshold_rad=1.5, scale=0.5,
+            shift_invalid_to_threshold=shift)  # fmt: skip
+        torch.testing.assert_close(r, col(r_expected))
+        torch.testing.assert_close(J, J_expected)
+        assert kept.nonzero().reshape(-1).tolist() == full_weight
+    J, r, kept = LmResidualFns._scale_down_rows_from_r_J_differencing_below_error(
+        robot=panda, r=col([0.5, 0.1, 1.6, 0.1, 0.1, 0.1, 0.1]), J=torch.ones((7, 14)), mjac_threshold_m=0.25,
+        mjac_threshold_rad=1.5, scale=0.5)  # fmt: skip
+    assert kept.tolist() == [False, False, True, False, False, False, False]  # all revolute: only 1.6 rad is over
+    # pose rows [roll pitch yaw x y z] x 4 configs; thresholds 0.125 m / 1e-8 rad, scale 0.3
+    r_gt = [0, 0, 0, 0, 0, -0.1, 0, 0, 0, 0, 0, 0.15, 0, 0, 0, 0, 0, 0, 0.000807, -0.002434, 0.000551, 0.000002, 0.000606, 0.001627]
+    want = [0, 0, 0, 0, 0, -0.03, 0, 0, 0, 0, 0, 0.15, 0, 0, 0, 0, 0, 0, 0.000807, -0.002434, 0.000551, 0.000002 * 0.3,
+            0.000606 * 0.3, 0.001627 * 0.3]  # fmt: skip
+    r, _, _ = LmResidualFns._scale_down_rows_from_r_J_pose_below_error(col(r_gt), torch.zeros((24, 32)), 0.125, 1e-8, 0.3)
+    torch.testing.assert_close(r, col(want))
+    # filter: thresholds 0.1 rad / 0.5 m, measured from the threshold
+    z7 = [0.0] * 7
+    r, _ = filter_rows_from_r_J_differencing(panda, col(z7 + z7), torch.zeros((14, 14)), 0.1, 0.5, shift_to_threshold=True)
+    assert r.shape == (0, 1)
+    r, _ = filter_rows_from_r_J_differencing(panda, col([0.15, -0.15, 0, 0, 0, 0, 0.5] + [0.0] * 6 + [1.5]),
+                                             torch.zeros((14, 14)), 0.1, 0.5, shift_to_threshold=True)  # fmt: skip
+    torch.testing.assert_close(r, col([0.05, -0.05, 0.4, 1.4]))
+    r, _ = filter_rows_from_r_J_differencing(fetch, col([0.4, 0.05, -0.05] + [0.0] * 5 + [-0.1] + [0.0] * 7),
+                                             torch.zeros((16, 16)), 0.1, 0.5, shift_to_threshold=True)  # fmt: skip
+    assert r.shape == (0, 1)
+    r, J = filter_rows_from_r_J_differencing(fetch, col([0.6, 0.25, -0.25] + [0.0] * 5 + [-0.7] + [0.0] * 7),
+                                             torch.zeros((16, 16)), 0.1, 0.5, shift_to_threshold=True)  # fmt: skip
+    torch.testing.assert_close(r, col([0.1, 0.15, -0.15, -0.2]))
+    assert J.shape == (4, 16)
