@@ -2122,11 +2122,32 @@ int check_launch(const cppf_robot* rb) {
     return CPPF_OK;
 }
 
-int enter(const cppf_robot* rb) {
-    CPPF_REQUIRE(rb != nullptr, "robot handle is NULL");
-    CPPF_HIP(hipSetDevice(rb->device));
-    return CPPF_OK;
-}
+// Launches go to the robot's device; the calling thread's current device is put back on return (a caller -- torch included --
+// that had another device current must not find it changed behind its back).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define CPPF_ENTER(rb)                                                                                              \
+    CPPF_REQUIRE((rb) != nullptr, "robot handle is NULL");                                                          \
+    DeviceGuard device_guard__((rb)->device);                                                                        \
+    if (device_guard__.err != hipSuccess)                                                                            \
+        return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the robot's device failed: ") +               \
+                                      hipGetErrorString(device_guard__.err))
 
 }  // namespace
 
@@ -2262,7 +2283,7 @@ int cppf_set_joint_limit_padding(cppf_robot* robot, const float* lo_padded, cons
 }
 
 int cppf_forward_kinematics(const cppf_robot* robot, const float* x, int n, float* poses, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return CPPF_OK;
     CPPF_REQUIRE(x && poses, "x / poses is NULL");
@@ -2273,7 +2294,7 @@ int cppf_forward_kinematics(const cppf_robot* robot, const float* x, int n, floa
 }
 
 int cppf_jacobian(const cppf_robot* robot, const float* x, int n, float* J, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return CPPF_OK;
     CPPF_REQUIRE(x && J, "x / J is NULL");
@@ -2285,7 +2306,7 @@ int cppf_jacobian(const cppf_robot* robot, const float* x, int n, float* J, void
 
 int cppf_pose_errors(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* e,
                      float* current_poses, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
     const size_t n = (size_t)S * W;
     if (n == 0) return CPPF_OK;
@@ -2298,7 +2319,7 @@ int cppf_pose_errors(const cppf_robot* robot, const float* x, const float* targe
 }
 
 int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return CPPF_OK;
     CPPF_REQUIRE(x, "x is NULL");
@@ -2309,7 +2330,7 @@ int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* s
 
 int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
                        const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(params && out, "params / out is NULL");
     CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
     CPPF_REQUIRE(params->n_steps >= 1, "n_steps must be >= 1");
@@ -2370,7 +2391,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
 
 int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,
                          uint8_t* jlim_mask, float* ext_cost, float* min_self, float* min_env, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
     const size_t n = (size_t)S * W;
     if (n == 0) return CPPF_OK;
@@ -2395,7 +2416,7 @@ int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, 
 }
 
 int cppf_self_collision_distances(const cppf_robot* robot, const float* x, int n, float* dists, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     if (n == 0 || robot->coll.npairs == 0) return CPPF_OK;
     CPPF_REQUIRE(x && dists, "x / dists is NULL");
@@ -2408,7 +2429,7 @@ int cppf_self_collision_distances(const cppf_robot* robot, const float* x, int n
 
 int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n, const float* cuboid, const float* Rt,
                                  float* dists, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     CPPF_REQUIRE(cuboid && Rt, "cuboid / Rt is NULL");
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -2431,7 +2452,7 @@ int cppf_env_collision_distances(const cppf_robot* robot, const float* x, int n,
 
 int cppf_self_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, float* jac, float* dists,
                                            void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     if (n == 0 || robot->coll.npairs == 0) return CPPF_OK;
     CPPF_REQUIRE(x && jac, "x / jac is NULL");
@@ -2445,7 +2466,7 @@ int cppf_self_collision_distances_jacobian(const cppf_robot* robot, const float*
 
 int cppf_env_collision_distances_jacobian(const cppf_robot* robot, const float* x, int n, const float* cuboid,
                                           const float* Rt, float* jac, float* dists, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(n >= 0, "n < 0");
     CPPF_REQUIRE(cuboid && Rt, "cuboid / Rt is NULL");
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -2468,7 +2489,7 @@ int cppf_env_collision_distances_jacobian(const cppf_robot* robot, const float* 
 
 int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* pos_err_m,
                             float* rot_err_rad, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
     const size_t n = (size_t)S * W;
     if (n == 0) return CPPF_OK;
@@ -2483,7 +2504,7 @@ int cppf_pose_error_metrics(const cppf_robot* robot, const float* x, const float
 
 int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* target, int S, int W, float* out,
                        void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
     if (S == 0) return CPPF_OK;
     CPPF_REQUIRE(x && target && out, "x / target / out is NULL");
@@ -2496,7 +2517,7 @@ int cppf_seed_validity(const cppf_robot* robot, const float* x, const float* tar
 int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, const float* ext_cost, const float* pos_err_m,
                       const float* rot_err_rad, const uint8_t* self_mask, const uint8_t* env_mask,
                       const uint8_t* jlim_mask, float* out, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
     if (S == 0) return CPPF_OK;
     CPPF_REQUIRE(x && ext_cost && pos_err_m && rot_err_rad && self_mask && env_mask && jlim_mask && out, "NULL pointer");
@@ -2509,7 +2530,7 @@ int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, con
 
 int cppf_plan_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, const uint8_t* self_mask,
                       const uint8_t* env_mask, const float* q_init, float* out, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
     if (S == 0) return CPPF_OK;
     CPPF_REQUIRE((size_t)S * W <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
@@ -2524,7 +2545,7 @@ int cppf_plan_metrics(const cppf_robot* robot, const float* x, const float* targ
 int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* target, const float* virtual_configs, int S,
                       int W, const cppf_full_params* params, float* work_blocks, float* work_G, float* work_y,
                       float* x_out, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(params, "params is NULL");
     CPPF_REQUIRE(S >= 0 && W >= 1, "S < 0 or W < 1");
     CPPF_REQUIRE(params->lm_lambda > 0.f, "lm_lambda must be > 0");
@@ -2597,7 +2618,7 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
 }
 
 int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float prismatic_scaling, float* mjacs, void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(k >= 1 && T >= 1, "k, T must be >= 1");
     if (T == 1) return CPPF_OK;
     CPPF_REQUIRE(q && mjacs, "q / mjacs is NULL");
@@ -2613,7 +2634,7 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
                    void* stream) {
-    if (int rc = enter(robot)) return rc;
+    CPPF_ENTER(robot);
     CPPF_REQUIRE(k >= 1 && T >= 1, "k, T must be >= 1");
     CPPF_REQUIRE(q && ext_cost && work_qT && work_costsT && work_memoT && best_path && best_idx, "NULL pointer");
     CPPF_REQUIRE((size_t)k * T * robot->desc.ndof <= 0x7fffffffu, "k*T*d exceeds 2^31-1");
