@@ -45,17 +45,25 @@ def main():
     write = counter("pmc_write/pmc_counter_collection.csv", "WRITE_SIZE", grid)
     for key, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         summary[key] = {"dispatches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
-    # scripts/pmc_probe.py: variants A..D, three rounds; keep the last round
-    sq = {}
-    for r in read_csv("pmc_valu/pmc_counter_collection.csv"):
-        if "cppf" in r["Kernel_Name"]:
-            e = sq.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"][:100],
-                                                      "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})  # fmt: skip
-            e[r["Counter_Name"]] = float(r["Counter_Value"])
-    disp = [sq[k] for k in sorted(sq)][-4:]
-    for d, label in zip(disp, ("A: K=10, no collision", "B: K=20, no collision", "C: K=10 + collision (bench launch, no summary)",
-                               "D: collision_masks alone")):  # fmt: skip
-        d["variant"] = label + " -- scripts/pmc_probe.py, random inputs"
+    # scripts/pmc_probe.py: variants A..E, three rounds; keep the last round.  Two counter passes over the same script.
+    labels = ("A: K=10, no collision (random inputs)", "B: K=20, no collision (random inputs)",
+              "C: K=10 + collision (random inputs, no summary)", "D: collision_masks alone (random inputs)",
+              "E: the bench launch: K=10 + collision + per-seed summary, problem inputs")  # fmt: skip
+    disp = [{"variant": lab} for lab in labels]
+    for rel in ("pmc_valu/pmc_counter_collection.csv", "pmc_valu2/pmc_counter_collection.csv"):
+        if not os.path.exists(os.path.join(REC, rel)):
+            continue
+        sq = {}
+        for r in read_csv(rel):
+            if "cppf" in r["Kernel_Name"] and int(r["Grid_Size"]) == 1024 * 256:
+                e = sq.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"][:100],
+                                                          "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})  # fmt: skip
+                e[r["Counter_Name"]] = float(r["Counter_Value"])
+        last = [sq[k] for k in sorted(sq)][-len(labels):]
+        for d, e in zip(disp, last):
+            for k, v in e.items():
+                d[k if k not in ("dur_ns",) or k not in d else "dur_ns_pass2"] = v
+    for d in disp:
         d["valu_per_row"] = d["SQ_INSTS_VALU"] * 64 / (1024 * 256) if "SQ_INSTS_VALU" in d else None
     summary["sq_counters_scripts_pmc_probe_last_round"] = disp
     with open(os.path.join(OUT, f"{TAG}_pmc_summary.json"), "w") as f:
