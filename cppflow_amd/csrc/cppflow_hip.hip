@@ -1275,6 +1275,12 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
             float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
             lds_capsule(lds, tid, a, a0, a1);
             lds_capsule(lds, tid, b, b0, b1);
+            {  // broad phase (cull_far): only pairs that penetrate contribute rows, and a far pair cannot penetrate
+                float ma[3], mb[3];
+                capsule_mid(a0, a1, ma);
+                capsule_mid(b0, b1, mb);
+                if (cull_far(mid_dist2(ma, mb), co.pair_cull[pi])) continue;
+            }
             const float sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
             const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
             if (dist < 0.f) {
@@ -1297,6 +1303,11 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
             for (int c = 0; c < co.ncaps; ++c) {
                 float w0[3], w1[3], cs[3], cb[3];
                 lds_capsule(lds, tid, c, w0, w1);
+                {
+                    float m[3];
+                    capsule_mid(w0, w1, m);
+                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), co.cap_cull[c])) continue;
+                }
                 const float sd = seg_box_closest(w0, w1, co.obs_lo[o], co.obs_hi[o], cs, cb);
                 const float dist = sd - co.cap_r[c];
                 if (dist < 0.f) {
@@ -1681,8 +1692,32 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
             }
     };
 
+    // D_t^-1 is needed by both neighbours of t: every lane inverts its own block once per level and shares it through LDS
+    __shared__ float s_P[BS][NT + 1];  // +1: odd row stride, no bank conflicts on the strided neighbour reads
+    auto load_inv = [&](int u, float (&M)[D][D]) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+                const float v = s_P[u][k++];
+                M[i][j] = v;
+                M[j][i] = v;
+            }
+    };
     for (int st = 1; st < T; st <<= 1) {
         float nD[D][D], ny[D], nL[D][D];
+        if (act) {
+            float Dn[D][D], P[D][D];
+            load_sym(blocks + (base + t) * SB, Dn);
+            spd_inverse<D>(Dn, prm.lm_lambda, P);
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) s_P[t][k++] = P[i][j];
+        }
+        __syncthreads();
         if (act) {
             const float* own = blocks + (base + t) * SB;
             load_sym(own, nD);
@@ -1694,10 +1729,9 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
                 for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
             const int tm = t - st, tp = t + st;
             if (tm >= 0) {
-                float Dn[D][D], P[D][D], Lt[D][D], Lm[D][D], ym[D];
+                float P[D][D], Lt[D][D], Lm[D][D], ym[D];
                 const float* nb = blocks + (base + tm) * SB;
-                load_sym(nb, Dn);
-                spd_inverse<D>(Dn, prm.lm_lambda, P);
+                load_inv(tm, P);
 #pragma unroll
                 for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -1735,10 +1769,9 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
                 }
             }
             if (tp < T) {
-                float Dn[D][D], P[D][D], Lp[D][D], yp[D];
+                float P[D][D], Lp[D][D], yp[D];
                 const float* nb = blocks + (base + tp) * SB;
-                load_sym(nb, Dn);
-                spd_inverse<D>(Dn, prm.lm_lambda, P);
+                load_inv(tp, P);
 #pragma unroll
                 for (int i = 0; i < D; ++i)
 #pragma unroll
