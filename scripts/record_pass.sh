@@ -25,11 +25,11 @@ echo "== kbench"
 timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
 echo "== rocprofv3 pmc FETCH_SIZE"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
 echo "== rocprofv3 pmc WRITE_SIZE"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
 echo "== rocprofv3 pmc SQ instruction counters (two passes)"
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu_stderr.txt"
 timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu2" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu2_stderr.txt"

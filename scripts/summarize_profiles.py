@@ -71,7 +71,7 @@ def main():
     key = f"{cfg['robot']}_S{cfg['seeds_per_gpu']}_W{cfg['waypoints']}_K{cfg['lm_iterations_per_step']}_coll{int(cfg['collision_fused'])}"
     fk, wk = summary["FETCH_SIZE"]["mean_KB"], summary["WRITE_SIZE"]["mean_KB"]
     traffic = {
-        "_how": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 ; rocprofv3 --pmc "
+        "_how": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 ; rocprofv3 --pmc "
         "WRITE_SIZE -- (same): scripts/record_pass.sh.  Mean over the lm_fused_kernel dispatches.  FETCH_SIZE (KB) is doubled "
         "(gfx950 reports half the bytes of a coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) is exact.",
         key: {
