@@ -17,6 +17,10 @@ tracking the path, x0 = clamp(q*_s + 0.1 randn) (the construction of the referen
 `--inputs random` switches to the 8d fall-back (independent q* ~ U(limits) per waypoint, tests/optimization_test.py:136-137),
 which is the worst case for the wave-uniform collision broad phase.
 
+Timing: `--prewarm-ms` (60) of untimed launches bring the GPU to its sustained clocks, then W untimed warm-up steps, then
+exactly K steps between barrier + synchronize pairs; the maximum over ranks is reported.  Consecutive steps are independent
+batches (a ring of four output-buffer sets) alternating between `--streams` (2) HIP streams.
+
 Prints ONE JSON line (rank 0).
 """
 
