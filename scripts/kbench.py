@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks on one MI355X (developer tool): times the fused launch for a grid of (robot, K, collide)
-with HIP events, interleaved rounds in one process (cdna guide rule 24).  Usage: python scripts/kbench.py [--rounds 5]"""
+with HIP events, interleaved rounds in one process (cdna guide rule 24), after a 60 ms pre-warm to sustained clocks.  Usage: python scripts/kbench.py [--rounds 5]"""
 import argparse
 import os
 import sys
@@ -55,6 +55,15 @@ def main():
     for fn in [c[1] for c in cases]:
         fn()
     torch.cuda.synchronize()
+    # bring the GPU to its sustained clocks first (see bench.py --prewarm-ms): ~60 ms of the heaviest fused launch
+    import time
+
+    heavy = [c[1] for c in cases if "plan K=10 coll=1 +summary" in c[0]][0]
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.06:
+        for _ in range(50):
+            heavy()
+        torch.cuda.synchronize()
     for _ in range(args.rounds):
         for name, fn, _K in cases:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
