@@ -473,6 +473,14 @@ def main():
                 "note": "binding resource is the fp32 FMA rate (157.3 TFLOP/s: vector peak == f32-input MFMA peak); the "
                 "kernel issues VALU FMAs, no MFMA instructions.  achieved = algorithmic flops (SURVEY 8d) / kernel time",
                 "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
+                # the isolated launch has only 4 rows per SIMD lane in flight (262 144 rows on 65 536 lanes): its loop is
+                # partly latency-bound; with two independent batches in flight (the timed configuration) the same kernels
+                # deliver this rate per GPU
+                "at_step_rate": {
+                    "achieved": flops_launch / (elapsed / args.steps) / 1e12,
+                    "frac": flops_launch / (elapsed / args.steps) / 1e12 / F32_PEAK_TFLOPS,
+                    "batches_in_flight": n_streams,
+                },
             },
         }
         if world == 1 and not args.no_cpu_baseline:
