@@ -644,42 +644,48 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
     }
 }
 
-// one row of the fused launch: K LM iterations, then metrics / collision stage
-template <class RB, int COLL>
-__device__ __forceinline__ void lm_fused_row(const RB& rb, const CollK& co, const LmK& prm, const float* __restrict__ x_in,
-                                             const float* __restrict__ target, const cppf_lm_outputs& out, float* lds,
-                                             int tid, size_t row, float (&q)[RB::D], RowSummary& rs) {
-    constexpr int D = RB::D;
-    float Rt[9], tt[3];
-    load_x<D>(x_in, row, q);
+// ---- one row of the fused launch, in three pieces: load, one LM iteration, finish (store, metrics, collision stage) -----------
+template <class RB>
+__device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restrict__ x_in, const float* __restrict__ target,
+                                            size_t row, float (&q)[RB::D], float (&Rt)[9], float (&tt)[3]) {
+    load_x<RB::D>(x_in, row, q);
     load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+}
 
-    for (int it = 0; it < prm.n_steps; ++it) {
-        float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
-        fk_ee_axes<RB>(rb, q, R, p, ax, og);
-        pose_error(Rt, tt, R, p, e);
-        jacobian_from_axes<RB>(rb, p, ax, og, J);
-        lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
-        if (it == prm.n_steps - 1) {
-            // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
-            if (out.J_out) {
-                float* Jo = out.J_out + row * 6 * D;
+template <class RB>
+__device__ __forceinline__ void lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
+                                               const float (&Rt)[9], const float (&tt)[3], float (&q)[RB::D]) {
+    constexpr int D = RB::D;
+    float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
+    fk_ee_axes<RB>(rb, q, R, p, ax, og);
+    pose_error(Rt, tt, R, p, e);
+    jacobian_from_axes<RB>(rb, p, ax, og, J);
+    lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+    if (last) {
+        // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
+        if (out.J_out) {
+            float* Jo = out.J_out + row * 6 * D;
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
-            }
-            if (out.e_out) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
-            }
+                for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
         }
+        if (out.e_out) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) q[j] += delta[j];
-        if (prm.clamp) clamp_row<RB>(rb, q);
+            for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+        }
     }
-    if (out.x_out) store_x<D>(out.x_out, row, q);
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] += delta[j];
+    if (prm.clamp) clamp_row<RB>(rb, q);
+}
 
+template <class RB, int COLL>
+__device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, const cppf_lm_outputs& out, float* lds, int tid,
+                                              size_t row, const float (&Rt)[9], const float (&tt)[3], const float (&q)[RB::D],
+                                              RowSummary& rs) {
+    constexpr int D = RB::D;
+    if (out.x_out) store_x<D>(out.x_out, row, q);
     const bool want_metrics = out.pos_err_m || out.rot_err_rad || out.seed_summary;
     if constexpr (COLL != 0) {
         const bool do_self = out.self_mask || out.min_self || out.ext_cost || out.seed_summary;
@@ -744,7 +750,12 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
 #pragma unroll
     for (int j = 0; j < D; ++j) q[j] = 0.f;
     RowSummary rs;
-    if (active) lm_fused_row<RB, COLL>(rb, co, prm, x_in, target, out, lds, tid, row, q, rs);
+    if (active) {
+        float Rt[9], tt[3];
+        lm_row_load<RB>(prm, x_in, target, row, q, Rt, tt);
+        for (int it = 0; it < prm.n_steps; ++it) lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+        lm_row_finish<RB, COLL>(rb, co, out, lds, tid, row, Rt, tt, q, rs);
+    }
     if constexpr (COLL != 0) {
         if (out.seed_summary) block_seed_summary<RB>(rb, prm.W, row, active, q, rs, out.seed_summary);
     }
