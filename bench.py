@@ -96,7 +96,8 @@ def make_inputs_problem(robot, S, W, device, seed):
     """SURVEY.md 8(d) inputs: the target path of the reference problem the configuration names (committed fixture; the 12-DoF
     chain has no reference problem: target = FK of a smooth random walk q*_{t+1} = clamp(q*_t + 0.02 randn)) and, per seed, a
     distinct IK branch q*_s that tracks the path (waypoint 0 solved by damped LM from a U(limits) start, every later waypoint
-    warm-started from its predecessor -- what IKFlow + dp_search hand to the optimiser), then x0 = clamp(q*_s + 0.1 randn)
+    warm-started from its predecessor, a branch that loses the path continuing on one that did not -- what IKFlow + dp_search
+    hand to the optimiser), then x0 = clamp(q*_s + 0.1 randn)
     (the construction of the reference's tests/optimization_test.py:82).  Returns (x0 [S*W,d], target [W,7], description)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     lo = torch.tensor([l for l, _ in robot.actuated_joints_limits], dtype=torch.float32)
@@ -132,8 +133,16 @@ def make_inputs_problem(robot, S, W, device, seed):
             break
     x[todo] = r["x"][todo]
     x = x.contiguous()
+    gd = torch.Generator(device=device).manual_seed(seed + 17)
     for w in range(W):
-        x = robot.lm_pose_steps(x, target[w : w + 1].contiguous(), 1e-6, 3.5, 0.35, n_steps=8)["x"]
+        r = robot.lm_pose_steps(x, target[w : w + 1].contiguous(), 1e-6, 3.5, 0.35, n_steps=8, want_errors=True)
+        x = r["x"]
+        # a branch that loses the path (runs into a joint limit) continues on a branch that did not
+        ok = (r["pos_err_m"] < 1e-4) & (r["rot_err_rad"] < 1.75e-3)
+        donors = torch.nonzero(ok).reshape(-1)
+        if 0 < donors.numel() < S:
+            pick = donors[torch.randint(donors.numel(), (S,), generator=gd, device=device)]
+            x = torch.where(ok[:, None], x, x[pick]).contiguous()
         branch[:, w] = x
     noise = 0.1 * torch.randn((S, W, d), generator=g)
     x0 = torch.minimum(torch.maximum(branch + noise.to(device), lo_d), hi_d).reshape(S * W, d).contiguous()
