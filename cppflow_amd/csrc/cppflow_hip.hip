@@ -286,7 +286,8 @@ struct CollOut {
 // ---- broad phase (mask-only launches) -----------------------------------------------------------------------------------------
 // A capsule's segment lies in the ball of radius h (half its length, a constant of the rigid link) about its mid point m,
 // so  dist(seg_a, seg_b) >= |m_a - m_b| - h_a - h_b  and  dist(seg_c, box) >= dist(m_c, box) - h_c.  A pair is skipped when
-// EVERY active lane of the wavefront has   |m_a - m_b|^2 > (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4)   (tabulated, rounded up).
+// EVERY active lane of the wavefront has   |m_a - m_b|^2 > (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4)   (tabulated, rounded up;
+// evaluated on doubled mid points against 4 x the threshold, which is the same comparison bit for bit).
 // The exact functions return the squared distance between two points ON the segments / box (whatever parameters the
 // fp32 arithmetic lands on), which is >= the true squared distance up to the ~1e-6 relative rounding of the final
 // difference and dot product; with the 1 cm margin the skipped test could only have said "no hit", so the masks are
@@ -371,9 +372,12 @@ __device__ __forceinline__ void capsule_fk_static(const RB& rb, const float (&q)
     }
 }
 
+// twice the capsule's mid point: the broad phase works on doubled coordinates (|s_a - s_b|^2 against 4 x the tabulated
+// threshold, the cuboid corners doubled by the host) -- exactly the same comparison as on the mid points themselves (scaling
+// by powers of two is exact), without the three multiplies per capsule
 __device__ __forceinline__ void capsule_mid(const float (&a0)[3], const float (&a1)[3], float (&m)[3]) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) m[k] = 0.5f * (a0[k] + a1[k]);
+    for (int k = 0; k < 3; ++k) m[k] = a0[k] + a1[k];
 }
 
 template <class RB, bool WANT_MIN>
@@ -396,7 +400,7 @@ __device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
                 float ma[3], mb[3];
                 capsule_mid(w0[a], w1[a], ma);
                 capsule_mid(w0[b], w1[b], mb);
-                if (cull_far(mid_dist2(ma, mb), T::pair_cull[pi])) continue;
+                if (cull_far(mid_dist2(ma, mb), 4.f * T::pair_cull[pi])) continue;
             }
             const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
             if constexpr (WANT_MIN) {
@@ -418,7 +422,7 @@ __device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
                 if constexpr (!WANT_MIN) {
                     float m[3];
                     capsule_mid(w0[c], w1[c], m);
-                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), T::cap_cull[c])) continue;
+                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), 4.f * T::cap_cull[c])) continue;
                 }
                 const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
@@ -463,8 +467,8 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
             if constexpr (!WANT_MIN) {
                 float ma[3], mb[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) ma[k] = 0.5f * (a0[k] + a1[k]), mb[k] = 0.5f * (b0[k] + b1[k]);
-                if (cull_far(mid_dist2(ma, mb), co.pair_cull[pi])) continue;
+                for (int k = 0; k < 3; ++k) ma[k] = a0[k] + a1[k], mb[k] = b0[k] + b1[k];  // doubled mid points
+                if (cull_far(mid_dist2(ma, mb), co.pair_cull4[pi])) continue;
             }
             const float d2 = seg_seg_dist2(a0, a1, b0, b1);
             if constexpr (WANT_MIN) {
@@ -487,8 +491,8 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
                 if constexpr (!WANT_MIN) {
                     float m[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) m[k] = 0.5f * (w0[k] + w1[k]);
-                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), co.cap_cull[c])) continue;
+                    for (int k = 0; k < 3; ++k) m[k] = w0[k] + w1[k];  // doubled mid point
+                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), co.cap_cull4[c])) continue;
                 }
                 const float d2 = seg_box_dist2(w0, w1, co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
@@ -1290,7 +1294,7 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
                 float ma[3], mb[3];
                 capsule_mid(a0, a1, ma);
                 capsule_mid(b0, b1, mb);
-                if (cull_far(mid_dist2(ma, mb), co.pair_cull[pi])) continue;
+                if (cull_far(mid_dist2(ma, mb), co.pair_cull4[pi])) continue;
             }
             const float sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
             const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
@@ -1317,7 +1321,7 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
                 {
                     float m[3];
                     capsule_mid(w0, w1, m);
-                    if (cull_far(point_box_dist2(m, co.obs_lo[o], co.obs_hi[o]), co.cap_cull[c])) continue;
+                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), co.cap_cull4[c])) continue;
                 }
                 const float sd = seg_box_closest(w0, w1, co.obs_lo[o], co.obs_hi[o], cs, cb);
                 const float dist = sd - co.cap_r[c];
@@ -2260,7 +2264,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.cap_r[c] = desc->cap_r[c];
         co.cap_link[c] = (int8_t)desc->cap_link[c];
         co.cap_thr[c] = sqrt_threshold(desc->cap_r[c]);
-        co.cap_cull[c] = cull_threshold(cap_half_length(*desc, c) + (double)desc->cap_r[c]);
+        co.cap_cull4[c] = 4.f * cull_threshold(cap_half_length(*desc, c) + (double)desc->cap_r[c]);
     }
     // cap_begin[l+1] = first capsule whose link >= l
     for (int l = -1; l <= d; ++l) {
@@ -2274,7 +2278,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.pair_b[p] = (uint8_t)desc->pairs[p][1];
         co.pair_thr[p] = sqrt_threshold(desc->cap_r[desc->pairs[p][0]] + desc->cap_r[desc->pairs[p][1]]);
         const int a = desc->pairs[p][0], b = desc->pairs[p][1];
-        co.pair_cull[p] = cull_threshold(cap_half_length(*desc, a) + cap_half_length(*desc, b) + (double)desc->cap_r[a] +
+        co.pair_cull4[p] = 4.f * cull_threshold(cap_half_length(*desc, a) + cap_half_length(*desc, b) + (double)desc->cap_r[a] +
                                          (double)desc->cap_r[b]);
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
@@ -2306,6 +2310,8 @@ int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const
             CPPF_REQUIRE(cuboids[o * 6 + k] <= cuboids[o * 6 + 3 + k], "cuboid min corner > max corner");
             robot->coll.obs_lo[o][k] = R[9 + k] + cuboids[o * 6 + k];
             robot->coll.obs_hi[o][k] = R[9 + k] + cuboids[o * 6 + 3 + k];
+            robot->coll.obs_lo2[o][k] = 2.f * robot->coll.obs_lo[o][k];
+            robot->coll.obs_hi2[o][k] = 2.f * robot->coll.obs_hi[o][k];
         }
     }
     robot->coll.nobs = n_obs;

@@ -37,12 +37,14 @@ struct CollK {
     int8_t cap_link[CPPF_MAX_CAPSULES];   // moving link of each capsule (-1 = base)
     float pair_thr[CPPF_MAX_PAIRS];       // smallest y with sqrt_rn(y) >= r_a + r_b:  sqrt(d2) - (r_a+r_b) < 0  <=>  d2 < y
     float cap_thr[CPPF_MAX_CAPSULES];     // the same for r alone (capsule vs cuboid)
-    float pair_cull[CPPF_MAX_PAIRS];      // broad phase: (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4), h = half length
-    float cap_cull[CPPF_MAX_CAPSULES];    // broad phase: (h + r + 1 cm)^2 (1 + 1e-4)
+    float pair_cull4[CPPF_MAX_PAIRS];     // broad phase: 4 (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4), h = half length (x4: doubled mid points)
+    float cap_cull4[CPPF_MAX_CAPSULES];   // broad phase: 4 (h + r + 1 cm)^2 (1 + 1e-4)
     uint8_t pair_a[CPPF_MAX_PAIRS];
     uint8_t pair_b[CPPF_MAX_PAIRS];
     float obs_lo[CPPF_MAX_OBSTACLES][3];  // world-frame box corners
     float obs_hi[CPPF_MAX_OBSTACLES][3];
+    float obs_lo2[CPPF_MAX_OBSTACLES][3];  // 2 x the corners (broad phase on doubled mid points)
+    float obs_hi2[CPPF_MAX_OBSTACLES][3];
     float jl_lo[CPPF_MAX_DOF];  // padded limits of search.py:46-51
     float jl_hi[CPPF_MAX_DOF];
     int32_t ncaps, npairs, nobs, has_jl;
@@ -109,10 +111,15 @@ struct StaRobot {
 
 // ---- sin / cos ------------------------------------------------------------------------------------------------------------
 // Cody-Waite reduction by pi/2 in three exact pieces + Cephes single-precision minimax polynomials on [-pi/4, pi/4].
-// ~22 VALU instructions, no slow path: joint angles are bounded by the joint limits (|q| < 2^10 is ample).
+// ~24 VALU instructions, no slow path: joint angles are bounded by the joint limits (|q| < 2^10 is ample; the magic-number
+// rounding needs |x * 2/pi| < 2^22).
 // The fp32 oracle build uses the identical formula, so FK agrees bit for bit.
 __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
-    const float k = __builtin_rintf(x * 0.63661977236758134f);
+    // k = round-to-nearest-even(x * 2/pi) by the magic-number trick: adding 1.5 * 2^23 leaves the integer in the low mantissa
+    // bits of t (one rounding, of the exact fma), so t's bit pattern also carries k mod 4 -- no v_rndne / v_cvt_i32
+    const float magic = 12582912.0f;
+    const float t = CPPF_FMA(x, 0.63661977236758134f, magic);
+    const float k = t - magic;
     float r = CPPF_FMA(-k, 1.5703125f, x);
     r = CPPF_FMA(-k, 4.837512969970703125e-4f, r);
     r = CPPF_FMA(-k, 7.54978995489188e-8f, r);
@@ -121,13 +128,12 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
     const float sn = CPPF_FMA(r * z, ps, r);
     const float pc = CPPF_FMA(CPPF_FMA(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
     const float cs = CPPF_FMA(z * z, pc, CPPF_FMA(-0.5f, z, 1.0f));
-    const int q = ((int)k) & 3;
-    float so = (q & 1) ? cs : sn;
-    float co = (q & 1) ? sn : cs;
-    if (q == 1 || q == 2) co = -co;
-    if (q >= 2) so = -so;
-    s = so;
-    c = co;
+    const uint32_t ki = __float_as_uint(t);
+    const bool odd = ki & 1u;  // odd quadrants swap the two polynomials
+    const uint32_t so = __float_as_uint(odd ? cs : sn) ^ ((ki << 30) & 0x80000000u);         // sin negated in quadrants 2, 3
+    const uint32_t co = __float_as_uint(odd ? sn : cs) ^ (((ki + 1u) << 30) & 0x80000000u);  // cos in quadrants 1, 2
+    s = __uint_as_float(so);
+    c = __uint_as_float(co);
 }
 
 // ---- canonical FK steps ---------------------------------------------------------------------------------------------------

@@ -149,7 +149,11 @@ int orc_is_f32(void) {
 /* Cody-Waite reduction by pi/2 (3 constants) + Cephes single-precision minimax polynomials on [-pi/4, pi/4].
  * Written with explicit fmaf so that the HIP kernels (which use the same formula) agree bit for bit. */
 static void sincos_real(float x, float* s, float* c) {
-    float k = rintf(x * 0.63661977236758134f);
+    /* k = round-to-nearest-even(x * 2/pi) by the magic-number trick: adding 1.5 * 2^23 leaves the integer in the low mantissa
+     * bits of t (one rounding, of the exact fma), so t's bit pattern also carries k mod 4 without a float->int conversion */
+    const float magic = 12582912.0f;
+    float t = fmaf(x, 0.63661977236758134f, magic);
+    float k = t - magic;
     float r = fmaf(-k, 1.5703125f, x);
     r = fmaf(-k, 4.837512969970703125e-4f, r);
     r = fmaf(-k, 7.54978995489188e-8f, r);
@@ -158,13 +162,16 @@ static void sincos_real(float x, float* s, float* c) {
     float sn = fmaf(r * z, ps, r);
     float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
     float cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
-    int q = ((int)k) & 3;
-    float so = (q & 1) ? cs : sn;
-    float co = (q & 1) ? sn : cs;
-    if (q == 1 || q == 2) co = -co;
-    if (q >= 2) so = -so;
-    *s = so;
-    *c = co;
+    uint32_t ki, so, co, sb, cb;
+    memcpy(&ki, &t, 4);
+    memcpy(&sb, &sn, 4);
+    memcpy(&cb, &cs, 4);
+    so = (ki & 1u) ? cb : sb; /* odd quadrants swap the two polynomials */
+    co = (ki & 1u) ? sb : cb;
+    so ^= (ki << 30) & 0x80000000u;        /* sin is negated in quadrants 2, 3 */
+    co ^= ((ki + 1u) << 30) & 0x80000000u; /* cos in quadrants 1, 2 */
+    memcpy(s, &so, 4);
+    memcpy(c, &co, 4);
 }
 #else
 static void sincos_real(double x, double* s, double* c) {
