@@ -23,6 +23,10 @@ for c in C2 C3 C5; do
 done
 echo "== kbench"
 timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
+echo "== launch model"
+timeout -k 10 300 python scripts/launch_model.py > "$OUT/launch_model.txt" 2>&1
+echo "== iterations per launch (steady state)"
+for k in 10 20 30; do timeout -k 10 300 python bench.py --no-cpu-baseline --lm-steps $k | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('K =', d['config']['lm_iterations_per_step'], ' step', round(d['ms_per_step']*1e3,2), 'us  isolated kernel', round(d['roofline']['kernel_ms']*1e3,2), 'us')" >> "$OUT/launch_model.txt"; done
 echo "== rocprofv3 kernel trace"
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"

@@ -87,7 +87,7 @@ def main():
     for src, dst in (("bench.json", "bench.json"), ("bench_streams1.json", "bench_streams1.json"), ("bench_dist1.json", "bench_dist1.json"),
                      ("bench_random_inputs.json", "bench_random_inputs.json"), ("valu_issue_rate_calibration.txt", "valu_issue_rate_calibration.txt"),
                      ("bench_C2.json", "bench_C2.json"), ("bench_C3.json", "bench_C3.json"), ("bench_C5.json", "bench_C5.json"),
-                     ("kbench.txt", "kbench.txt"), ("pytest_gpu.txt", "pytest_gpu.txt")):  # fmt: skip
+                     ("kbench.txt", "kbench.txt"), ("launch_model.txt", "launch_model.txt"), ("pytest_gpu.txt", "pytest_gpu.txt")):  # fmt: skip
         if os.path.exists(os.path.join(REC, src)):
             shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{dst}"))
     print(json.dumps(summary, indent=1)[:3000])
