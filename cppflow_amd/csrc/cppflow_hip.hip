@@ -2404,7 +2404,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     // per-seed summary: fused into the launch when a workgroup holds whole seeds, else the separate reduction afterwards
     cppf_lm_outputs outk = *out;
     float* const summary_dst = out->seed_summary;
-    const bool summary_after = out->seed_summary && !(W == 64 || W == 128 || W == 256);
+    const bool summary_after = out->seed_summary && !(W >= 64 && kBlock % W == 0 && (W & (W - 1)) == 0);  // 64, 128, 256
     if (summary_after) {
         CPPF_REQUIRE(out->x_out && out->pos_err_m && out->rot_err_rad && out->self_mask && out->env_mask &&
                          out->jlim_mask && out->ext_cost,
