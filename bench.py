@@ -5,8 +5,8 @@ A "step" is ONE pass of the hot path over one batch of synthetic seeds: a single
 (cppf_lm_pose_steps) doing `--lm-steps` K iterations of { pose-only LM step ; clamp to joint limits } on every
 (seed, waypoint) row, then the pose-error metrics, self / environment collision masks, joint-limit mask and search cost of
 the result, followed by the per-seed summary reduction (8 floats per seed: the x_is_valid maxima, collision counts, summed
-cost) -- and, for N > 1, one RCCL all-gather of those summaries (32 KB per rank; asynchronous, double-buffered, so it
-overlaps the next step's kernel).  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S
+cost) -- and, for N > 1, RCCL all-gathers of those summaries (32 KB per rank and step, `--gather-every` = 8 steps per
+collective, issued on an auxiliary stream while the next bucket's kernels run).  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S
 seeds: weak scaling, seeds sharded, no data-path collective other than that all-gather).
 
 Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two
@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps, to reach sustained clocks (0 disables)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps alternate between")
     ap.add_argument("--inputs", choices=["problem", "random"], default="problem",
                     help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); "
@@ -315,26 +317,24 @@ def main():
     else:
         x0, target = make_inputs(robot, S, W, device, seed=rank)
         inputs_desc = "per waypoint q* ~ U(limits), target = FK(q*), seeds = clamp(q* + 0.1 randn) (SURVEY 8d fall-back inputs)"
-    NBUF = 4  # ring depth of output buffer sets (see below)
+    G = max(1, args.gather_every)  # steps per collective (N > 1): the [S,8] summaries of G consecutive steps travel together
+    NBUF = max(4, 2 * G)  # ring of output buffer sets: two buckets of G steps, one being filled while the other is on the wire
     x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
     packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
                for _ in range(NBUF)]  # fmt: skip
     x_out, packed = x_outs[0], packeds[0]
     prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
-    # per-seed summaries (8 floats per seed) are what every rank needs from every other rank each step; kept in a ring of
-    # buffers so that the all-gather of step i (on the communicator's stream) overlaps the fused kernels of later steps
-    # (ring depth NBUF: the collective of step i only has to be complete before step i + NBUF reuses its buffers)
-    summaries = [torch.empty((S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if collide else None
-    gathered = [torch.empty((world * S, 8), dtype=torch.float32, device=device) for _ in range(NBUF)] if (dist is not None and collide) else None
-    works = [None] * NBUF
+    # per-seed summaries (8 floats per seed) are what every rank needs from every other rank; the fused launch of ring slot b
+    # writes summ_all[b] itself (in-kernel epilogue when W is 64 / 128 / 256, else a second reduction kernel issued by the same
+    # C call); a bucket of G slots is all-gathered in one collective on an auxiliary stream, overlapping the next bucket's kernels
+    summ_all = torch.empty((NBUF, S, 8), dtype=torch.float32, device=device) if collide else None
+    use_dist = dist is not None and collide
+    gathered = [torch.empty((world, G, S, 8), dtype=torch.float32, device=device) for _ in range(NBUF // G)] if use_dist else None
 
     if collide:
-        # one pre-marshalled plan per ring slot: the launch writes that slot's [S,8] per-seed summary itself (in-kernel
-        # epilogue when W is 64 / 128 / 256, else a second reduction kernel issued by the same C call)
-        plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=sm, **prm)
-                 for xo, pk, sm in zip(x_outs, packeds, summaries)]  # fmt: skip
-        launches = [p.launch for p in plans]
-        launch, outputs = launches[0], plans[0].outputs
+        plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=summ_all[b], **prm)
+                 for b, (xo, pk) in enumerate(zip(x_outs, packeds))]  # fmt: skip
+        launch, outputs = plans[0].launch, plans[0].outputs
     else:
         pos_err = torch.empty(n, dtype=torch.float32, device=device)
 
@@ -346,47 +346,42 @@ def main():
     step_no = [0]
 
     # --streams 2: consecutive steps are independent batches (own output buffers per ring slot), so they alternate between
-    # two HIP streams and one launch's tail (its last, partly filled round of workgroups) overlaps the next one's ramp-up
+    # two HIP streams and one launch's tail overlaps the next one's ramp-up
     n_streams = max(1, min(args.streams, NBUF))
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)] if n_streams > 1 else None
-    if streams is not None:
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(device))
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(device))
+    aux = torch.cuda.Stream(device=device) if use_dist else None  # the collectives are issued (and waited for) here
+    launched = [torch.cuda.Event() for _ in streams]  # "this stream's launches of the bucket are enqueued"
+    bucket_done = [None] * (NBUF // G)  # recorded on aux when the bucket's collective has completed
 
-    def step_multi_stream():
+    def step():
+        if not collide:
+            return launch()
         b = step_no[0] % NBUF
         step_no[0] += 1
         st = streams[b % n_streams]
-        if gathered is None:
+        if not use_dist:
             plans[b].launch_on(st)
             return
-        with torch.cuda.stream(st):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
-            launches[b]()
-            works[b] = dist.all_gather_into_tensor(gathered[b], summaries[b], async_op=True)
-
-    def step():
-        if streams is not None and collide:
-            return step_multi_stream()
-        b = step_no[0] % NBUF
-        step_no[0] += 1
-        if works[b] is not None:
-            works[b].wait()  # stream-side wait: the buffers of step i-2 are free again
-            works[b] = None
-        if collide:
-            launches[b]()
-        else:
-            launch()
-        if gathered is not None:
-            works[b] = dist.all_gather_into_tensor(gathered[b], summaries[b], async_op=True)
+        bucket = b // G
+        if bucket_done[bucket] is not None:
+            st.wait_event(bucket_done[bucket])  # this bucket's slots were on the wire 2 G steps ago
+        plans[b].launch_on(st)
+        if b % G == G - 1:  # the bucket is complete: gather its G summaries from every rank
+            for k, s_k in enumerate(streams):
+                launched[k].record(s_k)
+                aux.wait_event(launched[k])
+            with torch.cuda.stream(aux):
+                work = dist.all_gather_into_tensor(gathered[bucket], summ_all[bucket * G : (bucket + 1) * G], async_op=True)
+                work.wait()  # stream-side: aux waits for the communicator's stream
+                done = bucket_done[bucket] if bucket_done[bucket] is not None else torch.cuda.Event()
+                done.record(aux)
+                bucket_done[bucket] = done
 
     def drain():
-        for b in range(NBUF):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
+        if aux is not None:
+            aux.synchronize()
 
     def barrier():
         if dist is not None:
@@ -412,6 +407,13 @@ def main():
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
+    # diagnostic, outside the timed region: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)
+    th = time.perf_counter()
+    for i in range(64):
+        step()
+    t_enqueued = (time.perf_counter() - th) / 64 * args.steps
+    drain()
+    torch.cuda.synchronize()
     # kernel duration: a second, untimed pass with HIP events bracketing each launch on the launch stream (torch's
     # current stream is the stream the kernel is launched on); no collective inside the bracket
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -459,6 +461,7 @@ def main():
                 "inputs": inputs_desc,
                 "streams": n_streams,
                 "prewarm_ms": args.prewarm_ms,
+                "host_enqueue_us_per_step": 1e6 * t_enqueued / args.steps,
                 "robot": args.robot,
                 "seeds_per_gpu": S,
                 "waypoints": W,
@@ -466,8 +469,10 @@ def main():
                 "lm_iterations_per_step": K,
                 "collision_fused": collide,
                 "obstacles": len(obstacles),
-                "per_step": "one fused launch incl. the per-seed summary reduction" + (" + async all-gather of the [S,8] summaries" if gathered is not None else ""),
-                "allgather_bytes_per_rank": int(summaries[0].numel() * 4) if gathered is not None else 0,
+                "per_step": "one fused launch incl. the per-seed summary reduction"
+                + (f" + async all-gather of the [S,8] summaries, {G} steps per collective" if gathered is not None else ""),
+                "allgather_bytes_per_rank_per_step": int(summ_all[0].numel() * 4) if gathered is not None else 0,
+                "steps_per_allgather": G if gathered is not None else 0,
                 "converged_frac_pos_err_lt_1e-4": conv_frac,
             },
             "roofline": {
