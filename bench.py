@@ -369,18 +369,24 @@ def main():
             st.wait_event(bucket_done[bucket])  # this bucket's slots were on the wire 2 G steps ago
         plans[b].launch_on(st)
         if b % G == G - 1:  # the bucket is complete: gather its G summaries from every rank
-            for k, s_k in enumerate(streams):
-                launched[k].record(s_k)
-                aux.wait_event(launched[k])
-            with torch.cuda.stream(aux):
-                work = dist.all_gather_into_tensor(gathered[bucket], summ_all[bucket * G : (bucket + 1) * G], async_op=True)
-                work.wait()  # stream-side: aux waits for the communicator's stream
-                done = bucket_done[bucket] if bucket_done[bucket] is not None else torch.cuda.Event()
-                done.record(aux)
-                bucket_done[bucket] = done
+            gather_bucket(bucket)
+
+    def gather_bucket(bucket):
+        for k, s_k in enumerate(streams):
+            launched[k].record(s_k)
+            aux.wait_event(launched[k])
+        with torch.cuda.stream(aux):
+            work = dist.all_gather_into_tensor(gathered[bucket], summ_all[bucket * G : (bucket + 1) * G], async_op=True)
+            work.wait()  # stream-side: aux waits for the communicator's stream
+            done = bucket_done[bucket] if bucket_done[bucket] is not None else torch.cuda.Event()
+            done.record(aux)
+            bucket_done[bucket] = done
 
     def drain():
         if aux is not None:
+            if step_no[0] % G != 0:  # a partly filled bucket: its summaries are exchanged too before the clock stops
+                gather_bucket((step_no[0] % NBUF) // G)
+                step_no[0] += G - step_no[0] % G  # the next step starts a fresh bucket
             aux.synchronize()
 
     def barrier():
