@@ -1,0 +1,238 @@
+// kernels_chain.h -- per-row chain evaluation: FK with joint axes, pose error, geometric Jacobian, the damped solve, the clamp.
+// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+#pragma once
+
+// ---- per-row chain evaluation ---------------------------------------------------------------------------------------------
+
+template <int D>
+__device__ __forceinline__ void load_x(const float* __restrict__ x, size_t row, float (&q)[D]) {
+    const float* p = x + row * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(p)[k];
+            q[4 * k] = v.x, q[4 * k + 1] = v.y, q[4 * k + 2] = v.z, q[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) q[j] = p[j];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_x(float* __restrict__ x, size_t row, const float (&q)[D]) {
+    float* p = x + row * D;
+    if constexpr (D % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k)
+            reinterpret_cast<float4*>(p)[k] = make_float4(q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) p[j] = q[j];
+    }
+}
+
+// FK to the end-effector frame only
+template <class RB>
+__device__ __forceinline__ void fk_ee(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3]) {
+    frame_identity(R, p);
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+        fk_joint(R, p, rb.pris(j), q[j]);
+    }
+    fk_fixed_ee(rb, R, p);
+}
+
+// FK keeping every joint's world axis and origin (for the Jacobian)
+template <class RB>
+__device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
+                                           float (&ax)[RB::D][3], float (&og)[RB::D][3]) {
+    frame_identity(R, p);
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, rb.pris(j), q[j]);
+    }
+    fk_fixed_ee(rb, R, p);
+}
+
+// geometric Jacobian, rows 0:3 angular / 3:6 linear
+template <class RB>
+__device__ __forceinline__ void jacobian_from_axes(const RB& rb, const float (&pe)[3], const float (&ax)[RB::D][3],
+                                                   const float (&og)[RB::D][3], float (&J)[6][RB::D]) {
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        const float z0 = ax[j][0], z1 = ax[j][1], z2 = ax[j][2];
+        if (!rb.pris(j)) {
+            const float rx = pe[0] - og[j][0], ry = pe[1] - og[j][1], rz = pe[2] - og[j][2];
+            J[0][j] = z0, J[1][j] = z1, J[2][j] = z2;
+            J[3][j] = CPPF_FMA(z1, rz, -(z2 * ry));
+            J[4][j] = CPPF_FMA(z2, rx, -(z0 * rz));
+            J[5][j] = CPPF_FMA(z0, ry, -(z1 * rx));
+        } else {
+            J[0][j] = J[1][j] = J[2][j] = 0.f;
+            J[3][j] = z0, J[4][j] = z1, J[5][j] = z2;
+        }
+    }
+}
+
+// get_6d_pose_errors without the quaternion detour: the five terms quaternion_to_rpy reads from q_target * q_cur^-1 are
+// entries of R_err = R_target * R_cur^T  (cppflow/optimization_utils.py:813-819)
+__device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
+                                           const float (&p)[3], float (&e)[6]) {
+    const float e20 = dot3(Rt[6], Rt[7], Rt[8], R[0], R[1], R[2]);
+    const float e21 = dot3(Rt[6], Rt[7], Rt[8], R[3], R[4], R[5]);
+    const float e22 = dot3(Rt[6], Rt[7], Rt[8], R[6], R[7], R[8]);
+    const float e10 = dot3(Rt[3], Rt[4], Rt[5], R[0], R[1], R[2]);
+    const float e00 = dot3(Rt[0], Rt[1], Rt[2], R[0], R[1], R[2]);
+    float sp = -e20;
+    sp = sp > 1.f ? 1.f : (sp < -1.f ? -1.f : sp);
+    e[0] = atan2f(e21, e22);
+    e[1] = asinf(sp);
+    e[2] = atan2f(e10, e00);
+    e[3] = tt[0] - p[0];
+    e[4] = tt[1] - p[1];
+    e[5] = tt[2] - p[2];
+}
+
+// positional / geodesic rotational error (cppflow/evaluation_utils.py:134-141).  The reference evaluates
+// 2*acos(clamp(q_t . q_c, -1+1e-7, 1-1e-7)) folded to [0, pi]; that is the rotation angle theta of R_err, floored at
+// 2*acos(1 - 1e-7) = 8.944e-4 rad by the clamp.  theta is taken from atan2(|skew(R_err)|/2, (tr - 1)/2), which keeps
+// full relative accuracy for small angles (acos near 1 does not).
+__device__ __forceinline__ void pose_metrics(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
+                                             const float (&p)[3], float& pos_err, float& rot_err) {
+    const float dx = tt[0] - p[0], dy = tt[1] - p[1], dz = tt[2] - p[2];
+    pos_err = __builtin_sqrtf(CPPF_FMA(dz, dz, CPPF_FMA(dy, dy, dx * dx)));
+    float E[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            E[3 * i + j] = dot3(Rt[3 * i], Rt[3 * i + 1], Rt[3 * i + 2], R[3 * j], R[3 * j + 1], R[3 * j + 2]);
+    const float a0 = E[7] - E[5], a1 = E[2] - E[6], a2 = E[3] - E[1];
+    const float sn = 0.5f * __builtin_sqrtf(CPPF_FMA(a2, a2, CPPF_FMA(a1, a1, a0 * a0)));
+    const float cs = 0.5f * (E[0] + E[4] + E[8] - 1.f);
+    const float theta = atan2f(sn, cs);
+    rot_err = fmaxf(theta, 8.94427191e-4f);
+}
+
+// One damped Gauss-Newton update in dual form.  With S = diag(a_rot x3, a_pos x3) the reference scales J and e in place
+// (optimization.py:77-80) and solves (Js^T Js + lambda I) delta = Js^T es; here the scaling is folded into the 6x6 system:
+//     A = S (J J^T) S + lambda I,   A y = S e,   delta = J^T (S y)
+// (21 + 6 + 6 multiplies instead of 6 d + 6), identical in exact arithmetic.  J and e are left UNscaled.
+template <int D>
+__device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
+                                              float a_rot, float (&delta)[D]) {
+    const float srr = a_rot * a_rot, srp = a_rot * a_pos, spp = a_pos * a_pos;
+    // Cholesky A = L L^T with reciprocal pivots and pivot floor lambda (every exact pivot of A is >= lambda_min(A) >=
+    // lambda, so the floor only acts on rounding noise)
+    float L[6][6], inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int i = j; i < 6; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
+            s *= (i < 3 ? (j < 3 ? srr : srp) : (j < 3 ? srp : spp));
+            if (i == j) s += lambda;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
+            if (i == j) {
+                s = fmaxf(s, lambda);
+                inv[j] = __frsqrt_rn(s);
+            } else {
+                L[i][j] = s * inv[j];
+            }
+        }
+    }
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = e[i] * (i < 3 ? a_rot : a_pos);
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] *= (i < 3 ? a_rot : a_pos);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = CPPF_FMA(J[i][k], y[i], s);
+        delta[k] = s;
+    }
+}
+
+// Fewer than 6 joints: J J^T (6x6) is rank-deficient and the dual form loses its conditioning advantage, while J^T J (d x d)
+// is well conditioned -- solve the reference's primal system (optimization.py:85-88) by Cholesky.
+template <int D>
+__device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
+                                                float a_rot, float (&delta)[D]) {
+    const float s2[2] = {a_rot * a_rot, a_pos * a_pos};
+    float L[D][D], inv[D], y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+#pragma unroll
+        for (int i = j; i < D; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s = CPPF_FMA(s2[k >= 3] * J[k][i], J[k][j], s);
+            if (i == j) s += lambda;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
+            if (i == j) {
+                s = fmaxf(s, lambda);
+                inv[j] = __frsqrt_rn(s);
+            } else {
+                L[i][j] = s * inv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s = CPPF_FMA(s2[k >= 3] * J[k][i], e[k], s);
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < D; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
+        y[i] = s * inv[i];
+        delta[i] = y[i];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void lm_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos, float a_rot,
+                                         float (&delta)[D]) {
+    if constexpr (D < 6)
+        lm_primal_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+    else
+        lm_dual_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+}
+
+template <class RB>
+__device__ __forceinline__ void clamp_row(const RB& rb, float (&q)[RB::D]) {
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) q[j] = fminf(fmaxf(q[j], rb.lo(j)), rb.hi(j));
+}

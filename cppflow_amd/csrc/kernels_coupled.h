@@ -1,0 +1,776 @@
+// kernels_coupled.h -- the coupled LM step: waypoint-local blocks, distance Jacobians, the three eliminations of the block-tridiagonal system.
+// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+#pragma once
+
+// ---- coupled ("full") LM step: cppflow/optimization.py:95-144 + LmResidualFns.get_r_and_J (optimization_utils.py:486-731) -------
+// The reference stacks pose / differencing / virtual-config / collision residuals of ONE trajectory into a dense
+// J [(6T + d(T-1) + ...) x dT], forms the dense dT x dT normal matrix and factors it (O((dT)^3)).  Structurally
+// A = J^T J + lambda I is block-tridiagonal with d x d blocks: pose and collision rows only touch their own waypoint's
+// block, the differencing row (t,j) = a_j * wrap(x[t+1,j] - x[t,j]) couples (t,j) with (t+1,j) through -a_j^2 on the
+// off-diagonal, virtual-config rows and lambda add to the diagonal.  So:
+//   full_blocks_kernel  (one lane per (seed, waypoint) row): the waypoint-local part  M_t = sum Js^T Js + sum alpha^2 g g^T,
+//                        m_t = Js^T es - sum alpha^2 dist g   (g = gradient of a colliding capsule distance)
+//   full_solve_kernel   (one lane per seed): adds the analytic differencing / virtual-config / lambda terms and runs the
+//                        block-tridiagonal elimination D'_t = A_tt - E G_{t-1} E,  G_t = D'_t^-1  (E = -diag(a^2)) forward and
+//                        back -- O(T d^3) per trajectory, any number of trajectories at once (the reference: one, :128).
+
+struct FullK {
+    float lm_lambda, a_pos, a_rot, a_diff, a_diff_pris, a_vq, a_self, a_env;
+    int32_t use_pose, use_diff, use_vq, n_vq, use_self, use_env;
+    int32_t S, W;
+};
+
+// gradient of a point rigidly attached to moving link `link`, projected on n:  n . d(c)/dq_j  for every joint j
+template <class RB>
+__device__ __forceinline__ void point_grad(const RB& rb, int link, const float (&n)[3], const float (&c)[3],
+                                           const float (&ax)[RB::D][3], const float (&og)[RB::D][3], float sign,
+                                           float (&g)[RB::D]) {
+#pragma unroll
+    for (int j = 0; j < RB::D; ++j) {
+        float v;
+        if (!rb.pris(j)) {
+            const float rx = c[0] - og[j][0], ry = c[1] - og[j][1], rz = c[2] - og[j][2];
+            const float cx = ax[j][1] * rz - ax[j][2] * ry, cy = ax[j][2] * rx - ax[j][0] * rz,
+                        cz = ax[j][0] * ry - ax[j][1] * rx;
+            v = n[0] * cx + n[1] * cy + n[2] * cz;
+        } else {
+            v = n[0] * ax[j][0] + n[1] * ax[j][1] + n[2] * ax[j][2];
+        }
+        g[j] += (j <= link) ? sign * v : 0.f;
+    }
+}
+
+// M (upper triangle, row-major i <= j) += w * g g^T ;  m += wm * g
+template <int D>
+__device__ __forceinline__ void rank1(float (&M)[D * (D + 1) / 2], float (&m)[D], const float (&g)[D], float w, float wm) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float wi = w * g[i];
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            M[k] = CPPF_FMA(wi, g[j], M[k]);
+            ++k;
+        }
+        m[i] = CPPF_FMA(wm, g[i], m[i]);
+    }
+}
+
+// Robot.self_collision_distances_jacobian(x) / Robot.env_collision_distances_jacobian(x, cuboid, Tcuboid) (jrl; call sites
+// cppflow/optimization_utils.py:670, 710): d(distance)/dq per pair / per capsule with the closest points held fixed on their
+// links,  n . (dc1/dq - dc2/dq)  (0 where the segments touch: the direction is undefined).  Same FK, closest-point and
+// gradient code as the coupled step (full_blocks_kernel), which only ever needs the colliding ones.
+template <int D, bool ENV>
+__global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK ch, const CollK co, int n,
+                                                                    const float* __restrict__ x, float blo0, float blo1,
+                                                                    float blo2, float bhi0, float bhi1, float bhi2,
+                                                                    float* __restrict__ jac, float* __restrict__ dists) {
+    extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3];
+    load_x<D>(x, row, q);
+    frame_identity(R, p);
+    for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, rb.pris(j), q[j]);
+        for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
+            float w0[3], w1[3];
+            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
+            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lds[(c * 6 + k) * kBlock + tid] = w0[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+            }
+        }
+    }
+    const int count = ENV ? co.ncaps : co.npairs;
+    for (int e = 0; e < count; ++e) {
+        float nrm[3] = {0.f, 0.f, 0.f}, g[D], sd, radius;
+#pragma unroll
+        for (int j = 0; j < D; ++j) g[j] = 0.f;
+        if constexpr (ENV) {
+            const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
+            float w0[3], w1[3], cs[3], cb[3];
+            lds_capsule(lds, tid, e, w0, w1);
+            sd = seg_box_closest(w0, w1, lo, hi, cs, cb);
+            radius = co.cap_r[e];
+            if (sd > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
+            }
+            point_grad<RB>(rb, co.cap_link[e], nrm, cs, ax, og, 1.f, g);
+        } else {
+            const int a = co.pair_a[e], b = co.pair_b[e];
+            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            radius = co.cap_r[a] + co.cap_r[b];
+            if (sd > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
+            }
+            point_grad<RB>(rb, co.cap_link[a], nrm, c1, ax, og, 1.f, g);
+            point_grad<RB>(rb, co.cap_link[b], nrm, c2, ax, og, -1.f, g);
+        }
+        float* o = jac + (row * count + e) * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = g[j];
+        if (dists) dists[row * count + e] = sd - radius;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ target,
+                                                             float* __restrict__ blocks) {
+    extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    constexpr int NT = D * (D + 1) / 2;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    const size_t n = (size_t)prm.S * prm.W;
+    if (row >= n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3], M[NT], m[D];
+    load_x<D>(x, row, q);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) M[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) m[j] = 0.f;
+
+    // FK with joint axes / origins, capsule end points to LDS (same canonical chain as everywhere else)
+    frame_identity(R, p);
+    for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        fk_fixed_joint(rb, j, R, p);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ax[j][i] = R[3 * i + 2];
+            og[j][i] = p[i];
+        }
+        fk_joint(R, p, rb.pris(j), q[j]);
+        for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
+            float w0[3], w1[3];
+            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
+            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lds[(c * 6 + k) * kBlock + tid] = w0[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+            }
+        }
+    }
+
+    if (prm.use_pose) {  // optimization_utils.py:503-543
+        float Re[9], pe[3], Rt[9], tt[3], J[6][D], e[6];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Re[k] = R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pe[k] = p[k];
+        fk_fixed_ee(rb, Re, pe);
+        load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+        pose_error(Rt, tt, Re, pe, e);
+        jacobian_from_axes<RB>(rb, pe, ax, og, J);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float a = i < 3 ? prm.a_rot : prm.a_pos;
+            float g[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) g[j] = a * J[i][j];
+            rank1<D>(M, m, g, 1.f, a * e[i]);
+        }
+    }
+    if (prm.use_self) {  // :645-680: rows where -alpha * dist > 0
+        const float w = prm.a_self * prm.a_self;
+        for (int pi = 0; pi < co.npairs; ++pi) {
+            const int a = co.pair_a[pi], b = co.pair_b[pi];
+            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            {  // broad phase (cull_far): only pairs that penetrate contribute rows, and a far pair cannot penetrate
+                float ma[3], mb[3];
+                capsule_mid(a0, a1, ma);
+                capsule_mid(b0, b1, mb);
+                if (cull_far(mid_dist2(ma, mb), co.pair_cull4[pi])) continue;
+            }
+            const float sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
+            if (dist < 0.f) {
+                float nrm[3] = {0.f, 0.f, 0.f}, g[D];
+                if (sd > 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) g[j] = 0.f;
+                point_grad<RB>(rb, co.cap_link[a], nrm, c1, ax, og, 1.f, g);
+                point_grad<RB>(rb, co.cap_link[b], nrm, c2, ax, og, -1.f, g);
+                rank1<D>(M, m, g, w, -w * dist);
+            }
+        }
+    }
+    if (prm.use_env) {  // :685-727
+        const float w = prm.a_env * prm.a_env;
+        for (int o = 0; o < co.nobs; ++o)
+            for (int c = 0; c < co.ncaps; ++c) {
+                float w0[3], w1[3], cs[3], cb[3];
+                lds_capsule(lds, tid, c, w0, w1);
+                {
+                    float m[3];
+                    capsule_mid(w0, w1, m);
+                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), co.cap_cull4[c])) continue;
+                }
+                const float sd = seg_box_closest(w0, w1, co.obs_lo[o], co.obs_hi[o], cs, cb);
+                const float dist = sd - co.cap_r[c];
+                if (dist < 0.f) {
+                    float nrm[3] = {0.f, 0.f, 0.f}, g[D];
+                    if (sd > 0.f) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) g[j] = 0.f;
+                    point_grad<RB>(rb, co.cap_link[c], nrm, cs, ax, og, 1.f, g);
+                    rank1<D>(M, m, g, w, -w * dist);
+                }
+            }
+    }
+    float* o = blocks + row * (NT + D);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) o[k] = M[k];
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[NT + j] = m[j];
+}
+
+// inverse of a symmetric positive definite D x D matrix (full storage in, full storage out) by Cholesky; pivots floored
+template <int D>
+__device__ __forceinline__ void spd_inverse(const float (&A)[D][D], float floor_v, float (&G)[D][D]) {
+    float L[D][D], Li[D][D], inv[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[j][k], L[j][k], s);
+        s = fmaxf(s, floor_v);
+        inv[j] = __frsqrt_rn(s);
+        L[j][j] = s * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            float t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = CPPF_FMA(-L[i][k], L[j][k], t);
+            L[i][j] = t * inv[j];
+        }
+    }
+    // Li = L^-1 (lower triangular)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        Li[j][j] = inv[j];
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < i; ++k) t = CPPF_FMA(-L[i][k], Li[k][j], t);
+            Li[i][j] = t * inv[i];
+        }
+    }
+    // G = Li^T Li
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = j; k < D; ++k) t = CPPF_FMA(Li[k][i], Li[k][j], t);
+            G[i][j] = t;
+            G[j][i] = t;
+        }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                        const float* __restrict__ xv, const float* __restrict__ blocks,
+                                                        float* __restrict__ workG, float* __restrict__ worky,
+                                                        float* __restrict__ x_out) {
+    constexpr int NT = D * (D + 1) / 2;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= prm.S) return;
+    const int T = prm.W;
+    const size_t base = (size_t)s * T;
+    float a2[D];  // a_j^2 = (alpha_differencing * prismatic scaling)^2  (optimization_utils.py:607-612)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float a = prm.use_diff ? prm.a_diff * (((ch.pris_mask >> j) & 1u) ? prm.a_diff_pris : 1.f) : 0.f;
+        a2[j] = a * a;
+    }
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+
+    float G[D][D], y[D], xp[D], xc[D], xn[D];
+    load_x<D>(x, base, xc);
+    // ---- forward elimination
+    for (int t = 0; t < T; ++t) {
+        const float* blk = blocks + (base + t) * (NT + D);
+        float A[D][D], b[D];
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    const float v = blk[k++];
+                    A[i][j] = v;
+                    A[j][i] = v;
+                }
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = blk[NT + j];
+        }
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        if (has_next) load_x<D>(x, base + t + 1, xn);
+        const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            A[j][j] += cnt * a2[j] + (vq ? beta2 : 0.f) + prm.lm_lambda;
+            // J^T r of the differencing rows: +a^2 w_t at (t,j), -a^2 w_{t-1} at (t,j)   (w = wrapped joint change)
+            if (has_next) b[j] = CPPF_FMA(a2[j], wrap_pi(xn[j] - xc[j]), b[j]);
+            if (has_prev) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xp[j]), b[j]);
+        }
+        if (vq) {  // r = beta * wrap(x - x_virtual), J = -beta I  (optimization_utils.py:430-484)
+            float v[D];
+            if (xv) load_x<D>(xv, base + t, v);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? wrap_pi(xc[j] - v[j]) : 0.f, b[j]);
+        }
+        if (has_prev) {
+            // D' = A - E G E ,  y = b - E G y_prev   with E = -diag(a2)
+            float Gy[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    acc = CPPF_FMA(G[i][j], y[j], acc);
+                    A[i][j] = CPPF_FMA(-(a2[i] * a2[j]), G[i][j], A[i][j]);
+                }
+                Gy[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[i] = CPPF_FMA(a2[i], Gy[i], b[i]);  // b - (-a2) * (G y_prev)
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) y[i] = b[i];
+        }
+        spd_inverse<D>(A, prm.lm_lambda, G);
+        float* gout = workG + (base + t) * NT;
+        float* yout = worky + (base + t) * D;
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) gout[k++] = G[i][j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) yout[j] = y[j];
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            xp[j] = xc[j];
+            xc[j] = xn[j];
+        }
+    }
+    // ---- back substitution: delta_t = G_t (y_t - E delta_{t+1}) = G_t (y_t + a2 .* delta_{t+1})
+    float dl[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) dl[j] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float* gin = workG + (base + t) * NT;
+        const float* yin = worky + (base + t) * D;
+        float rhs[D], Gt[D][D];
+        {
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    const float v = gin[k++];
+                    Gt[i][j] = v;
+                    Gt[j][i] = v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) rhs[j] = (t + 1 < T) ? CPPF_FMA(a2[j], dl[j], yin[j]) : yin[j];
+        float nd[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc = CPPF_FMA(Gt[i][j], rhs[j], acc);
+            nd[i] = acc;
+        }
+        float xr[D];
+        load_x<D>(x, base + t, xr);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            dl[j] = nd[j];
+            xr[j] += nd[j];  // optimization.py:113: x + delta_x
+        }
+        store_x<D>(x_out, base + t, xr);
+    }
+}
+
+// Wavefront-parallel form of full_solve_kernel for D <= 8: one wavefront per trajectory, lane l <-> element
+// (i, j) = (l >> 3, l & 7) of the 8 x 8 matrix that holds the d x d block padded with the identity.  The elimination is
+// inherently sequential in t, so the only parallelism inside a trajectory is inside the d x d operations: the block inverse
+// is an in-place Gauss-Jordan sweep (per pivot: one v_readlane for the pivot, two cross-lane reads for its row and column,
+// one fused update on all 64 lanes), matrix-vector products are a lane-local multiply plus a 3-step xor-butterfly over the
+// row or column bits.  Operands of step t+1 are requested before step t is computed, so their latency hides behind it.
+template <int D>
+__global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                             const float* __restrict__ xv,
+                                                             const float* __restrict__ blocks, float* __restrict__ workG,
+                                                             float* __restrict__ worky, float* __restrict__ x_out) {
+    static_assert(D <= 8, "one 8x8 tile per wavefront");
+    constexpr int NT = D * (D + 1) / 2;
+    const int s = blockIdx.x;
+    if (s >= prm.S) return;
+    const int lane = threadIdx.x, i = lane >> 3, j = lane & 7;
+    const bool in = i < D && j < D, colv = j < D;
+    const int T = prm.W;
+    const size_t base = (size_t)s * T;
+    const int ii = i < j ? i : j, jj = i < j ? j : i;
+    const int tri = in ? ii * D - (ii * (ii - 1)) / 2 + (jj - ii) : 0;  // offset of (min, max) in the packed upper triangle
+    auto a2_of = [&](int c) {
+        if (!prm.use_diff || c >= D) return 0.f;
+        const float a = prm.a_diff * (((ch.pris_mask >> c) & 1u) ? prm.a_diff_pris : 1.f);
+        return a * a;
+    };
+    const float a2i = a2_of(i), a2j = a2_of(j);
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+    const int jc = colv ? j : 0;  // padded lanes read column 0 (their values are never used)
+
+    // ---- forward elimination
+    float G = 0.f, y_row = 0.f;
+    float xp = 0.f, xc = x[(base + 0) * D + jc], xn = T > 1 ? x[(base + 1) * D + jc] : 0.f;
+    float Mij = blocks[(base + 0) * (NT + D) + tri], bj = blocks[(base + 0) * (NT + D) + NT + jc];
+    float vj = xv ? xv[(base + 0) * D + jc] : 0.f;
+    for (int t = 0; t < T; ++t) {
+        // request the operands of step t+1 now
+        float nM = 0.f, nb = 0.f, nx2 = 0.f, nv = 0.f;
+        if (t + 1 < T) {
+            nM = blocks[(base + t + 1) * (NT + D) + tri];
+            nb = blocks[(base + t + 1) * (NT + D) + NT + jc];
+            if (xv) nv = xv[(base + t + 1) * D + jc];
+        }
+        if (t + 2 < T) nx2 = x[(base + t + 2) * D + jc];
+
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        float A = in ? Mij : (i == j ? 1.f : 0.f);
+        if (in && i == j) A += ((has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f)) * a2j + (vq ? beta2 : 0.f) + prm.lm_lambda;
+        float b = colv ? bj : 0.f;
+        if (colv) {
+            if (has_next) b = CPPF_FMA(a2j, wrap_pi(xn - xc), b);
+            if (has_prev) b = CPPF_FMA(-a2j, wrap_pi(xc - xp), b);
+            if (vq && xv) b = CPPF_FMA(-beta2, wrap_pi(xc - vj), b);
+        }
+        float ycol = b;
+        if (has_prev) {
+            A = CPPF_FMA(-(a2i * a2j), G, A);  // D' = A - E G E   (padding: a2 = 0)
+            float pr = G * y_row;              // G_ij y_i, summed over i -> (G y)_j in every lane of column j
+            pr += __shfl_xor(pr, 8, 64);
+            pr += __shfl_xor(pr, 16, 64);
+            pr += __shfl_xor(pr, 32, 64);
+            ycol = CPPF_FMA(a2j, pr, b);  // y = b - E (G y_prev)
+        }
+        // in-place Gauss-Jordan inverse (SPD: no pivoting; pivots floored like the Cholesky pivots of the per-lane kernel)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float pv = fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), k * 9)), prm.lm_lambda);
+            const float pinv = 1.f / pv;
+            const float rk = __shfl(A, k * 8 + j, 64);        // A_kj
+            const float ck = __shfl(A, (lane & 56) + k, 64);  // A_ik
+            float nvl = CPPF_FMA(-(ck * pinv), rk, A);
+            nvl = (i == k) ? rk * pinv : nvl;
+            nvl = (j == k) ? -(ck * pinv) : nvl;
+            nvl = (i == k && j == k) ? pinv : nvl;
+            A = nvl;
+        }
+        G = A;
+        if (in && i <= j) workG[(base + t) * NT + tri] = G;
+        if (i == 0 && colv) worky[(base + t) * D + j] = ycol;
+        y_row = __shfl(ycol, j * 8 + i, 64);  // lane (i,j) takes y_i from column i
+        xp = xc, xc = xn, xn = nx2;
+        Mij = nM, bj = nb, vj = nv;
+    }
+    // ---- back substitution: delta_t = G_t (y_t + a2 .* delta_{t+1})
+    float dl = 0.f;  // delta_{t+1}, column-replicated
+    float Gn = in ? workG[(base + T - 1) * NT + tri] : (i == j ? 1.f : 0.f);
+    float yn = colv ? worky[(base + T - 1) * D + j] : 0.f;
+    float xr = (in && j == 0) ? x[(base + T - 1) * D + i] : 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float Gt = Gn, yt = yn, xt = xr;
+        if (t > 0) {
+            Gn = in ? workG[(base + t - 1) * NT + tri] : (i == j ? 1.f : 0.f);
+            yn = colv ? worky[(base + t - 1) * D + j] : 0.f;
+            xr = (in && j == 0) ? x[(base + t - 1) * D + i] : 0.f;
+        }
+        const float rhs = (t + 1 < T) ? CPPF_FMA(a2j, dl, yt) : yt;
+        float pr = Gt * rhs;  // G_ij rhs_j, summed over j -> delta_i in every lane of row i
+        pr += __shfl_xor(pr, 1, 64);
+        pr += __shfl_xor(pr, 2, 64);
+        pr += __shfl_xor(pr, 4, 64);
+        if (in && j == 0) x_out[(base + t) * D + i] = xt + pr;  // optimization.py:113: x + delta_x
+        dl = __shfl(pr, j * 8 + i, 64);
+    }
+}
+
+// Parallel-in-time form for few trajectories (the planner's cadence is ONE, cppflow/optimization.py:128): the two kernels
+// above walk the T waypoints one after the other (2 T dependent block steps, ~1.4 us each), which leaves the chip idle when
+// S is small.  Parallel cyclic reduction eliminates in ceil(log2 T) levels instead: one lane per waypoint, one workgroup per
+// trajectory.  With A block-tridiagonal and symmetric, at stride s row t couples to t - s through L_t (and to t + s through
+// L_{t+s}^T); one level replaces
+//     alpha = -L_t D_{t-s}^-1 ,  gamma = -L_{t+s}^T D_{t+s}^-1
+//     D_t <- D_t + alpha L_t^T + gamma L_{t+s} ,   y_t <- y_t + alpha y_{t-s} + gamma y_{t+s} ,   L_t <- alpha L_{t-s}
+// which doubles the stride; after the last level delta_t = D_t^-1 y_t.  O(T log T d^3) work instead of O(T d^3), all of it
+// parallel.  State lives in the caller's workspace (D_t packed | y_t in work_blocks, L_t dense in work_G) and is exchanged
+// between the lanes of the workgroup through L1 / L2 (workgroup-scope fences of __syncthreads).  Used without the pose block
+// (diagonal blocks = (cnt a^2 + lambda) I + collision terms: well conditioned, the Schur complements stay SPD).
+template <int D, int BS>
+__global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
+                                                            const float* __restrict__ xv, float* blocks, float* workL,
+                                                            float* __restrict__ x_out) {
+    constexpr int NT = D * (D + 1) / 2, SB = NT + D, DD = D * D;
+    const int s = blockIdx.x, t = threadIdx.x, T = prm.W;
+    const bool act = t < T;
+    const size_t base = (size_t)s * T;
+    float a2[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const float a = prm.use_diff ? prm.a_diff * (((ch.pris_mask >> j) & 1u) ? prm.a_diff_pris : 1.f) : 0.f;
+        a2[j] = a * a;
+    }
+    const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+
+    // ---- assemble row t in place: D_t = M_t + (cnt a^2 + [vq] beta^2 + lambda) I,  y_t = m_t + analytic J^T r terms
+    if (act) {
+        float* blk = blocks + (base + t) * SB;
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        float xc[D], xo[D], b[D];
+        load_x<D>(x, base + t, xc);
+#pragma unroll
+        for (int j = 0; j < D; ++j) b[j] = blk[NT + j];
+        if (has_next) {
+            load_x<D>(x, base + t + 1, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(a2[j], wrap_pi(xo[j] - xc[j]), b[j]);
+        }
+        if (has_prev) {
+            load_x<D>(x, base + t - 1, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xo[j]), b[j]);
+        }
+        if (vq && xv) {
+            load_x<D>(xv, base + t, xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, wrap_pi(xc[j] - xo[j]), b[j]);
+        }
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            blk[k] += cnt * a2[i] + (vq ? beta2 : 0.f) + prm.lm_lambda;  // diagonal entry (i, i) of the packed upper triangle
+            k += D - i;
+        }
+#pragma unroll
+        for (int j = 0; j < D; ++j) blk[NT + j] = b[j];
+        float* Lt = workL + (base + t) * DD;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Lt[i * D + j] = (i == j && has_prev) ? -a2[i] : 0.f;  // E = -diag(a^2)
+    }
+    __syncthreads();
+
+    auto load_sym = [&](const float* src, float (&M)[D][D]) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+                const float v = src[k++];
+                M[i][j] = v;
+                M[j][i] = v;
+            }
+    };
+
+    // D_t^-1 is needed by both neighbours of t: every lane inverts its own block once per level and shares it through LDS
+    __shared__ float s_P[BS][NT + 1];  // +1: odd row stride, no bank conflicts on the strided neighbour reads
+    auto load_inv = [&](int u, float (&M)[D][D]) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+                const float v = s_P[u][k++];
+                M[i][j] = v;
+                M[j][i] = v;
+            }
+    };
+    for (int st = 1; st < T; st <<= 1) {
+        float nD[D][D], ny[D], nL[D][D];
+        if (act) {
+            float Dn[D][D], P[D][D];
+            load_sym(blocks + (base + t) * SB, Dn);
+            spd_inverse<D>(Dn, prm.lm_lambda, P);
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) s_P[t][k++] = P[i][j];
+        }
+        __syncthreads();
+        if (act) {
+            const float* own = blocks + (base + t) * SB;
+            load_sym(own, nD);
+#pragma unroll
+            for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
+            const int tm = t - st, tp = t + st;
+            if (tm >= 0) {
+                float P[D][D], Lt[D][D], Lm[D][D], ym[D];
+                const float* nb = blocks + (base + tm) * SB;
+                load_inv(tm, P);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Lt[i][j] = workL[(base + t) * DD + i * D + j];
+                        Lm[i][j] = workL[(base + tm) * DD + i * D + j];
+                    }
+#pragma unroll
+                for (int j = 0; j < D; ++j) ym[j] = nb[NT + j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    float al[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc = CPPF_FMA(Lt[i][k], P[k][j], acc);
+                        al[j] = -acc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float accD = nD[i][j], accL = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            accD = CPPF_FMA(al[k], Lt[j][k], accD);  // alpha L_t^T
+                            accL = CPPF_FMA(al[k], Lm[k][j], accL);  // alpha L_{t-s}
+                        }
+                        nD[i][j] = accD;
+                        nL[i][j] = accL;
+                    }
+                    float accy = ny[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) accy = CPPF_FMA(al[k], ym[k], accy);
+                    ny[i] = accy;
+                }
+            }
+            if (tp < T) {
+                float P[D][D], Lp[D][D], yp[D];
+                const float* nb = blocks + (base + tp) * SB;
+                load_inv(tp, P);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Lp[i][j] = workL[(base + tp) * DD + i * D + j];
+#pragma unroll
+                for (int j = 0; j < D; ++j) yp[j] = nb[NT + j];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    float ga[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc = CPPF_FMA(Lp[k][i], P[k][j], acc);  // L_{t+s}^T D_{t+s}^-1
+                        ga[j] = -acc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        float accD = nD[i][j];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) accD = CPPF_FMA(ga[k], Lp[k][j], accD);  // gamma L_{t+s}
+                        nD[i][j] = accD;
+                    }
+                    float accy = ny[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) accy = CPPF_FMA(ga[k], yp[k], accy);
+                    ny[i] = accy;
+                }
+            }
+        }
+        __syncthreads();  // every lane has read its neighbours' old state
+        if (act) {
+            float* own = blocks + (base + t) * SB;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) own[k++] = 0.5f * (nD[i][j] + nD[j][i]);  // symmetric in exact arithmetic
+#pragma unroll
+            for (int j = 0; j < D; ++j) own[NT + j] = ny[j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) workL[(base + t) * DD + i * D + j] = nL[i][j];
+        }
+        __syncthreads();
+    }
+    if (act) {
+        float Dn[D][D], P[D][D], xr[D];
+        const float* own = blocks + (base + t) * SB;
+        load_sym(own, Dn);
+        spd_inverse<D>(Dn, prm.lm_lambda, P);
+        load_x<D>(x, base + t, xr);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc = CPPF_FMA(P[i][k], own[NT + k], acc);
+            xr[i] += acc;  // optimization.py:113: x + delta_x
+        }
+        store_x<D>(x_out, base + t, xr);
+    }
+}

@@ -1,0 +1,406 @@
+// kernels_fused.h -- the fused launch and the single-purpose row kernels (FK, Jacobian, pose errors / metrics, clamp, distances, seed validity).
+// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+#pragma once
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_target(const float* __restrict__ target, int w, float (&Rt)[9], float (&tt)[3]) {
+    const float* t = target + (size_t)w * 7;
+    tt[0] = t[0], tt[1] = t[1], tt[2] = t[2];
+    quat_to_mat(t[3], t[4], t[5], t[6], Rt);
+}
+
+// What one row hands to the in-kernel per-seed summary (block_seed_summary)
+struct RowSummary {
+    float pos_err = 0.f, rot_err = 0.f, cost = 0.f;
+    int self_hit = 0, env_hit = 0, jl = 0;
+};
+
+// DPP reduction of a NON-NEGATIVE value over the 64 lanes of a wavefront into lane 63 (other lanes end up with partial
+// results).  Lanes without a source in a DPP step read the identity 0 (`old` operand), valid for max and for sums here
+// because every reduced quantity is >= 0.  No LDS traffic (ds_bpermute butterflies cost ~50 LDS-pipe ops per wave).
+template <int CTRL>
+__device__ __forceinline__ float dpp_or_zero(float x) {  // lanes without a source lane read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
+    auto op = [](float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; };
+    const float s1 = dpp_or_zero<0x111>(v), s2 = dpp_or_zero<0x112>(v), s3 = dpp_or_zero<0x113>(v);  // row_shr:1,2,3
+    v = op(op(v, s1), op(s2, s3));         // the 4 lanes ending here (within a row of 16)
+    v = op(v, dpp_or_zero<0x114>(v));      // row_shr:4   -> 8 lanes
+    v = op(v, dpp_or_zero<0x118>(v));      // row_shr:8   -> lane 15 of each row holds its row
+    v = op(v, dpp_or_zero<0x142>(v));      // row_bcast:15 -> lanes 31 / 63 hold rows 0-1 / 2-3
+    v = op(v, dpp_or_zero<0x143>(v));      // row_bcast:31 -> lane 63 holds all four rows
+    return v;
+}
+
+// Per-seed summary inside the fused launch (same 8 numbers, bit for bit, as seed_summary_kernel; every reduction is a max
+// or a sum of small integers / multiples of 100, so the order does not matter).  Requires W in {64, 128, 256}: a workgroup
+// then covers whole seeds and a seed is 1, 2 or 4 whole wavefronts.  Joint changes need the NEXT waypoint's final q:
+// lane + 1 through DPP wave_shl:1, the first lane of the next wavefront through LDS.
+template <class RB>
+__device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t row, bool active, const float (&q)[RB::D],
+                                                   const RowSummary& rs, float* __restrict__ out) {
+    constexpr int D = RB::D;
+    __shared__ float s_q[kBlock / 64][D];
+    __shared__ float s_red[kBlock / 64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float rad2deg = 57.29577951308232087680f;
+    const int wps = W >> 6;  // wavefronts per seed: 1, 2 or 4
+    if (wps > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s_q[wave][j] = q[j];
+        }
+        __syncthreads();
+    }
+    const bool seed_ends_here = ((wave + 1) & (wps - 1)) == 0;  // this wavefront holds the seed's last waypoints
+    const bool has_next = active && !(lane == 63 && seed_ends_here);
+    const int nw = wave + 1 < kBlock / 64 ? wave + 1 : wave;
+    float mrev = 0.f, mpri = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        float qn = dpp_or_zero<0x130>(q[j]);  // wave_shl:1 -- lane i reads lane i + 1
+        qn = (lane == 63) ? s_q[nw][j] : qn;  // (stale but unused when wps == 1: has_next is false there)
+        const float dq = qn - q[j];
+        const bool pr = rb.pris(j);
+        const float a = pr ? fabsf(100.f * dq) : fabsf(rad2deg * wrap_pi(dq));
+        mpri = fmaxf(mpri, pr ? a : 0.f);
+        mrev = fmaxf(mrev, pr ? 0.f : a);
+    }
+    float v[8] = {100.f * rs.pos_err, rad2deg * rs.rot_err, has_next ? mrev : 0.f, has_next ? mpri : 0.f,
+                  (float)rs.self_hit, (float)rs.env_hit, (float)rs.jl, rs.cost};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = active ? v[k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_reduce_to_lane63<true>(v[k]);
+#pragma unroll
+    for (int k = 4; k < 8; ++k) v[k] = wave_reduce_to_lane63<false>(v[k]);
+    float* o = out + ((uint32_t)row >> (31 - __builtin_clz((uint32_t)W))) * 8;  // seed = row / W, W a power of two
+    if (wps == 1) {
+        if (active && lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = v[k];
+        }
+        return;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (active && lane == 63 && seed_ends_here) {
+        for (int i = 1; i < wps; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], s_red[wave - i][k]);
+#pragma unroll
+            for (int k = 4; k < 8; ++k) v[k] += s_red[wave - i][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = v[k];
+    }
+}
+
+// ---- one row of the fused launch, in three pieces: load, one LM iteration, finish (store, metrics, collision stage) -----------
+template <class RB>
+__device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restrict__ x_in, const float* __restrict__ target,
+                                            size_t row, float (&q)[RB::D], float (&Rt)[9], float (&tt)[3]) {
+    load_x<RB::D>(x_in, row, q);
+    load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+}
+
+template <class RB>
+__device__ __forceinline__ void lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
+                                               const float (&Rt)[9], const float (&tt)[3], float (&q)[RB::D]) {
+    constexpr int D = RB::D;
+    float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
+    fk_ee_axes<RB>(rb, q, R, p, ax, og);
+    pose_error(Rt, tt, R, p, e);
+    jacobian_from_axes<RB>(rb, p, ax, og, J);
+    lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+    if (last) {
+        // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
+        if (out.J_out) {
+            float* Jo = out.J_out + row * 6 * D;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
+        }
+        if (out.e_out) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] += delta[j];
+    if (prm.clamp) clamp_row<RB>(rb, q);
+}
+
+template <class RB, int COLL>
+__device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, const cppf_lm_outputs& out, float* lds, int tid,
+                                              size_t row, const float (&Rt)[9], const float (&tt)[3], const float (&q)[RB::D],
+                                              RowSummary& rs) {
+    constexpr int D = RB::D;
+    if (out.x_out) store_x<D>(out.x_out, row, q);
+    const bool want_metrics = out.pos_err_m || out.rot_err_rad || out.seed_summary;
+    if constexpr (COLL != 0) {
+        const bool do_self = out.self_mask || out.min_self || out.ext_cost || out.seed_summary;
+        const bool do_env = out.env_mask || out.min_env || out.ext_cost || out.seed_summary;
+        rs.jl = jlim_hit<D>(co, q);
+        // capsule FK first, then the pose metrics off its last-link frame (after which the target pose and the frame are
+        // dead), then the pair / cuboid tests
+        CollOut c;
+        auto metrics = [&](float (&R)[9], float (&p)[3]) {
+            if (want_metrics) {
+                fk_fixed_ee(rb, R, p);
+                pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
+                if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
+                if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
+            }
+        };
+        if constexpr (RB::kStatic) {
+            constexpr int L = RB::Table::L > 0 ? RB::Table::L : 1;
+            float w0[L][3], w1[L][3];
+            {
+                float R[9], p[3];
+                capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+                metrics(R, p);
+            }
+            c = collide_tests_static<RB, COLL == 2>(co, w0, w1, do_self, do_env);
+        } else {
+            {
+                float R[9], p[3];
+                fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
+                metrics(R, p);
+            }
+            c = collide_from_lds<COLL == 2>(co, lds, tid, do_self, do_env);
+        }
+        rs.self_hit = c.self_hit, rs.env_hit = c.env_hit;
+        rs.cost = 100.f * (float)rs.jl + 1000.f * (float)c.env_hit + 1000.f * (float)c.self_hit;
+        write_coll_outputs(row, c, rs.jl, out.self_mask, out.env_mask, out.jlim_mask, out.ext_cost, out.min_self,
+                           out.min_env);
+    } else {
+        if (want_metrics) {
+            float R[9], p[3];
+            fk_ee<RB>(rb, q, R, p);
+            pose_metrics(Rt, tt, R, p, rs.pos_err, rs.rot_err);
+            if (out.pos_err_m) out.pos_err_m[row] = rs.pos_err;
+            if (out.rot_err_rad) out.rot_err_rad[row] = rs.rot_err;
+        }
+    }
+}
+
+// COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
+// out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
+template <class RB, int COLL>
+__global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+                                                          const float* __restrict__ x_in,
+                                                          const float* __restrict__ target, const cppf_lm_outputs out) {
+    extern __shared__ float lds[];
+    constexpr int D = RB::D;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    const bool active = row < (size_t)prm.n;
+    float q[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] = 0.f;
+    RowSummary rs;
+    if (active) {
+        float Rt[9], tt[3];
+        lm_row_load<RB>(prm, x_in, target, row, q, Rt, tt);
+        for (int it = 0; it < prm.n_steps; ++it) lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+        lm_row_finish<RB, COLL>(rb, co, out, lds, tid, row, Rt, tt, q, rs);
+    }
+    if constexpr (COLL != 0) {
+        if (out.seed_summary) block_seed_summary<RB>(rb, prm.W, row, active, q, rs, out.seed_summary);
+    }
+}
+
+template <class RB, bool WANT_MIN>
+__global__ __launch_bounds__(kBlock, CPPF_WAVES_COLL) void collision_kernel(const ChainK ch, const CollK co, int n,
+                                                           const float* __restrict__ x, uint8_t* self_mask,
+                                                           uint8_t* env_mask, uint8_t* jlim_mask, float* ext_cost,
+                                                           float* min_self, float* min_env) {
+    extern __shared__ float lds[];
+    constexpr int D = RB::D;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3];
+    load_x<D>(x, row, q);
+    // wave-uniform: which halves of the work the caller asked for (jlim-only calls skip FK altogether)
+    const bool do_self = self_mask || min_self || ext_cost;
+    const bool do_env = env_mask || min_env || ext_cost;
+    CollOut c;
+    c.min_self = c.min_env = INFINITY;
+    c.self_hit = c.env_hit = 0;
+    if (do_self || do_env) c = collide_row<RB, WANT_MIN>(rb, co, q, lds, tid, R, p, do_self, do_env);
+    write_coll_outputs(row, c, jlim_hit<D>(co, q), self_mask, env_mask, jlim_mask, ext_cost, min_self, min_env);
+}
+
+// full distance matrices (Robot.self_collision_distances / env_collision_distances); box = the single cuboid, co.nobs unused
+template <int D, bool ENV>
+__global__ __launch_bounds__(kBlock) void distances_kernel(const ChainK ch, const CollK co, int n,
+                                                           const float* __restrict__ x, float blo0, float blo1,
+                                                           float blo2, float bhi0, float bhi1, float bhi2,
+                                                           float* __restrict__ dists) {
+    extern __shared__ float lds[];
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const int tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3];
+    load_x<D>(x, row, q);
+    fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
+    if constexpr (ENV) {
+        const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
+        for (int c = 0; c < co.ncaps; ++c) {
+            float w0[3], w1[3];
+            lds_capsule(lds, tid, c, w0, w1);
+            dists[row * co.ncaps + c] = seg_box_dist(w0, w1, lo, hi) - co.cap_r[c];
+        }
+    } else {
+        for (int pi = 0; pi < co.npairs; ++pi) {
+            const int a = co.pair_a[pi], b = co.pair_b[pi];
+            float a0[3], a1[3], b0[3], b1[3];
+            lds_capsule(lds, tid, a, a0, a1);
+            lds_capsule(lds, tid, b, b0, b1);
+            dists[row * co.npairs + pi] = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void fk_kernel(const ChainK ch, const CollK co, int n, const float* __restrict__ x,
+                                                    float* __restrict__ poses) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], qt[4];
+    load_x<D>(x, row, q);
+    fk_ee<RB>(rb, q, R, p);
+    mat_to_quat(R, qt);
+    float* o = poses + row * 7;
+    o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = qt[0], o[4] = qt[1], o[5] = qt[2], o[6] = qt[3];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void jacobian_kernel(const ChainK ch, const CollK co, int n,
+                                                          const float* __restrict__ x, float* __restrict__ Jout) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], ax[D][3], og[D][3], J[6][D];
+    load_x<D>(x, row, q);
+    fk_ee_axes<RB>(rb, q, R, p, ax, og);
+    jacobian_from_axes<RB>(rb, p, ax, og, J);
+    float* Jo = Jout + row * 6 * D;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j];
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pose_errors_kernel(const ChainK ch, const CollK co, int n, int W,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ target, float* __restrict__ e_out,
+                                                             float* __restrict__ cur_out) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], Rt[9], tt[3], e[6];
+    load_x<D>(x, row, q);
+    load_target(target, (int)(row % (size_t)W), Rt, tt);
+    fk_ee<RB>(rb, q, R, p);
+    pose_error(Rt, tt, R, p, e);
+    if (e_out) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) e_out[row * 6 + i] = e[i];
+    }
+    if (cur_out) {
+        float qt[4];
+        mat_to_quat(R, qt);
+        float* o = cur_out + row * 7;
+        o[0] = p[0], o[1] = p[1], o[2] = p[2], o[3] = qt[0], o[4] = qt[1], o[5] = qt[2], o[6] = qt[3];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pose_metrics_kernel(const ChainK ch, const CollK co, int n, int W,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ target,
+                                                              float* __restrict__ pos_err, float* __restrict__ rot_err) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (size_t)n) return;
+    float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
+    load_x<D>(x, row, q);
+    load_target(target, (int)(row % (size_t)W), Rt, tt);
+    fk_ee<RB>(rb, q, R, p);
+    pose_metrics(Rt, tt, R, p, pe, re);
+    if (pos_err) pos_err[row] = pe;
+    if (rot_err) rot_err[row] = re;
+}
+
+__global__ __launch_bounds__(kBlock) void clamp_kernel(const ChainK ch, size_t total, float* __restrict__ x) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % (size_t)ch.ndof);
+    x[i] = fminf(fmaxf(x[i], ch.lo[j]), ch.hi[j]);
+}
+
+// one wavefront per seed: lanes stride over the seed's W waypoints, then a 64-lane butterfly max
+template <int D>
+__global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, const CollK co, int S, int W,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ target, float* __restrict__ out) {
+    using RB = DynRobot<D>;
+    const RB rb{ch, co};
+    const int s = blockIdx.x;
+    if (s >= S) return;
+    const float rad2deg = 57.29577951308232087680f;
+    float mp = 0.f, mr = 0.f, mrev = 0.f, mpri = 0.f;
+    for (int w = threadIdx.x; w < W; w += 64) {
+        const size_t row = (size_t)s * W + w;
+        float q[D], R[9], p[3], Rt[9], tt[3], pe, re;
+        load_x<D>(x, row, q);
+        load_target(target, w, Rt, tt);
+        fk_ee<RB>(rb, q, R, p);
+        pose_metrics(Rt, tt, R, p, pe, re);
+        mp = fmaxf(mp, 100.f * pe);
+        mr = fmaxf(mr, rad2deg * re);
+        if (w + 1 < W) {
+            float qn[D];
+            load_x<D>(x, row + 1, qn);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float dq = qn[j] - q[j];
+                if (rb.pris(j))
+                    mpri = fmaxf(mpri, fabsf(100.f * dq));
+                else
+                    mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mp = fmaxf(mp, __shfl_xor(mp, off, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, off, 64));
+        mrev = fmaxf(mrev, __shfl_xor(mrev, off, 64));
+        mpri = fmaxf(mpri, __shfl_xor(mpri, off, 64));
+    }
+    if (threadIdx.x == 0) {
+        out[s * 4 + 0] = mp, out[s * 4 + 1] = mr, out[s * 4 + 2] = mrev, out[s * 4 + 3] = mpri;
+    }
+}

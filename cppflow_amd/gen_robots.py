@@ -54,7 +54,7 @@ def sqrt_threshold(r) -> np.float32:
 
 def cull_threshold(reach: float) -> np.float32:
     """Broad-phase threshold on a squared mid-point distance: (reach + 1 cm)^2 (1 + 1e-4), rounded up to fp32 (reach = half
-    lengths + radii).  Conservative by construction -- see cull_far in csrc/cppflow_hip.hip."""
+    lengths + radii).  Conservative by construction -- see cull_far in csrc/kernels_collision.h."""
     y = (float(reach) + 0.01) ** 2 * (1.0 + 1e-4)
     f = np.float32(y)
     if float(f) < y:
