@@ -82,6 +82,46 @@ __device__ __forceinline__ void jacobian_from_axes(const RB& rb, const float (&p
     }
 }
 
+// atan2 / asin for the LM residual (roll / yaw / pitch of R_err, three per iteration -- 14 % of the loop with the library
+// versions, whose IEEE divisions and special-case handling the residual does not need).  Minimax polynomials fitted for this
+// kernel: atan(a) = a + a s P7(s) on a in [0, 1] after the min / max reduction (max abs error 8e-8, relative 1.6e-7),
+// asin(x) = x + x z P4(z) on |x| <= 0.5 and pi/2 - 2 asin(sqrt((1 - |x|) / 2)) beyond (3.4e-8 / 1.5e-7).  Both keep full
+// RELATIVE accuracy towards 0, which is what the iteration needs as the residual vanishes; exact at 0.
+__device__ __forceinline__ float atan2_lm(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+    float inv = __builtin_amdgcn_rcpf(mx);
+    inv = CPPF_FMA(CPPF_FMA(-mx, inv, 1.f), inv, inv);  // one Newton step on the 1-ulp reciprocal
+    const float a = mn * inv, s = a * a;
+    float p = 0.002546269f;
+    p = CPPF_FMA(p, s, -0.014814576f);
+    p = CPPF_FMA(p, s, 0.040576745f);
+    p = CPPF_FMA(p, s, -0.07317518f);
+    p = CPPF_FMA(p, s, 0.10549001f);
+    p = CPPF_FMA(p, s, -0.14178993f);
+    p = CPPF_FMA(p, s, 0.19989419f);
+    p = CPPF_FMA(p, s, -0.33332935f);
+    float r = CPPF_FMA(a * s, p, a);
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.f ? 3.14159265358979323846f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
+__device__ __forceinline__ float asin_lm(float x) {  // |x| <= 1
+    const float ax = fabsf(x);
+    const bool big = ax > 0.5f;
+    const float z = big ? CPPF_FMA(-0.5f, ax, 0.5f) : x * x;
+    const float t = big ? __builtin_amdgcn_sqrtf(z) : ax;
+    float p = 0.04374494f;
+    p = CPPF_FMA(p, z, 0.023150224f);
+    p = CPPF_FMA(p, z, 0.04570716f);
+    p = CPPF_FMA(p, z, 0.07493067f);
+    p = CPPF_FMA(p, z, 0.16666822f);
+    float r = CPPF_FMA(t * z, p, t);
+    r = big ? CPPF_FMA(-2.f, r, 1.57079632679489661923f) : r;
+    return __builtin_copysignf(r, x);
+}
+
 // get_6d_pose_errors without the quaternion detour: the five terms quaternion_to_rpy reads from q_target * q_cur^-1 are
 // entries of R_err = R_target * R_cur^T  (cppflow/optimization_utils.py:813-819)
 __device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
@@ -93,9 +133,9 @@ __device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&t
     const float e00 = dot3(Rt[0], Rt[1], Rt[2], R[0], R[1], R[2]);
     float sp = -e20;
     sp = sp > 1.f ? 1.f : (sp < -1.f ? -1.f : sp);
-    e[0] = atan2f(e21, e22);
-    e[1] = asinf(sp);
-    e[2] = atan2f(e10, e00);
+    e[0] = atan2_lm(e21, e22);
+    e[1] = asin_lm(sp);
+    e[2] = atan2_lm(e10, e00);
     e[3] = tt[0] - p[0];
     e[4] = tt[1] - p[1];
     e[5] = tt[2] - p[2];
