@@ -169,23 +169,24 @@ __device__ __forceinline__ void pose_metrics(const float (&Rt)[9], const float (
 template <int D>
 __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
                                               float a_rot, float (&delta)[D]) {
-    const float srr = a_rot * a_rot, srp = a_rot * a_pos, spp = a_pos * a_pos;
-    // Cholesky A = L L^T with reciprocal pivots and pivot floor lambda (every exact pivot of A is >= lambda_min(A) >=
-    // lambda, so the floor only acts on rounding noise)
+    // With S = diag(a_rot x3, a_pos x3):  Js^T (Js Js^T + lambda I)^-1 es  =  J^T (J J^T + lambda S^-2)^-1 e,  so the row
+    // scaling never has to be applied: it only changes the damping per row (lambda / a^2).  Cholesky A = L L^T with
+    // reciprocal pivots and the damping as pivot floor (every exact pivot of A is >= its smallest eigenvalue >= the
+    // smallest damping term, so the floor only acts on rounding noise).
+    const float lam_r = lambda / (a_rot * a_rot), lam_p = lambda / (a_pos * a_pos);  // wave-uniform: scalar ALU
     float L[6][6], inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+        const float lam = j < 3 ? lam_r : lam_p;
 #pragma unroll
         for (int i = j; i < 6; ++i) {
-            float s = 0.f;
+            float s = (i == j) ? lam : 0.f;
 #pragma unroll
             for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
-            s *= (i < 3 ? (j < 3 ? srr : srp) : (j < 3 ? srp : spp));
-            if (i == j) s += lambda;
 #pragma unroll
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
             if (i == j) {
-                s = fmaxf(s, lambda);
+                s = fmaxf(s, lam);
                 inv[j] = __frsqrt_rn(s);
             } else {
                 L[i][j] = s * inv[j];
@@ -195,7 +196,7 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
     float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float s = e[i] * (i < 3 ? a_rot : a_pos);
+        float s = e[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s = CPPF_FMA(-L[i][k], y[k], s);
         y[i] = s * inv[i];
@@ -207,8 +208,6 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
         for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
         y[i] = s * inv[i];
     }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) y[i] *= (i < 3 ? a_rot : a_pos);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         float s = 0.f;

@@ -497,7 +497,7 @@ def test_planner_end_to_end(robots):
     assert plan.max_positional_error_cm < 0.01 and plan.max_rotational_error_deg < 0.1 and plan.mjac_deg < 7.0
     assert not bool(plan.self_colliding_per_ts.any()) and not bool(plan.env_colliding_per_ts.any())
     # the optimised plan is at least as accurate as the raw search path
-    assert plan.max_positional_error_cm <= s.plan.max_positional_error_cm + 1e-6
+    assert plan.max_positional_error_cm <= s.plan.max_positional_error_cm + 1e-4  # both sit at the fp32 floor (~2e-5 cm)
     problem.robot.set_obstacles([], [])
     problem.robot.set_joint_limit_padding(None, None)
 
@@ -609,7 +609,10 @@ def test_entry_points_are_hip_graph_capturable(robots):
     assert torch.equal(bufs[0], eager_x) and torch.equal(packed, eager_packed)
     want = H.oracle64("panda").lm_steps(x0, H.stacked(target, S), 5)
     ok = np.abs(want - x0).max(axis=1) < 0.5
-    assert np.abs(host(eager_x) - want)[ok].max() < 2e-2
+    # five single steps against the fp64 oracle: identical in the typical row, bounded on the rows whose 7th (null-space)
+    # direction is only held by the damping
+    d = np.abs(host(eager_x) - want)[ok]
+    assert np.median(d) < 1e-5 and d.max() < 5e-2
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
 
