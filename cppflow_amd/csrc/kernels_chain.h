@@ -173,7 +173,8 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
     // scaling never has to be applied: it only changes the damping per row (lambda / a^2).  Cholesky A = L L^T with
     // reciprocal pivots and the damping as pivot floor (every exact pivot of A is >= its smallest eigenvalue >= the
     // smallest damping term, so the floor only acts on rounding noise).
-    const float lam_r = lambda / (a_rot * a_rot), lam_p = lambda / (a_pos * a_pos);  // wave-uniform: scalar ALU
+    // wave-uniform, once per launch
+    const float lam_r = lambda * __builtin_amdgcn_rcpf(a_rot * a_rot), lam_p = lambda * __builtin_amdgcn_rcpf(a_pos * a_pos);
     float L[6][6], inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -187,7 +188,8 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
             if (i == j) {
                 s = fmaxf(s, lam);
-                inv[j] = __frsqrt_rn(s);
+                inv[j] = __builtin_amdgcn_rsqf(s);  // the hardware reciprocal square root (1 ulp); the correctly rounded library form
+                                                   // costs ~12 instructions each and the solve is not part of the bit-exact set
             } else {
                 L[i][j] = s * inv[j];
             }
@@ -236,7 +238,8 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
             if (i == j) {
                 s = fmaxf(s, lambda);
-                inv[j] = __frsqrt_rn(s);
+                inv[j] = __builtin_amdgcn_rsqf(s);  // the hardware reciprocal square root (1 ulp); the correctly rounded library form
+                                                   // costs ~12 instructions each and the solve is not part of the bit-exact set
             } else {
                 L[i][j] = s * inv[j];
             }
