@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- LM-IK iterations/s of the fused MI355X hot path (BASELINE.json metric), one process per GPU.
 
+    python bench.py --gpus N --steps K --warmup W
+
 A "step" is ONE pass of the hot path over one batch of synthetic seeds: a single launch of the fused kernel
 (cppf_lm_pose_steps) doing `--lm-steps` K iterations of { pose-only LM step ; clamp to joint limits } on every
 (seed, waypoint) row, then the pose-error metrics, self / environment collision masks, joint-limit mask and search cost of
-the result, followed by the per-seed summary reduction (8 floats per seed: the x_is_valid maxima, collision counts, summed
-cost) -- and, for N > 1, RCCL all-gathers of those summaries (32 KB per rank and step, `--gather-every` = 8 steps per
-collective, issued on an auxiliary stream while the next bucket's kernels run).  value = rows * K * steps / wall-time, summed over ranks (every rank owns its own S
-seeds: weak scaling, seeds sharded, no data-path collective other than that all-gather).
+the result, and the per-seed summary reduction (8 floats per seed: the x_is_valid maxima, collision counts, summed cost).
+For N > 1 the summaries of `--gather-every` consecutive steps are all-gathered over RCCL on an auxiliary stream and CONSUMED:
+every rank runs x_is_valid's seed selection (cppf_select_valid_seed_gathered, cppflow/optimization_utils.py:856-909) over all
+ranks' seeds for every step, and a ring slot is reused only after that selection has completed.  value = rows * K * steps /
+wall-time over all ranks.
 
-Workload at N = 1: BASELINE.json configs[3] geometry on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two
-cuboids of panda__2cubes -- the configuration the metric is quoted on ("1024 seeds x 256 waypoints x 7-DoF at 1 MI355X").
+Launching.  `python bench.py --gpus N` with WORLD_SIZE unset starts N fresh rank processes itself -- BEFORE this process
+touches the GPU -- relays rank 0's single JSON line and exits with the children's status; under torch.distributed.run
+(WORLD_SIZE set) it is one rank.
+
+Scaling.  N = 1: BASELINE.json configs[3] on one GPU -- Panda (7-DoF), 1024 seeds x 256 waypoints, the two cuboids of
+panda__2cubes -- the configuration the metric is quoted on.  N > 1 defaults to STRONG scaling, the configuration
+BASELINE.json names ("1024 seeds x 256 waypoints, seed-sharded across 2/4/8 MI355X"): the same 1024 seeds split by
+`distributed.seed_shard`; the weak-scaling figure (1024 seeds per GPU) is measured in the same run and reported as the
+sibling key `weak_scaling`.  `--scaling weak` makes the weak figure the headline instead.
+
 Inputs are already resident in HBM when the timed region starts: the target path is the named reference
 problem's (panda__2cubes resampled to 256 waypoints; committed fixture), the seeds are synthetic -- per seed an IK branch
 tracking the path, x0 = clamp(q*_s + 0.1 randn) (the construction of the reference's tests/optimization_test.py:82).
 `--inputs random` switches to the 8d fall-back (independent q* ~ U(limits) per waypoint, tests/optimization_test.py:136-137),
-which is the worst case for the wave-uniform collision broad phase.
+the worst case for the wave-uniform collision broad phase; at N = 1 that figure is also reported as the sibling key
+`random_inputs`, and the one-stream figure as `one_stream`.
 
 Timing: `--prewarm-ms` (60) of untimed launches bring the GPU to its sustained clocks, then W untimed warm-up steps, then
 exactly K steps between barrier + synchronize pairs; the maximum over ranks is reported.  Consecutive steps are independent
-batches (a ring of four output-buffer sets) alternating between `--streams` (2) HIP streams.
+batches (a ring of output-buffer sets) alternating between `--streams` HIP streams.
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,11 +39,14 @@ Prints ONE JSON line (rank 0).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
+
+torch = None  # imported by main() AFTER the launcher decision: the parent of an N > 1 run never loads a GPU runtime
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -39,6 +54,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak == fp32-input MFMA peak
+N_SIMD = 1024  # 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4  # MI355X_MICROARCH.md: max clock; one VALU wave-instruction occupies a SIMD for 2 cycles
 
 
 def algorithmic_flops_per_row_iter(d: int) -> float:
@@ -60,17 +77,34 @@ def algorithmic_bytes_per_row(d: int, collide: bool) -> float:
     return 8.0 * d + 28.0 + (6.0 if collide else 0.0)
 
 
+def _profile_record(fname, key):
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(key)
+
+
+def workload_key(robot, S, W, K, collide, inputs="problem"):
+    return f"{robot}_S{S}_W{W}_K{K}_coll{int(collide)}" + ("" if inputs == "problem" else f"_{inputs}")
+
+
 def traffic_from_profiles(robot, S, W, K, collide):
     """HBM bytes per launch of the fused kernel from the rocprofv3 PMC passes committed under profiles/ (separate
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950).  bench.py cannot profile itself, so the figure is the recorded one for the matching workload, else None."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rec = json.load(f)
-    key = f"{robot}_S{S}_W{W}_K{K}_coll{int(collide)}"
-    return rec.get(key, {}).get("hbm_bytes_per_launch")
+    for fname in ("r2_traffic.json", "r1_traffic.json"):
+        rec = _profile_record(fname, workload_key(robot, S, W, K, collide))
+        if rec:
+            return rec.get("hbm_bytes_per_launch")
+    return None
+
+
+def issue_record_from_profiles(robot, S, W, K, collide, inputs):
+    """{"valu_insts_per_launch": SQ_INSTS_VALU of one fused launch (wave-instructions), "flops_per_valu_lane_op": executed
+    flops per VALU lane-operation from the kernel's ISA (FMA = 2, mul / add / sub = 1, everything else 0)} recorded by
+    `rocprofv3 --pmc SQ_INSTS_VALU` for the matching workload (scripts/record_pass.sh -> profiles/r2_issue.json), else None."""
+    return _profile_record("r2_issue.json", workload_key(robot, S, W, K, collide, inputs))
 
 
 def make_inputs(robot, S, W, device, seed):
@@ -243,30 +277,38 @@ def cpu_baseline_c(robot_name, obstacles, d, W, K, budget_s=6.0):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--robot", default="panda")
-    ap.add_argument("--seeds", type=int, default=1024, help="seeds per GPU")
+    ap.add_argument("--seeds", type=int, default=1024,
+                    help="seeds of the configuration: the TOTAL that is sharded over the GPUs under strong scaling, per GPU under weak")
     ap.add_argument("--waypoints", type=int, default=256)
     ap.add_argument("--lm-steps", type=int, default=10, help="K fused LM iterations per launch")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                    help="auto = strong for N > 1 (BASELINE.json configs[3]: the same seeds sharded over the GPUs); the other mode "
+                    "is measured in the same run and reported as a sibling key")  # fmt: skip
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps, to reach sustained clocks (0 disables)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the independent steps alternate between")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
+                    "fill the chip with two launches in flight)")  # fmt: skip
+    ap.add_argument("--shape", choices=["auto", "row", "quad"], default="auto", help="kernel shape (cppf_lm_params.shape)")
     ap.add_argument("--inputs", choices=["problem", "random"], default="problem",
                     help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); "
                     "random: independent random configurations per waypoint (the 8d fall-back, worst case for the broad phase)")  # fmt: skip
     ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-siblings", action="store_true", help="skip the one_stream / random_inputs / weak_scaling sibling measurements")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
-                    help="BASELINE.json configs[1..4] geometry per GPU (default = C4, the configuration the metric is quoted on)")  # fmt: skip
-    args = ap.parse_args()
+                    help="BASELINE.json configs[1..4] geometry (default = C4, the configuration the metric is quoted on)")  # fmt: skip
+    args = ap.parse_args(argv)
     if args.config is not None:
-        preset = {  # robot, seeds per GPU, waypoints, collision fused
+        preset = {  # robot, seeds, waypoints, collision fused
             "C2": ("panda", 128, 64, False),  # FK+Jacobian+LM only
             "C3": ("fetch", 512, 256, True),  # + collision fused (fetch__hello has no obstacles: self-collision only)
             "C4": ("panda", 1024, 256, True),
@@ -274,16 +316,278 @@ def main():
         }[args.config]
         args.robot, args.seeds, args.waypoints = preset[0], preset[1], preset[2]
         args.no_collide = not preset[3]
+    return args
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this parent has not imported torch,
+    let alone touched the GPU), relay rank 0's JSON line, return the first non-zero exit status (0 if every rank succeeded).
+    Never replaces a running process: children are started with subprocess and waited for."""
+    import tempfile
+
+    n = args.gpus
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs, out0 = [], tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # fmt: skip
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))  # fmt: skip
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:  # a rank died: the others would wait in a collective for ever
+                    other.terminate()
+    for pr in procs:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    out0.seek(0)
+    for ln in out0.read().splitlines():  # stdout carries the ONE JSON line; anything else a library printed goes to stderr
+        (sys.stdout if ln.startswith('{"metric"') else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+class HostStagedGather:
+    """Rehearsal transport (CPPF_BENCH_SHARE_GPU=1: several ranks share ONE GPU, which RCCL refuses): the all-gather goes
+    through gloo with the payload staged on the host.  Same call sites, same dependency structure, meaningless timing."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_gather(self, out, inp):
+        host_in = inp.cpu()  # synchronises on the current (auxiliary) stream
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host_out, host_in)
+        out.copy_(host_out)
+
+
+class RcclGather:
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_gather(self, out, inp):
+        work = self.dist.all_gather_into_tensor(out, inp, async_op=True)
+        work.wait()  # stream-side: the current (auxiliary) stream waits for the communicator's stream
+
+
+class Runner:
+    """One workload (a batch of S seeds x W waypoints on this rank) and the machinery that steps it: a ring of output-buffer
+    sets, `n_streams` launch streams, and -- with a transport -- the bucketed all-gather of the per-seed summaries on an
+    auxiliary stream followed by the seed selection over every rank's seeds."""
+
+    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device):
+        from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
+
+        self.robot, self.x0, self.target, self.K, self.collide, self.device = robot, x0, target, K, collide, device
+        n, W = x0.shape[0], target.shape[0]
+        self.n, self.S, self.W, self.world = n, n // W, W, world
+        self.G = G = max(1, G)
+        self.NBUF = NBUF = max(4, 2 * G)  # two buckets of G slots: one being filled while the other is on the wire
+        prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
+        self.prm = prm
+        self.x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
+        self.packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
+                        for _ in range(NBUF)]  # fmt: skip
+        self.summ_all = torch.empty((NBUF, self.S, 8), dtype=torch.float32, device=device) if collide else None
+        self.transport = transport if collide else None
+        self.shape = shape
+        if collide:
+            self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=self.summ_all[b],
+                                               shape=shape, **prm)
+                          for b, (xo, pk) in enumerate(zip(self.x_outs, self.packeds))]  # fmt: skip
+            self.outputs = self.plans[0].outputs
+        else:
+            self.plans, self.outputs = None, None
+        if self.transport is not None:
+            self.gathered = [torch.empty((world, G, self.S, 8), dtype=torch.float32, device=device) for _ in range(NBUF // G)]
+            self.selected = [torch.empty((G, 4), dtype=torch.int32, device=device) for _ in range(NBUF // G)]
+            self.constraints = DEFAULT_CONSTRAINTS
+            self.aux = torch.cuda.Stream(device=device)
+        else:
+            self.gathered = self.selected = self.aux = None
+        self.n_streams = max(1, min(n_streams, NBUF))
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream(device))
+        self.launched = [torch.cuda.Event() for _ in self.streams]  # "this stream's launches of the bucket are enqueued"
+        self.bucket_done = [None] * (NBUF // G)  # recorded on aux when the bucket's collective + selection have completed
+        self.step_no = 0
+
+    def launch(self):
+        """one launch on torch's current stream (ring slot 0)"""
+        if self.collide:
+            self.plans[0].launch()
+        else:
+            self.robot.lm_pose_steps(self.x0, self.target, n_steps=self.K, clamp=True, x_out=self.x_outs[0], want_errors=True,
+                                     shape=self.shape, **self.prm)  # fmt: skip
+
+    def step(self):
+        if not self.collide:
+            return self.launch()
+        b = self.step_no % self.NBUF
+        self.step_no += 1
+        st = self.streams[b % self.n_streams]
+        if self.transport is None:
+            self.plans[b].launch_on(st)
+            return
+        bucket = b // self.G
+        if self.bucket_done[bucket] is not None:
+            st.wait_event(self.bucket_done[bucket])  # this bucket's slots were on the wire 2 G steps ago
+        self.plans[b].launch_on(st)
+        if b % self.G == self.G - 1:  # the bucket is complete: gather its G summaries from every rank and consume them
+            self.gather_bucket(bucket)
+
+    def gather_bucket(self, bucket):
+        G = self.G
+        for k, s_k in enumerate(self.streams):
+            self.launched[k].record(s_k)
+            self.aux.wait_event(self.launched[k])
+        with torch.cuda.stream(self.aux):
+            self.transport.all_gather(self.gathered[bucket], self.summ_all[bucket * G : (bucket + 1) * G])
+            # the consumer (cppflow/optimization_utils.py:856-909 over ALL ranks' seeds, one row of `selected` per step)
+            self.robot.select_valid_seed(self.gathered[bucket], self.constraints, out=self.selected[bucket])
+            done = self.bucket_done[bucket] if self.bucket_done[bucket] is not None else torch.cuda.Event()
+            done.record(self.aux)
+            self.bucket_done[bucket] = done
+
+    def drain(self):
+        if self.aux is not None:
+            if self.step_no % self.G != 0:  # a partly filled bucket: its summaries are exchanged too before the clock stops
+                self.gather_bucket((self.step_no % self.NBUF) // self.G)
+                self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
+            self.aux.synchronize()
+
+    def timed(self, steps, warmup, prewarm_ms, barrier):
+        """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then exactly `steps`
+        steps between barrier + synchronize pairs.  Returns this rank's elapsed seconds."""
+        # the pre-warm is time-based, so it must not contain collectives (ranks would issue different numbers of them):
+        # bare launches round-robin over the ring slots and streams
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+            for i in range(48):
+                if self.collide:
+                    self.plans[i % self.NBUF].launch_on(self.streams[i % self.n_streams])
+                else:
+                    self.launch()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.step()
+        self.drain()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.drain()
+        barrier()
+        return time.perf_counter() - t0
+
+    def host_enqueue_us(self):
+        """diagnostic: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)"""
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(64):
+            self.step()
+        t = (time.perf_counter() - th) / 64
+        self.drain()
+        torch.cuda.synchronize()
+        return 1e6 * t
+
+    def kernel_ms(self, reps):
+        """isolated launch duration: HIP events bracketing single launches on the launch stream (torch's current stream IS
+        the stream the kernel is launched on); no collective inside the bracket"""
+        kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in kev:
+            a.record()
+            self.launch()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in kev]))
+
+
+def dryrun(args, world, rank):
+    """CPPF_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, no GPU): the rank choreography of an N > 1 run without a single
+    kernel -- gloo process group, seed sharding, one all-gather of [S_local, 8] stand-in summaries (the seed indices),
+    the host-side seed selection over all ranks' seeds, max-over-ranks, ONE JSON line from rank 0.  It measures nothing and
+    says so (`value` null, `data` "dryrun")."""
+    import torch.distributed as dist
+
+    from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
+    from cppflow_amd.distributed import allgather_seed_summaries, drop_padding, padded_shard_size, seed_shard, shard_counts
+    from cppflow_amd.evaluation_utils import seed_metrics_are_below_threshold
+
+    if os.environ.get("CPPF_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)  # gloo / RCCL print banners on stdout; it carries exactly ONE JSON line
+    os.dup2(2, 1)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    S, W = args.seeds, args.waypoints
+    b, e = seed_shard(S, rank, world)
+    S_pad = padded_shard_size(S, W, world)
+    mine = torch.zeros((S_pad, 8), dtype=torch.float32)
+    mine[: e - b, 7] = torch.arange(b, e, dtype=torch.float32)  # stand-in for the summed cost: the global seed index
+    mine[e - b :] = float("inf")  # filler seeds can never be selected
+    allseeds = drop_padding(allgather_seed_summaries(mine), S_pad, shard_counts(S, world))
+    valid = [i for i in range(allseeds.shape[0]) if seed_metrics_are_below_threshold(DEFAULT_CONSTRAINTS, allseeds[i, :4])[0]]
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
+        print(json.dumps({"metric": "LM-IK iterations/sec (seeds x waypoints)", "value": None, "unit": "LM-IK iterations/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "strong",
+                          "data": "dryrun (no GPU: launcher and collective choreography only)",
+                          "config": {"world_size": dist.get_world_size(), "seeds_total": S, "seeds_per_gpu_padded": S_pad,
+                                     "gathered_seed_ids": [int(v) for v in allseeds[:, 7]], "n_valid": len(valid),
+                                     "max_rank": int(t.item())}}), flush=True)  # fmt: skip
+        os.dup2(2, 1)
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:  # checked before anything touches the GPU
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` (it starts its own "
+                 f"ranks) or launch N ranks with torch.distributed.run and pass the same --gpus N")  # fmt: skip
+
+    global torch
+    import torch
+
+    if os.environ.get("CPPF_BENCH_DRYRUN", "0") == "1":
+        return dryrun(args, world, rank)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CPPF_BENCH_SHARE_GPU=1: rehearsal of the N > 1 code path on a one-GPU box (every rank on device 0, host-staged gloo)
+    share_gpu = os.environ.get("CPPF_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = 0 if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {dev_index} but only {torch.cuda.device_count()} are visible")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     saved_stdout_fd = None
+    transport = None
     # CPPF_BENCH_FORCE_DIST=1 initialises the RCCL process group even for one rank (rehearses the N > 1 code path)
     force_dist = os.environ.get("CPPF_BENCH_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
@@ -297,157 +601,190 @@ def main():
         sys.stdout.flush()
         saved_stdout_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            transport = HostStagedGather(dist)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+            transport = RcclGather(dist)
+        assert dist.get_world_size() == world
 
+    from cppflow_amd import _hip
+    from cppflow_amd.distributed import allgather_seed_outputs, seed_shard
     from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
     from cppflow_amd.robots import get_robot
     from cppflow_amd.search import DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC, DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE
 
     robot = get_robot(args.robot)
-    d, S, W, K = robot.ndof, args.seeds, args.waypoints, args.lm_steps
-    n = S * W
+    d, W, K = robot.ndof, args.waypoints, args.lm_steps
     collide = not args.no_collide
     obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if (collide and args.config != "C3") else []
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
+    shape = {"auto": _hip.SHAPE_AUTO, "row": _hip.SHAPE_ROW, "quad": _hip.SHAPE_QUAD}[args.shape]
 
-    if args.inputs == "problem":
-        x0, target, inputs_desc = make_inputs_problem(robot, S, W, device, seed=rank)
-    else:
-        x0, target = make_inputs(robot, S, W, device, seed=rank)
-        inputs_desc = "per waypoint q* ~ U(limits), target = FK(q*), seeds = clamp(q* + 0.1 randn) (SURVEY 8d fall-back inputs)"
-    G = max(1, args.gather_every)  # steps per collective (N > 1): the [S,8] summaries of G consecutive steps travel together
-    NBUF = max(4, 2 * G)  # ring of output buffer sets: two buckets of G steps, one being filled while the other is on the wire
-    x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
-    packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
-               for _ in range(NBUF)]  # fmt: skip
-    x_out, packed = x_outs[0], packeds[0]
-    prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
-    # per-seed summaries (8 floats per seed) are what every rank needs from every other rank; the fused launch of ring slot b
-    # writes summ_all[b] itself (in-kernel epilogue when W is 64 / 128 / 256, else a second reduction kernel issued by the same
-    # C call); a bucket of G slots is all-gathered in one collective on an auxiliary stream, overlapping the next bucket's kernels
-    summ_all = torch.empty((NBUF, S, 8), dtype=torch.float32, device=device) if collide else None
-    use_dist = dist is not None and collide
-    gathered = [torch.empty((world, G, S, 8), dtype=torch.float32, device=device) for _ in range(NBUF // G)] if use_dist else None
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    S_cfg = args.seeds
+    if scaling == "strong":
+        assert S_cfg % world == 0 and (S_cfg // world) >= 1, f"--seeds {S_cfg} must be a multiple of --gpus {world} under strong scaling"
+    S_main = S_cfg // world if scaling == "strong" else S_cfg
 
-    if collide:
-        plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=summ_all[b], **prm)
-                 for b, (xo, pk) in enumerate(zip(x_outs, packeds))]  # fmt: skip
-        launch, outputs = plans[0].launch, plans[0].outputs
-    else:
-        pos_err = torch.empty(n, dtype=torch.float32, device=device)
-
-        def launch():
-            robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=x_out, want_errors=True, **prm)
-
-        outputs = None
-
-    step_no = [0]
-
-    # --streams 2: consecutive steps are independent batches (own output buffers per ring slot), so they alternate between
-    # two HIP streams and one launch's tail overlaps the next one's ramp-up
-    n_streams = max(1, min(args.streams, NBUF))
-    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream(device))
-    aux = torch.cuda.Stream(device=device) if use_dist else None  # the collectives are issued (and waited for) here
-    launched = [torch.cuda.Event() for _ in streams]  # "this stream's launches of the bucket are enqueued"
-    bucket_done = [None] * (NBUF // G)  # recorded on aux when the bucket's collective has completed
-
-    def step():
-        if not collide:
-            return launch()
-        b = step_no[0] % NBUF
-        step_no[0] += 1
-        st = streams[b % n_streams]
-        if not use_dist:
-            plans[b].launch_on(st)
-            return
-        bucket = b // G
-        if bucket_done[bucket] is not None:
-            st.wait_event(bucket_done[bucket])  # this bucket's slots were on the wire 2 G steps ago
-        plans[b].launch_on(st)
-        if b % G == G - 1:  # the bucket is complete: gather its G summaries from every rank
-            gather_bucket(bucket)
-
-    def gather_bucket(bucket):
-        for k, s_k in enumerate(streams):
-            launched[k].record(s_k)
-            aux.wait_event(launched[k])
-        with torch.cuda.stream(aux):
-            work = dist.all_gather_into_tensor(gathered[bucket], summ_all[bucket * G : (bucket + 1) * G], async_op=True)
-            work.wait()  # stream-side: aux waits for the communicator's stream
-            done = bucket_done[bucket] if bucket_done[bucket] is not None else torch.cuda.Event()
-            done.record(aux)
-            bucket_done[bucket] = done
-
-    def drain():
-        if aux is not None:
-            if step_no[0] % G != 0:  # a partly filled bucket: its summaries are exchanged too before the clock stops
-                gather_bucket((step_no[0] % NBUF) // G)
-                step_no[0] += G - step_no[0] % G  # the next step starts a fresh bucket
-            aux.synchronize()
+    def inputs_for(S_local, mode, kind):
+        """(x0 [S_local*W, d], target, description).  Strong scaling: every rank builds the SAME S_cfg seeds (seed 0) and keeps
+        its `seed_shard`; weak scaling: rank r builds its own S_cfg seeds (seed r)."""
+        gen_seed = 0 if mode == "strong" else rank
+        if kind == "problem":
+            x_all, tgt, desc = make_inputs_problem(robot, S_cfg, W, device, seed=gen_seed)
+        else:
+            x_all, tgt = make_inputs(robot, S_cfg, W, device, seed=gen_seed)
+            desc = "per waypoint q* ~ U(limits), target = FK(q*), seeds = clamp(q* + 0.1 randn) (SURVEY 8d fall-back inputs)"
+        if mode == "strong" and world > 1:
+            b, e = seed_shard(S_cfg, rank, world)
+            x_all = x_all[b * W : e * W].contiguous()
+        return x_all, tgt, desc
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed pre-warm: the GPU needs tens of milliseconds of continuous work to settle at its sustained clocks and to fill
-    # the two-stream pipeline (a 200-step run after 10 warm-up steps measures 54 us per step, the same run after 25 ms of
-    # work 46 us); the W warm-up steps of the contract follow it, then exactly K timed steps between barriers.
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(50):
-            step()
-        drain()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # diagnostic, outside the timed region: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)
-    th = time.perf_counter()
-    for i in range(64):
-        step()
-    t_enqueued = (time.perf_counter() - th) / 64 * args.steps
-    drain()
-    torch.cuda.synchronize()
-    # kernel duration: a second, untimed pass with HIP events bracketing each launch on the launch stream (torch's
-    # current stream is the stream the kernel is launched on); no collective inside the bracket
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for i in range(args.steps):
-        kev[i][0].record()
-        launch()
-        kev[i][1].record()
-    torch.cuda.synchronize()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kev]))
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        if dist is not None:
+            if share_gpu:
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    G = max(1, args.gather_every)
+    # a strong-scaling shard is a fraction of a wavefront per SIMD: two launches in flight cannot fill the chip, four can
+    n_streams = args.streams if args.streams > 0 else (4 if (scaling == "strong" and world > 1) else 2)
+
+    x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
+    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device)
+    n = run.n
+    elapsed = max_over_ranks(run.timed(args.steps, args.warmup, args.prewarm_ms, barrier))
+    host_us = run.host_enqueue_us()
+    kernel_ms = run.kernel_ms(min(max(args.steps, 50), 2000))
 
     # sanity on the result of the last step (not timed): most rows converged
+    outputs = run.outputs
     if outputs is None:
-        outputs = robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=x_out, want_errors=True, **prm)
-        del pos_err
+        outputs = robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=run.x_outs[0], want_errors=True, shape=shape, **run.prm)
     conv_frac = float((outputs["pos_err_m"] < 1e-4).float().mean().item())
+    selected = None
+    if run.selected is not None:
+        torch.cuda.synchronize()
+        selected = [int(v) for v in run.selected[0][0].cpu()]
+
+    # Once per planning call (not per step): every rank gets ALL ranks' per-row costs / masks and candidate paths with one
+    # all-gather each and runs dp_search over them (cppflow/search.py:146-173 consumes every candidate's cost row).  Untimed
+    # here, reported beside the headline: it precedes the LM iterations in the reference pipeline (planners.py:274 -> 402).
+    plan_search = None
+    if collide:
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k_all = run.S * (world if dist is not None else 1)
+        for rep in range(2):
+            ev0.record()
+            if dist is not None and world > 1 and not share_gpu:
+                g = allgather_seed_outputs(run.packeds[0], run.S, W)
+                q_all = torch.empty((world,) + tuple(run.x_outs[0].shape), dtype=torch.float32, device=device)
+                dist.all_gather_into_tensor(q_all, run.x_outs[0])
+                cost_all, q_all = g.ext_cost.contiguous(), q_all.view(k_all, W, d)
+            else:
+                k_all = run.S
+                cost_all = run.outputs["ext_cost"].view(run.S, W)
+                q_all = run.x_outs[0].view(run.S, W, d)
+            robot.dp_search(q_all, cost_all)
+            ev1.record()
+            torch.cuda.synchronize()
+        plan_search = {"candidates": k_all, "waypoints": W, "ms": ev0.elapsed_time(ev1),
+                       "allgather_bytes_per_rank": int(run.packeds[0].numel() + run.x_outs[0].numel() * 4) if (dist is not None and world > 1) else 0,
+                       "what": "all-gather of the packed per-row outputs + candidate paths, then cppf_dp_search over every rank's "
+                       "candidates (once per planning call; untimed, outside `value`)"}  # fmt: skip
+
+    def measure_sibling(S_local, mode, kind, streams, steps):
+        """a second workload / pipeline depth measured like the headline (same barriers, same max over ranks)"""
+        xs, tg, _ = inputs_for(S_local, mode, kind)
+        r2 = Runner(robot, xs, tg, K, collide, streams, G, transport, world, shape, device)
+        el = max_over_ranks(r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier))
+        km = r2.kernel_ms(min(max(steps, 50), 500))
+        rows = float(r2.n) * world
+        del r2
+        torch.cuda.empty_cache()
+        return {"value": rows * K * steps / el, "ms_per_step": 1e3 * el / steps, "kernel_ms": km, "streams": streams,
+                "rows_per_gpu": int(rows // world)}  # fmt: skip
+
+    siblings = {}
+    if not args.no_siblings:
+        sib_steps = min(args.steps, 1000)
+        if world > 1:
+            other = "weak" if scaling == "strong" else "strong"
+            if other == "weak" or S_cfg % world == 0:
+                S_o = S_cfg if other == "weak" else S_cfg // world
+                r = measure_sibling(S_o, other, args.inputs, 2 if other == "weak" else 4, sib_steps)
+                r["scaling"] = other
+                r["seeds_per_gpu"] = S_o
+                siblings[other + "_scaling"] = r
+        else:
+            siblings["one_stream"] = measure_sibling(S_main, scaling, args.inputs, 1, sib_steps)
+            if args.inputs == "problem":
+                siblings["random_inputs"] = measure_sibling(S_main, scaling, "random", n_streams, sib_steps)
 
     if rank == 0:
         iters = float(n) * K * args.steps * world
-        flops_launch = n * (K * algorithmic_flops_per_row_iter(d)
-                            + (algorithmic_flops_collision(robot.n_capsules, robot.n_collision_pairs, len(obstacles)) if collide else 0.0))
+        alg_flops = n * (K * algorithmic_flops_per_row_iter(d)
+                         + (algorithmic_flops_collision(robot.n_capsules, robot.n_collision_pairs, len(obstacles)) if collide else 0.0))  # fmt: skip
         bytes_launch = n * algorithmic_bytes_per_row(d, collide)
-        ach_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
-        ach_gbps = bytes_launch / (kernel_ms * 1e-3) / 1e9
+        t_k = kernel_ms * 1e-3
+        alg_tflops = alg_flops / t_k / 1e12
+        ach_gbps = bytes_launch / t_k / 1e9
+        rec = issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs)
+        roof = {
+            # the binding resource is the fp32 VALU issue rate (157.3 TFLOP/s of FMAs = one wave-instruction per SIMD per 2
+            # cycles); the contract's vocabulary has no word for it, so `bound` says what it is and `mfma_used` that no
+            # matrix instruction is issued on this path
+            "bound": "valu",
+            "mfma_used": False,
+            "peak": F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "kernel": "lm_fused_kernel" if shape != _hip.SHAPE_QUAD else "lm_quad_kernel",
+            "kernel_ms": kernel_ms,
+            "algorithmic": {
+                "tflops": alg_tflops,
+                "frac": alg_tflops / F32_PEAK_TFLOPS,
+                "note": "SURVEY 8d flop model (primal J^T J + d^3/3 Cholesky, every collision test counted) / kernel time: "
+                "what the reference's formulation would need, NOT what this kernel executes (dual 6x6 solve, broad-phase culls)",
+            },
+            "traffic": traffic_from_profiles(args.robot, run.S, W, K, collide),
+            "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
+        }
+        if rec is not None:
+            valu = float(rec["valu_insts_per_launch"])
+            exe_tflops = valu * 64.0 * float(rec["flops_per_valu_lane_op"]) / t_k / 1e12
+            issue_s = valu * 2.0 / N_SIMD / (CLOCK_GHZ * 1e9)
+            roof.update({
+                "achieved": exe_tflops,
+                "frac": exe_tflops / F32_PEAK_TFLOPS,
+                "basis": "executed flops: SQ_INSTS_VALU of the matching launch (profiles/r2_issue.json) x 64 lanes x flops per VALU "
+                "lane-op from the kernel's ISA (FMA = 2, mul / add = 1, moves / selects / compares = 0), / live kernel time",
+                "valu_issue_frac": issue_s / t_k,
+                "valu_issue_frac_at_step_rate": issue_s / (elapsed / args.steps),
+            })  # fmt: skip
+        else:
+            capped = alg_tflops / F32_PEAK_TFLOPS
+            roof.update({
+                "achieved": alg_tflops if capped <= 1.0 else None,
+                "frac": capped if capped <= 1.0 else None,
+                "basis": "algorithmic flop model (no SQ_INSTS_VALU record for this workload under profiles/)"
+                + ("" if capped <= 1.0 else "; the model counts collision tests the broad phase skips, so the fraction would exceed 1 and is withheld"),
+            })  # fmt: skip
+        roof["at_step_rate"] = {
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "batches_in_flight": run.n_streams,
+            "algorithmic_tflops": alg_flops / (elapsed / args.steps) / 1e12,
+        }
         line = {
             "metric": "LM-IK iterations/sec (seeds x waypoints)",
             "value": iters / elapsed,
@@ -457,52 +794,44 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.robot}{'__2cubes geometry' if obstacles else ''}, {S} seeds/GPU x {W} waypoints x {d}-DoF, K={K} fused LM "
-                f"iterations per launch" + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
+                "workload": f"{args.robot}{'__2cubes geometry' if obstacles else ''}, "
+                + (f"{S_cfg} seeds sharded over {world} GPU(s) = {run.S} seeds/GPU" if scaling == "strong" else f"{run.S} seeds/GPU")
+                + f" x {W} waypoints x {d}-DoF, K={K} fused LM iterations per launch"
+                + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
                 "inputs": inputs_desc,
-                "streams": n_streams,
+                "streams": run.n_streams,
+                "kernel_shape": args.shape,
+                "early_out": "off (every row runs all K iterations: the metric counts K iterations per row)",
                 "prewarm_ms": args.prewarm_ms,
-                "host_enqueue_us_per_step": 1e6 * t_enqueued / args.steps,
+                "host_enqueue_us_per_step": host_us,
                 "robot": args.robot,
-                "seeds_per_gpu": S,
+                "seeds_total": S_cfg * (world if scaling == "weak" else 1),
+                "seeds_per_gpu": run.S,
                 "waypoints": W,
                 "ndof": d,
                 "lm_iterations_per_step": K,
                 "collision_fused": collide,
                 "obstacles": len(obstacles),
+                "world_size": dist.get_world_size() if dist is not None else 1,
+                "collective_backend": (None if dist is None else ("gloo, host-staged (one-GPU rehearsal: NOT a multi-GPU result)" if share_gpu else "nccl (RCCL)")),
                 "per_step": "one fused launch incl. the per-seed summary reduction"
-                + (f" + async all-gather of the [S,8] summaries, {G} steps per collective" if gathered is not None else ""),
-                "allgather_bytes_per_rank_per_step": int(summ_all[0].numel() * 4) if gathered is not None else 0,
-                "steps_per_allgather": G if gathered is not None else 0,
+                + (f" + async all-gather of the [S,8] summaries, {G} steps per collective, + x_is_valid seed selection over all "
+                   f"{run.S * world} seeds of every step on each rank" if run.gathered is not None else ""),
+                "allgather_bytes_per_rank_per_step": int(run.summ_all[0].numel() * 4) if run.gathered is not None else 0,
+                "steps_per_allgather": G if run.gathered is not None else 0,
+                "selected_seed_last_bucket": selected,
                 "converged_frac_pos_err_lt_1e-4": conv_frac,
             },
-            "roofline": {
-                "bound": "mfma",
-                "achieved": ach_tflops,
-                "peak": F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": ach_tflops / F32_PEAK_TFLOPS,
-                "traffic": traffic_from_profiles(args.robot, S, W, K, collide),
-                "kernel": "lm_fused_kernel",
-                "kernel_ms": kernel_ms,
-                "note": "binding resource is the fp32 FMA rate (157.3 TFLOP/s: vector peak == f32-input MFMA peak); the "
-                "kernel issues VALU FMAs, no MFMA instructions.  achieved = algorithmic flops (SURVEY 8d) / kernel time",
-                "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
-                # the isolated launch has only 4 rows per SIMD lane in flight (262 144 rows on 65 536 lanes): its loop is
-                # partly latency-bound; with two independent batches in flight (the timed configuration) the same kernels
-                # deliver this rate per GPU
-                "at_step_rate": {
-                    "achieved": flops_launch / (elapsed / args.steps) / 1e12,
-                    "frac": flops_launch / (elapsed / args.steps) / 1e12 / F32_PEAK_TFLOPS,
-                    "batches_in_flight": n_streams,
-                },
-            },
+            "roofline": roof,
         }
+        if plan_search is not None:
+            line["plan_search"] = plan_search
+        line.update(siblings)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_torch(args.robot, obstacles, d, W, K)
             line["cpu_baseline_c"] = cpu_baseline_c(args.robot, obstacles, d, W, K)

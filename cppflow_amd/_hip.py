@@ -52,6 +52,25 @@ class LmParams(ctypes.Structure):
         ("alpha_rotation", _f),
         ("n_steps", _i32),
         ("clamp", _i32),
+        ("tol_pos_m", _f),
+        ("tol_rot_rad", _f),
+        ("shape", _i32),
+    ]
+
+
+SHAPE_AUTO, SHAPE_ROW, SHAPE_QUAD = 0, 1, 2
+
+
+class Constraints(ctypes.Structure):
+    """struct cppf_constraints"""
+
+    _fields_ = [
+        ("max_allowed_position_error_cm", _f),
+        ("max_allowed_rotation_error_deg", _f),
+        ("max_allowed_mjac_deg", _f),
+        ("max_allowed_mjac_cm", _f),
+        ("self_collisions_ignored", _i32),
+        ("env_collisions_ignored", _i32),
     ]
 
 
@@ -81,6 +100,7 @@ class LmOutputs(ctypes.Structure):
         ("min_self", _vp),
         ("min_env", _vp),
         ("seed_summary", _vp),
+        ("n_iters", _vp),
     ]
 
 
@@ -117,6 +137,9 @@ SIGNATURES = {
                                                              _vp, _vp, _vp]),
     "cppf_mjacs": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     "cppf_plan_metrics": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "cppf_select_valid_seed": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.POINTER(Constraints), _vp, _vp]),
+    "cppf_select_valid_seed_gathered": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.POINTER(Constraints), _vp, _vp]),
     "cppf_seed_summary": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cppf_lm_full_step": (
         ctypes.c_int,

@@ -420,6 +420,11 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     prm.clamp = params->clamp;
     prm.n = (int)n;
     prm.W = W;
+    CPPF_REQUIRE(params->tol_pos_m >= 0.f && params->tol_rot_rad >= 0.f, "early-out tolerances must be >= 0");
+    CPPF_REQUIRE((params->tol_pos_m > 0.f) == (params->tol_rot_rad > 0.f), "set both early-out tolerances or neither");
+    CPPF_REQUIRE(!(params->tol_pos_m > 0.f && (out->J_out || out->e_out)), "early-out is not combinable with J_out / e_out");
+    prm.tol_pos2 = params->tol_pos_m * params->tol_pos_m;
+    prm.tol_rot2 = params->tol_rot_rad * params->tol_rot_rad;
     const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self ||
                       out->min_env || out->seed_summary;
     hipStream_t st = (hipStream_t)stream;
@@ -598,6 +603,30 @@ int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, con
                     hipLaunchKernelGGL((seed_summary_kernel<D>), dim3(S), dim3(64), 0, st, robot->chain, S, W, x, ext_cost,
                                        pos_err_m, rot_err_rad, self_mask, env_mask, jlim_mask, out));
     return check_launch(robot);
+}
+
+int cppf_select_valid_seed_gathered(const cppf_robot* robot, const float* gathered, int n_chunks, int n_groups, int S_chunk,
+                                    const cppf_constraints* constraints, int32_t* out, void* stream) {
+    CPPF_ENTER(robot);
+    CPPF_REQUIRE(n_chunks >= 1 && n_groups >= 1 && S_chunk >= 0, "n_chunks, n_groups must be >= 1 and S_chunk >= 0");
+    CPPF_REQUIRE((size_t)n_chunks * S_chunk <= 0x7fffffffu, "n_chunks * S_chunk exceeds 2^31-1 seeds");
+    CPPF_REQUIRE(constraints && out && (gathered || S_chunk == 0), "NULL pointer");
+    CPPF_REQUIRE(((uintptr_t)gathered & 15u) == 0, "the summaries must be 16-byte aligned");
+    SelectK k;
+    k.thr[0] = constraints->max_allowed_position_error_cm;
+    k.thr[1] = constraints->max_allowed_rotation_error_deg;
+    k.thr[2] = constraints->max_allowed_mjac_deg;
+    k.thr[3] = constraints->max_allowed_mjac_cm;
+    k.ignore_self = constraints->self_collisions_ignored;
+    k.ignore_env = constraints->env_collisions_ignored;
+    k.S_chunk = S_chunk, k.n_chunks = n_chunks, k.n_groups = n_groups;
+    hipLaunchKernelGGL(select_valid_seed_kernel, dim3((unsigned)n_groups), dim3(256), 0, (hipStream_t)stream, gathered, k, out);
+    return check_launch(robot);
+}
+
+int cppf_select_valid_seed(const cppf_robot* robot, const float* seed_summary, int S, const cppf_constraints* constraints,
+                           int32_t* out, void* stream) {
+    return cppf_select_valid_seed_gathered(robot, seed_summary, 1, 1, S, constraints, out, stream);
 }
 
 int cppf_plan_metrics(const cppf_robot* robot, const float* x, const float* target, int S, int W, const uint8_t* self_mask,

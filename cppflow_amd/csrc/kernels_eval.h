@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void plan_metrics_kernel(const ChainK ch, const
         fk_ee<RB>(rb, q, R, p);
         pose_metrics(Rt, tt, R, p, pe, re);
         const float pc = 100.f * pe, rd = rad2deg * re;
-        mx[0] = fmaxf(mx[0], pc), mx[1] = fmaxf(mx[1], rd);
+        mx[0] = fmaxf(mx[0], nan_to_inf(pc)), mx[1] = fmaxf(mx[1], nan_to_inf(rd));
         sm[0] += pc, sm[1] += rd;
 #pragma unroll
         for (int j = 0; j < D; ++j) sm[4] += (float)((q[j] < ch.lo[j]) + (ch.hi[j] < q[j]));  // evaluation_utils.py:24
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(64) void plan_metrics_kernel(const ChainK ch, const
                 const float dq = qn[j] - q[j];
                 if (rb.pris(j)) {
                     const float a = fabsf(dq);
-                    mx[3] = fmaxf(mx[3], 100.f * a), sm[3] += a;
+                    mx[3] = fmaxf(mx[3], nan_to_inf(100.f * a)), sm[3] += a;
                 } else {
                     const float a = fabsf(wrap_pi(dq));
-                    mx[2] = fmaxf(mx[2], rad2deg * a), sm[2] += a;
+                    mx[2] = fmaxf(mx[2], nan_to_inf(rad2deg * a)), sm[2] += a;
                 }
             }
         }
@@ -93,8 +93,8 @@ __global__ __launch_bounds__(64) void seed_summary_kernel(const ChainK ch, int S
     float mp = 0.f, mr = 0.f, mrev = 0.f, mpri = 0.f, ns = 0.f, ne = 0.f, nj = 0.f, sc = 0.f;
     for (int w = threadIdx.x; w < W; w += 64) {
         const size_t row = (size_t)s * W + w;
-        mp = fmaxf(mp, 100.f * pos_err[row]);
-        mr = fmaxf(mr, rad2deg * rot_err[row]);
+        mp = fmaxf(mp, nan_to_inf(100.f * pos_err[row]));
+        mr = fmaxf(mr, nan_to_inf(rad2deg * rot_err[row]));
         ns += (float)self_mask[row];
         ne += (float)env_mask[row];
         nj += (float)jlim_mask[row];
@@ -107,9 +107,9 @@ __global__ __launch_bounds__(64) void seed_summary_kernel(const ChainK ch, int S
             for (int j = 0; j < D; ++j) {
                 const float dq = qn[j] - q[j];
                 if ((ch.pris_mask >> j) & 1u)
-                    mpri = fmaxf(mpri, fabsf(100.f * dq));
+                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq)));
                 else
-                    mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
+                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wrap_pi(dq))));
             }
         }
     }
@@ -127,5 +127,58 @@ __global__ __launch_bounds__(64) void seed_summary_kernel(const ChainK ch, int S
     if (threadIdx.x == 0) {
         float* o = out + (size_t)s * 8;
         o[0] = mp, o[1] = mr, o[2] = mrev, o[3] = mpri, o[4] = ns, o[5] = ne, o[6] = nj, o[7] = sc;
+    }
+}
+
+// ---- x_is_valid's seed selection over [S,8] summaries (cppflow/optimization_utils.py:856-909) ------------------------------------
+// One workgroup per group of seeds: lanes stride over the seeds, then a min / sum / argmin reduction through LDS.  The seeds
+// of group g are `n_chunks` chunks of `S_chunk` rows at row offsets (r * n_groups + g) * S_chunk -- the layout an
+// all-gather of [n_groups, S_chunk, 8] buffers from n_chunks ranks leaves behind (n_chunks = n_groups = 1: a plain [S,8]).
+struct SelectK {
+    float thr[4];
+    int32_t ignore_self, ignore_env;
+    int32_t S_chunk, n_chunks, n_groups;
+};
+
+__global__ __launch_bounds__(256) void select_valid_seed_kernel(const float* __restrict__ summary, const SelectK k,
+                                                                int32_t* __restrict__ out) {
+    __shared__ int s_first[256];
+    __shared__ int s_count[256];
+    __shared__ float s_cost[256];
+    __shared__ int s_arg[256];
+    const int tid = threadIdx.x;
+    int first = 0x7fffffff, count = 0, arg = 0x7fffffff;
+    float best = INFINITY;
+    const int g = blockIdx.x, S = k.S_chunk * k.n_chunks;
+    out += 4 * g;
+    for (int s = tid; s < S; s += 256) {
+        const size_t row = ((size_t)(s / k.S_chunk) * k.n_groups + g) * k.S_chunk + (size_t)(s % k.S_chunk);
+        const float4 a = reinterpret_cast<const float4*>(summary)[2 * row], b = reinterpret_cast<const float4*>(summary)[2 * row + 1];
+        // strict '<' on the maxima (evaluation_utils.py:41-60): a NaN / inf maximum is "not below"
+        bool ok = a.x < k.thr[0] && a.y < k.thr[1] && a.z < k.thr[2] && a.w < k.thr[3];
+        ok = ok && (k.ignore_self || !(b.x > 0.f)) && (k.ignore_env || !(b.y > 0.f));
+        if (ok) {
+            first = s < first ? s : first;
+            ++count;
+        }
+        if (b.w < best) best = b.w, arg = s;  // s ascends per lane: first minimum kept
+    }
+    s_first[tid] = first, s_count[tid] = count, s_cost[tid] = best, s_arg[tid] = arg;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            s_first[tid] = s_first[tid + off] < s_first[tid] ? s_first[tid + off] : s_first[tid];
+            s_count[tid] += s_count[tid + off];
+            const float c = s_cost[tid + off];
+            const int a = s_arg[tid + off];
+            if (c < s_cost[tid] || (c == s_cost[tid] && a < s_arg[tid])) s_cost[tid] = c, s_arg[tid] = a;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = s_first[0] == 0x7fffffff ? -1 : s_first[0];
+        out[1] = s_count[0];
+        out[2] = s_arg[0] == 0x7fffffff ? -1 : s_arg[0];
+        out[3] = 0;
     }
 }

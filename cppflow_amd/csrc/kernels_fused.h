@@ -66,11 +66,11 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
         qn = (lane == 63) ? s_q[nw][j] : qn;  // (stale but unused when wps == 1: has_next is false there)
         const float dq = qn - q[j];
         const bool pr = rb.pris(j);
-        const float a = pr ? fabsf(100.f * dq) : fabsf(rad2deg * wrap_pi(dq));
+        const float a = nan_to_inf(pr ? fabsf(100.f * dq) : fabsf(rad2deg * wrap_pi(dq)));
         mpri = fmaxf(mpri, pr ? a : 0.f);
         mrev = fmaxf(mrev, pr ? 0.f : a);
     }
-    float v[8] = {100.f * rs.pos_err, rad2deg * rs.rot_err, has_next ? mrev : 0.f, has_next ? mpri : 0.f,
+    float v[8] = {nan_to_inf(100.f * rs.pos_err), nan_to_inf(rad2deg * rs.rot_err), has_next ? mrev : 0.f, has_next ? mpri : 0.f,
                   (float)rs.self_hit, (float)rs.env_hit, (float)rs.jl, rs.cost};
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = active ? v[k] : 0.f;
@@ -111,13 +111,21 @@ __device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restr
     load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
 }
 
+// One LM iteration of one row.  Returns true when the row was ALREADY converged at this linearisation point (early-out
+// tolerances of cppf_lm_params, off when 0): such a row is left untouched -- the reference's loop likewise stops stepping
+// once the pose is valid (cppflow/optimization.py:251-258, 326-358).
 template <class RB>
-__device__ __forceinline__ void lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
+__device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
                                                const float (&Rt)[9], const float (&tt)[3], float (&q)[RB::D]) {
     constexpr int D = RB::D;
     float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
     fk_ee_axes<RB>(rb, q, R, p, ax, og);
     pose_error(Rt, tt, R, p, e);
+    bool conv = false;
+    if (prm.tol_pos2 > 0.f) {  // wave-uniform
+        conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
+        if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
+    }
     jacobian_from_axes<RB>(rb, p, ax, og, J);
     lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
     if (last) {
@@ -134,9 +142,18 @@ __device__ __forceinline__ void lm_row_iterate(const RB& rb, const LmK& prm, con
             for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
         }
     }
+    if (prm.tol_pos2 > 0.f) {  // wave-uniform: the predicated update only exists on the early-out path
+        if (!conv) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) q[j] += delta[j];
+            if (prm.clamp) clamp_row<RB>(rb, q);
+        }
+        return conv;
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) q[j] += delta[j];
     if (prm.clamp) clamp_row<RB>(rb, q);
+    return false;
 }
 
 template <class RB, int COLL>
@@ -212,7 +229,25 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
     if (active) {
         float Rt[9], tt[3];
         lm_row_load<RB>(prm, x_in, target, row, q, Rt, tt);
-        for (int it = 0; it < prm.n_steps; ++it) lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+        // A non-finite input stays non-finite in the reference (torch.clamp and the solve propagate NaN); here fminf / fmaxf
+        // of the clamp would turn it into a joint limit, so such a row is poisoned after the loop instead (once per launch).
+        float chk = tt[0] + tt[1] + tt[2];
+#pragma unroll
+        for (int j = 0; j < D; ++j) chk += q[j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) chk += Rt[k];
+        const bool bad = !(fabsf(chk) < INFINITY);
+        int iters = 0;
+        for (int it = 0; it < prm.n_steps; ++it) {
+            const bool conv = lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+            iters += conv ? 0 : 1;
+            if (prm.tol_pos2 > 0.f && __builtin_amdgcn_ballot_w64(!conv) == 0ull) break;
+        }
+        if (out.n_iters) out.n_iters[row] = iters;
+        if (bad) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) q[j] = __builtin_nanf("");
+        }
         lm_row_finish<RB, COLL>(rb, co, out, lds, tid, row, Rt, tt, q, rs);
     }
     if constexpr (COLL != 0) {
@@ -357,7 +392,8 @@ __global__ __launch_bounds__(kBlock) void clamp_kernel(const ChainK ch, size_t t
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= total) return;
     const int j = (int)(i % (size_t)ch.ndof);
-    x[i] = fminf(fmaxf(x[i], ch.lo[j]), ch.hi[j]);
+    const float v = x[i];
+    x[i] = v != v ? v : fminf(fmaxf(v, ch.lo[j]), ch.hi[j]);  // torch.clamp keeps a NaN (fminf / fmaxf would drop it)
 }
 
 // one wavefront per seed: lanes stride over the seed's W waypoints, then a 64-lane butterfly max
@@ -378,8 +414,8 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
         load_target(target, w, Rt, tt);
         fk_ee<RB>(rb, q, R, p);
         pose_metrics(Rt, tt, R, p, pe, re);
-        mp = fmaxf(mp, 100.f * pe);
-        mr = fmaxf(mr, rad2deg * re);
+        mp = fmaxf(mp, nan_to_inf(100.f * pe));
+        mr = fmaxf(mr, nan_to_inf(rad2deg * re));
         if (w + 1 < W) {
             float qn[D];
             load_x<D>(x, row + 1, qn);
@@ -387,9 +423,9 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
             for (int j = 0; j < D; ++j) {
                 const float dq = qn[j] - q[j];
                 if (rb.pris(j))
-                    mpri = fmaxf(mpri, fabsf(100.f * dq));
+                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq)));
                 else
-                    mrev = fmaxf(mrev, fabsf(rad2deg * wrap_pi(dq)));
+                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wrap_pi(dq))));
             }
         }
     }

@@ -54,6 +54,7 @@ struct LmK {
     float lm_lambda, a_pos, a_rot;
     int32_t n_steps, clamp;
     int32_t n, W;
+    float tol_pos2, tol_rot2;  // early-out (cppf_lm_params.tol_*), squared; 0 = off
 };
 
 // ---- multiply / fma by a chain constant --------------------------------------------------------------------------------------
@@ -195,6 +196,10 @@ __device__ __forceinline__ void frame_identity(float (&R)[9], float (&p)[3]) {
 __device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2) {
     return CPPF_FMA(a2, b2, CPPF_FMA(a1, b1, a0 * b0));
 }
+
+// torch.max propagates a NaN, fmaxf drops it: the per-seed maxima map a NaN to +inf first, so that a seed holding a NaN row
+// compares "not below threshold" exactly as the reference's `error.max() < thr` does (cppflow/evaluation_utils.py:41-42)
+__device__ __forceinline__ float nan_to_inf(float v) { return v != v ? INFINITY : v; }
 
 // clamps as one v_med3_f32: for lo <= hi and a non-NaN x the median of (x, lo, hi) IS the clamp, value for value
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

@@ -36,6 +36,14 @@ def _require_device_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> t
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _require_output_tensor(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    """A caller-supplied OUTPUT buffer: the kernel writes through its data_ptr(), so a non-contiguous tensor cannot be
+    silently replaced by a contiguous copy (the caller's buffer would never be written)."""
+    t = _require_device_tensor(t, name, dtype) if t.is_contiguous() else None
+    assert t is not None, f"{name} is an output buffer and must be contiguous"
+    return t
+
+
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -298,6 +306,10 @@ class Robot:
         x_out: Optional[torch.Tensor] = None,
         packed_out: Optional[torch.Tensor] = None,
         summary_out: Optional[torch.Tensor] = None,
+        tol_pos_m: float = 0.0,
+        tol_rot_rad: float = 0.0,
+        want_iters: bool = False,
+        shape: int = _hip.SHAPE_AUTO,
     ) -> Dict[str, torch.Tensor]:
         """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
         (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7].
@@ -308,7 +320,12 @@ class Robot:
         every rank; it implies want_errors and want_collisions.  `summary_out` (fp32 [S,8], fields
         SEED_SUMMARY_FIELDS) receives the per-seed reduction of `seed_summary`, computed inside the same launch when
         W is 64, 128 or 256 and by a second kernel otherwise (which then needs the per-row outputs, i.e. `packed_out` or
-        want_errors + want_collisions)."""
+        want_errors + want_collisions).
+
+        `tol_pos_m` / `tol_rot_rad` (both or neither) switch on the in-launch early-out: rows already below tolerance at the
+        start of an iteration are left untouched and a wavefront of such rows leaves the loop (cppflow/optimization.py:326-358
+        stops the same way once the pose is valid); `want_iters` returns the per-row number of steps applied.  `shape` picks
+        the kernel shape (`_hip.SHAPE_ROW`: one row per lane; `_hip.SHAPE_QUAD`: four lanes per row; default: by batch size)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
@@ -316,7 +333,7 @@ class Robot:
         assert W > 0 and n % W == 0, f"x has {n} rows, not a multiple of the {W} target waypoints"
         dev = x.device
         if x_out is not None:
-            x_out = self._x2d(x_out, "x_out")
+            x_out = _require_output_tensor(x_out, "x_out")
             assert x_out.shape == x.shape and x_out.device == dev
         res: Dict[str, torch.Tensor] = {"x": x_out if x_out is not None else torch.empty_like(x)}
         out = _hip.LmOutputs()
@@ -353,7 +370,11 @@ class Robot:
             _check_summary_buffer(summary_out, n // W, dev)
             out.seed_summary = summary_out.data_ptr()
             res["seed_summary"] = summary_out
-        prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
+        if want_iters:
+            res["n_iters"] = torch.empty(n, dtype=torch.int32, device=dev)
+            out.n_iters = res["n_iters"].data_ptr()
+        prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)),
+                            float(tol_pos_m), float(tol_rot_rad), int(shape))
         _hip.check(
             _hip.lib().cppf_lm_pose_steps(
                 self._handle(dev), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(prm), ctypes.byref(out),
@@ -364,11 +385,38 @@ class Robot:
 
     def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
                        alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
-                       clamp: bool = True, summary_out: Optional[torch.Tensor] = None) -> "LmLaunchPlan":  # fmt: skip
+                       clamp: bool = True, summary_out: Optional[torch.Tensor] = None,
+                       shape: int = _hip.SHAPE_AUTO) -> "LmLaunchPlan":  # fmt: skip
         """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
         holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation."""
         return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                            summary_out)
+                            summary_out, shape)
+
+    def select_valid_seed(self, seed_summary: torch.Tensor, constraints, self_collisions_ignored: bool = False,
+                          env_collisions_ignored: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x_is_valid's seed selection (cppflow/optimization_utils.py:856-909) over [S,8] per-seed summaries (one GPU's, or
+        every rank's after the all-gather): int32 [4] on the device = (first valid seed or -1, number of valid seeds, seed of
+        smallest summed external cost, 0).  `constraints` is a `Constraints` (max_allowed_* fields).
+        Also accepts what one all-gather of [G, S_local, 8] buffers from `world` ranks leaves behind, as a 4-d tensor
+        [world, G, S_local, 8]: the result is then int32 [G, 4], row g for the world * S_local seeds of step g."""
+        s = _require_device_tensor(seed_summary, "seed_summary")
+        assert s.dim() in (2, 4) and s.shape[-1] == 8, tuple(s.shape)
+        n_chunks, n_groups, S_chunk = (1, 1, s.shape[0]) if s.dim() == 2 else tuple(s.shape[:3])
+        if out is None:
+            out = torch.empty(4 if s.dim() == 2 else (n_groups, 4), dtype=torch.int32, device=s.device)
+        else:
+            out = _require_output_tensor(out, "out", torch.int32)
+            assert out.numel() == 4 * n_groups
+        c = _hip.Constraints(float(constraints.max_allowed_position_error_cm), float(constraints.max_allowed_rotation_error_deg),
+                             float(constraints.max_allowed_mjac_deg), float(constraints.max_allowed_mjac_cm),
+                             int(bool(self_collisions_ignored)), int(bool(env_collisions_ignored)))  # fmt: skip
+        _hip.check(
+            _hip.lib().cppf_select_valid_seed_gathered(
+                self._handle(s.device), s.data_ptr(), n_chunks, n_groups, S_chunk, ctypes.byref(c), out.data_ptr(),
+                _stream_ptr(s.device),
+            )  # fmt: skip
+        )
+        return out
 
     def collision_masks(
         self, q: torch.Tensor, want_min_dists: bool = False, only: Optional[Sequence[str]] = None
@@ -575,9 +623,9 @@ def _check_summary_buffer(t: torch.Tensor, S: int, dev) -> None:
 
 class LmLaunchPlan:
     def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                 summary_out=None):  # fmt: skip
+                 summary_out=None, shape=_hip.SHAPE_AUTO):  # fmt: skip
         x = robot._x2d(x)
-        x_out = robot._x2d(x_out, "x_out")
+        x_out = _require_output_tensor(x_out, "x_out")
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
         assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0 and x_out.shape == x.shape
@@ -601,7 +649,8 @@ class LmLaunchPlan:
             out.seed_summary = summary_out.data_ptr()
             self.outputs["seed_summary"] = summary_out
         self._out = out
-        self._prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)))
+        self._prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)),
+                                  0.0, 0.0, int(shape))
         self._fn = _hip.lib().cppf_lm_pose_steps
         self._args = (robot._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(self._prm),
                       ctypes.byref(self._out))  # fmt: skip

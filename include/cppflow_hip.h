@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 2
+#define CPPF_ABI_VERSION 3
 
 #define CPPF_MAX_DOF 16
 #define CPPF_MAX_CAPSULES 24
@@ -67,7 +67,20 @@ typedef struct cppf_lm_params {
     float alpha_rotation; /* OptimizationParameters.alpha_rotation (0.35, :126) */
     int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration) */
     int32_t clamp;        /* 1: clamp_to_joint_limits after every step (the reference loop); 0: bare step (K must be 1) */
+    /* Early-out (0 = off): a row whose residual at the start of an iteration has ||t_target - t|| < tol_pos_m and
+     * ||(roll, pitch, yaw)|| < tol_rot_rad is left untouched from then on, and a wavefront whose rows are all below
+     * tolerance leaves the loop -- the in-launch counterpart of the reference loop stopping once the pose is valid
+     * (cppflow/optimization.py:251-258, 326-358).  Not combinable with J_out / e_out. */
+    float tol_pos_m;
+    float tol_rot_rad;
+    /* Kernel shape: CPPF_SHAPE_AUTO picks by batch size; CPPF_SHAPE_ROW = one (seed, waypoint) row per lane (throughput
+     * shape); CPPF_SHAPE_QUAD = four lanes cooperate on one row (latency shape for batches that cannot fill the chip). */
+    int32_t shape;
 } cppf_lm_params;
+
+#define CPPF_SHAPE_AUTO 0
+#define CPPF_SHAPE_ROW 1
+#define CPPF_SHAPE_QUAD 2
 
 /* Optional outputs of the fused launch; any pointer may be NULL. */
 typedef struct cppf_lm_outputs {
@@ -86,6 +99,7 @@ typedef struct cppf_lm_outputs {
                            * when W is 64, 128 or 256 (a 256-row workgroup then holds whole seeds); for any other W the entry point runs the
                            * separate reduction kernel afterwards, which needs x_out, pos_err_m, rot_err_rad, the three masks
                            * and ext_cost to be non-NULL.  Implies the collision stage. */
+    int32_t* n_iters;     /* [n]  LM steps actually applied to the row (< n_steps only with the early-out tolerances) */
 } cppf_lm_outputs;
 
 typedef struct cppf_robot cppf_robot; /* opaque: host copy of the description + launch state for one device */
@@ -188,6 +202,30 @@ int cppf_plan_metrics(const cppf_robot* robot, const float* x, const float* targ
 int cppf_seed_summary(const cppf_robot* robot, const float* x, int S, int W, const float* ext_cost, const float* pos_err_m,
                       const float* rot_err_rad, const uint8_t* self_mask, const uint8_t* env_mask,
                       const uint8_t* jlim_mask, float* out, void* stream);
+
+/* Constraints (cppflow/data_types.py:53-62; CLI values scripts/evaluate.py:51-56: 0.01 cm, 0.1 deg, 7 deg, 2 cm) and the two
+ * collision switches of cppflow/config.py:23-24 that x_is_valid reads (cppflow/optimization_utils.py:889, 896). */
+typedef struct cppf_constraints {
+    float max_allowed_position_error_cm;
+    float max_allowed_rotation_error_deg;
+    float max_allowed_mjac_deg;
+    float max_allowed_mjac_cm;
+    int32_t self_collisions_ignored;
+    int32_t env_collisions_ignored;
+} cppf_constraints;
+
+/* The seed selection of x_is_valid (cppflow/optimization_utils.py:856-909) over the per-seed summaries [S,8] of
+ * cppf_seed_summary / cppf_lm_outputs.seed_summary -- of one GPU, or of every rank after the all-gather: a seed is valid
+ * when its four maxima are strictly below the constraints (cppflow/evaluation_utils.py:29-75) and it has no self- /
+ * environment-colliding waypoint.  out (DEVICE int32 [4]) = { first valid seed in order or -1, number of valid seeds,
+ * seed of smallest summed external cost (first on ties), 0 }.  One small launch. */
+int cppf_select_valid_seed(const cppf_robot* robot, const float* seed_summary, int S, const cppf_constraints* constraints,
+                           int32_t* out, void* stream);
+/* The same over what ONE all-gather of [n_groups, S_chunk, 8] buffers from n_chunks ranks leaves behind
+ * (gathered [n_chunks, n_groups, S_chunk, 8]: the summaries of n_groups consecutive steps travel in one collective): group g
+ * is the n_chunks * S_chunk seeds of step g in rank order, seed index = rank * S_chunk + s.  out: DEVICE int32 [n_groups, 4]. */
+int cppf_select_valid_seed_gathered(const cppf_robot* robot, const float* gathered, int n_chunks, int n_groups, int S_chunk,
+                                    const cppf_constraints* constraints, int32_t* out, void* stream);
 
 /* cppflow/lm_hyper_parameters.py:14-56: the fields the coupled step reads (values of ALT_LOSS_V2_1_DIFF at :86-118) */
 typedef struct cppf_full_params {

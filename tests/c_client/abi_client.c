@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(target, h_t, sizeof(float) * W * 7, hipMemcpyHostToDevice, stream));
 
     cppf_lm_params prm;
+    memset(&prm, 0, sizeof prm); /* early-out off, shape = CPPF_SHAPE_AUTO */
     prm.lm_lambda = 1e-6f, prm.alpha_position = 3.5f, prm.alpha_rotation = 0.35f; /* ALT_LOSS_V2_1_POSE */
     prm.n_steps = K, prm.clamp = 1;
     cppf_lm_outputs out;

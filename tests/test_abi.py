@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_hip.SIGNATURES), set(names) ^ set(_hip.SIGNATURES)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.cppf_abi_version() == 2
+    assert lib.cppf_abi_version() == 3
 
 
 def test_struct_layouts_match_header_constants():
@@ -70,8 +70,9 @@ def test_struct_layouts_match_header_constants():
         assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == val
     # sizeof(cppf_robot_desc): 4 + 16*48 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
     assert ctypes.sizeof(_hip.RobotDesc) == 4 + 768 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
-    assert ctypes.sizeof(_hip.LmParams) == 20
-    assert ctypes.sizeof(_hip.LmOutputs) == 12 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_hip.LmParams) == 32
+    assert ctypes.sizeof(_hip.LmOutputs) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_hip.Constraints) == 24
 
 
 def test_invalid_descriptions_are_rejected_without_a_gpu(lib):

@@ -10,8 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cppflow_amd.distributed import (PACKED_BYTES_PER_ROW, allgather_seed_outputs, allgather_seed_summaries, seed_shard,
-                                     unpack_rows)  # fmt: skip
+from cppflow_amd.distributed import (PACKED_BYTES_PER_ROW, allgather_seed_outputs, allgather_seed_summaries, drop_padding,
+                                     padded_shard_size, seed_shard, shard_counts, unpack_rows)  # fmt: skip
 from tests import helpers as H
 
 S_TOTAL, W, K = 6, 16, 3
@@ -79,3 +79,71 @@ def test_two_rank_allgather_equals_single_process(tmp_path):
     assert s0.shape == (S_TOTAL, 8) and np.array_equal(s0, s1)
     np.testing.assert_allclose(s0[:, 7], cost.sum(1), rtol=1e-6)
     assert np.array_equal(s0[:, 4], sm.sum(1)) and np.array_equal(s0[:, 5], em.sum(1))
+
+
+# ---- uneven shards: 7 seeds over 2 ranks (4 + 3), W = 6 -> buffers padded to 4 seeds each ------------------------------------
+S_ODD, W_ODD = 7, 6
+
+
+def _fake_packed(S, W, first_seed):
+    """a packed buffer whose every field encodes (global seed, waypoint)"""
+    n = S * W
+    packed = torch.zeros(PACKED_BYTES_PER_ROW * n, dtype=torch.uint8)
+    cost, p, r, sm, em, jm = unpack_rows(packed, n)
+    seed = (first_seed + torch.arange(S)).repeat_interleave(W)
+    w = torch.arange(W).repeat(S)
+    cost.copy_((1000 * seed + w).float())
+    p.copy_((seed + 0.25).float())
+    r.copy_((w + 0.5).float())
+    sm.copy_((seed % 2).to(torch.uint8))
+    em.copy_((w % 2).to(torch.uint8))
+    jm.copy_(((seed + w) % 2).to(torch.uint8))
+    return packed
+
+
+def _worker_uneven(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, e = seed_shard(S_ODD, rank, world)
+        S_pad = padded_shard_size(S_ODD, W_ODD, world)
+        counts = shard_counts(S_ODD, world)
+        assert counts[rank] == e - b and (S_pad * W_ODD) % 4 == 0
+        packed = torch.zeros(PACKED_BYTES_PER_ROW * S_pad * W_ODD, dtype=torch.uint8)
+        own = _fake_packed(e - b, W_ODD, b)
+        for dst, src in zip(unpack_rows(packed, S_pad * W_ODD), unpack_rows(own, (e - b) * W_ODD)):
+            dst[: (e - b) * W_ODD].copy_(src)  # the filler seeds stay zero
+        g = allgather_seed_outputs(packed, S_pad, W_ODD, counts=counts)
+        summ = torch.full((S_pad, 8), -1.0)
+        summ[: e - b, 0] = torch.arange(b, e).float()
+        allsumm = drop_padding(allgather_seed_summaries(summ), S_pad, counts)
+        np.savez(os.path.join(out_dir, f"odd{rank}.npz"), cost=g.ext_cost.numpy(), pe=g.pos_err_m.numpy(), sm=g.self_mask.numpy(),
+                 jm=g.jlim_mask.numpy(), summ=allsumm.numpy())  # fmt: skip
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_shards_are_padded_and_the_filler_dropped(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_uneven, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    cost, pe, _, sm, _, jm = (t.numpy().reshape(S_ODD, W_ODD) for t in unpack_rows(_fake_packed(S_ODD, W_ODD, 0), S_ODD * W_ODD))
+    for rank in range(2):
+        z = np.load(os.path.join(str(tmp_path), f"odd{rank}.npz"))
+        assert z["cost"].shape == (S_ODD, W_ODD)
+        assert np.array_equal(z["cost"], cost) and np.array_equal(z["pe"], pe)
+        assert np.array_equal(z["sm"], sm.astype(bool)) and np.array_equal(z["jm"], jm.astype(bool))
+        assert np.array_equal(z["summ"][:, 0], np.arange(S_ODD))
+
+
+def test_unaligned_equal_shards_are_refused_with_a_clear_message():
+    # 3 seeds x 5 waypoints per rank = 15 rows: rank 1's fp32 slice would start at byte 225
+    import pytest
+
+    packed = torch.zeros(PACKED_BYTES_PER_ROW * 15, dtype=torch.uint8)
+    assert padded_shard_size(6, 5, 2) == 4
+    # single process: world == 1 never trips the check
+    allgather_seed_outputs(packed, 3, 5)
+    with pytest.raises(AssertionError):
+        allgather_seed_outputs(packed, 3, 5, counts=[3, 3])

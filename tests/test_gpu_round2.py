@@ -1,0 +1,166 @@
+"""Round-2 GPU tests (pytest -m gpu): NaN propagation like torch's, the in-launch early-out, x_is_valid's seed selection on
+the device, output-buffer contracts.  Every call goes through the C ABI of libcppflow_hip.so."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+LM = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device="cuda:0")
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def panda():
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot("panda")
+    rb.set_obstacles([c for c, _ in H.PANDA_2CUBES], [T for _, T in H.PANDA_2CUBES])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    return rb
+
+
+def test_nan_rows_stay_nan_like_the_reference_op_sequence(panda):
+    """torch.clamp / torch.max propagate NaN (cppflow/optimization_utils.py:831-833, evaluation_utils.py:41-42): a row with a NaN
+    joint (or a NaN target pose) comes back NaN, its seed's maxima are 'not below threshold', and no mask is raised for it --
+    exactly what the reference's op sequence (oracle/ref_torch.py) gives.  Finite rows are unaffected."""
+    from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
+    from cppflow_amd.robot_zoo import ROBOT_SPECS
+    from oracle import ref_torch
+
+    S, W, K = 4, 64, 3
+    x0, target = H.lm_problem("panda", S, W, seed=31)
+    x_bad = x0.copy()
+    x_bad[5, 2] = np.nan  # seed 0
+    x_bad[2 * W + 7, 0] = np.inf  # seed 2
+    summ = torch.empty((S, 8), dtype=torch.float32, device="cuda:0")
+    res = panda.lm_pose_steps(dev(x_bad), dev(target), n_steps=K, want_errors=True, want_collisions=True, summary_out=summ, **LM)
+    x = host(res["x"])
+    bad_rows = np.zeros(S * W, dtype=bool)
+    bad_rows[[5, 2 * W + 7]] = True
+    assert np.isnan(x[bad_rows]).all() and np.isfinite(x[~bad_rows]).all()
+    clean = panda.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_collisions=True, **LM)
+    assert np.array_equal(x[~bad_rows], host(clean["x"])[~bad_rows])
+    # the reference's op sequence on the same rows
+    rt = ref_torch.TorchRobot(ROBOT_SPECS["panda"](), device="cpu", dtype=torch.float32)
+    x_ref = ref_torch.lm_pose_steps(rt, torch.tensor(x_bad, dtype=torch.float32), torch.tensor(H.stacked(target, S), dtype=torch.float32), K)
+    assert np.array_equal(np.isnan(x_ref.numpy()).any(1), bad_rows)
+    assert np.isnan(host(res["pos_err_m"])[bad_rows]).all()
+    for k in ("self_mask", "env_mask"):
+        assert not res[k].cpu().numpy()[bad_rows].any()
+    s = host(summ)
+    assert np.isinf(s[0, 0]) and np.isinf(s[2, 0]) and np.isfinite(s[[1, 3]]).all()
+    sel = panda.select_valid_seed(summ, DEFAULT_CONSTRAINTS).cpu().numpy()
+    assert sel[0] not in (0, 2)
+    # standalone reductions and the standalone clamp agree
+    sv = host(panda.seed_validity(res["x"], dev(target)))
+    assert np.isinf(sv[0, 0]) and np.isinf(sv[2, 0]) and np.isfinite(sv[[1, 3]]).all()
+    xc = dev(x_bad)
+    panda.clamp_to_joint_limits(xc)
+    assert np.isnan(host(xc)[5, 2]) and host(xc)[2 * W + 7, 0] == H.chain("panda").hi[0]
+    # a NaN target pose poisons its waypoint in every seed
+    t_bad = target.copy()
+    t_bad[9, 4] = np.nan
+    r2 = panda.lm_pose_steps(dev(x0), dev(t_bad), n_steps=K, **LM)
+    rows9 = np.arange(S) * W + 9
+    assert np.isnan(host(r2["x"])[rows9]).all() and np.isfinite(np.delete(host(r2["x"]), rows9, axis=0)).all()
+
+
+def test_early_out_freezes_converged_rows_and_counts_iterations(panda):
+    """cppf_lm_params.tol_*: a row below tolerance at the start of an iteration is left untouched; n_iters counts the steps
+    applied.  With the tolerances off the launch runs all K iterations (what bench.py times)."""
+    S, W, K = 8, 64, 12
+    x0, target = H.lm_problem("panda", S, W, seed=32)
+    tol_p, tol_r = 1e-5, 1e-4
+    full = panda.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_iters=True, **LM)
+    assert (full["n_iters"].cpu().numpy() == K).all()
+    early = panda.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_iters=True, tol_pos_m=tol_p,
+                                tol_rot_rad=tol_r, **LM)  # fmt: skip
+    it = early["n_iters"].cpu().numpy()
+    assert it.min() >= 1 and it.max() <= K and (it < K).mean() > 0.8, (it.min(), it.max(), (it < K).mean())
+    # a row frozen after k steps equals the k-step result of the plain launch, bit for bit
+    xe = host(early["x"])
+    for k in (int(np.median(it)), int(it.min())):
+        rows = it == k
+        xk = host(panda.lm_pose_steps(dev(x0), dev(target), n_steps=k, **LM)["x"])
+        assert np.array_equal(xe[rows], xk[rows])
+    # frozen rows are converged: pose error below the tolerances (rpy norm bounds the rotation angle to first order)
+    frozen = it < K
+    assert host(early["pos_err_m"])[frozen].max() < tol_p * 1.01
+    assert host(early["rot_err_rad"])[frozen].max() < max(tol_r * 1.05, 8.95e-4)
+    # the oracle's own iteration reaches the tolerance on those rows within the same number of steps (+-1)
+    o = H.oracle64("panda")
+    tgt = H.stacked(target, S)
+    xs, need = x0.copy(), np.full(S * W, K, dtype=int)
+    for k in range(K):
+        e, _ = o.pose_errors(xs, tgt)
+        done = (np.linalg.norm(e[:, 3:], axis=1) < tol_p) & (np.linalg.norm(e[:, :3], axis=1) < tol_r) & (need == K)
+        need[done] = k
+        xs = o.lm_steps(xs, tgt, 1, solver=0, **LM)
+    agree = np.abs(need - it) <= 1
+    assert agree.mean() > 0.98, agree.mean()
+    with pytest.raises(AssertionError):
+        panda.lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, return_residual=True, tol_pos_m=1e-5, tol_rot_rad=1e-4, **LM)
+    with pytest.raises(AssertionError):
+        panda.lm_pose_steps(dev(x0), dev(target), n_steps=2, tol_pos_m=1e-5, **LM)
+
+
+def test_select_valid_seed_matches_x_is_valid_rule(panda):
+    from cppflow_amd.data_types import Constraints
+    from cppflow_amd.evaluation_utils import seed_metrics_are_below_threshold
+
+    rng = np.random.RandomState(5)
+    S = 777
+    c = Constraints(0.01, 0.1, 7.0, 2.0)
+    summ = np.zeros((S, 8), dtype=np.float32)
+    summ[:, 0] = rng.uniform(0, 0.02, S)
+    summ[:, 1] = rng.uniform(0, 0.2, S)
+    summ[:, 2] = rng.uniform(0, 14, S)
+    summ[:, 3] = rng.uniform(0, 4, S)
+    summ[:, 4] = rng.randint(0, 3, S) * (rng.rand(S) < 0.3)
+    summ[:, 5] = rng.randint(0, 3, S) * (rng.rand(S) < 0.3)
+    summ[:, 7] = rng.randint(0, 50, S) * 100.0
+    summ[10, 0] = np.nan
+    summ[11, 1] = np.inf
+
+    def rule(rows, ignore_self, ignore_env):
+        ok = [seed_metrics_are_below_threshold(c, r[:4])[0] and (ignore_self or r[4] == 0) and (ignore_env or r[5] == 0) for r in rows]
+        first = next((i for i, v in enumerate(ok) if v), -1)
+        return first, int(np.sum(ok)), int(np.argmin(rows[:, 7]))
+
+    for ig_s, ig_e in ((False, False), (True, False), (True, True)):
+        got = panda.select_valid_seed(dev(summ), c, ig_s, ig_e).cpu().numpy()
+        assert tuple(got[:3]) == rule(summ, ig_s, ig_e), (got, rule(summ, ig_s, ig_e))
+    none = summ.copy()
+    none[:, 0] = 1.0
+    assert tuple(panda.select_valid_seed(dev(none), c).cpu().numpy()[:2]) == (-1, 0)
+    # the all-gathered layout [world, G, S_local, 8]: group g = the seeds of step g in rank order
+    world, G, Sl = 3, 4, 50
+    g4 = summ[: world * G * Sl].reshape(world, G, Sl, 8)
+    got = panda.select_valid_seed(dev(g4), c).cpu().numpy()
+    for g in range(G):
+        rows = np.concatenate([g4[r, g] for r in range(world)], axis=0)
+        assert tuple(got[g, :3]) == rule(rows, False, False)
+
+
+def test_output_buffers_must_be_contiguous(panda):
+    S, W = 2, 64
+    x0, target = H.lm_problem("panda", S, W, seed=33)
+    wide = torch.empty((S * W, 14), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(AssertionError, match="contiguous"):
+        panda.lm_pose_steps(dev(x0), dev(target), n_steps=1, x_out=wide[:, :7], **LM)
+    # in-place use (x_out = x) writes the caller's buffer
+    x = dev(x0)
+    ptr = x.data_ptr()
+    res = panda.lm_pose_steps(x, dev(target), n_steps=2, x_out=x, **LM)
+    assert res["x"].data_ptr() == ptr and not np.array_equal(host(x), x0)
