@@ -370,9 +370,9 @@ class HostStagedGather:
 
     def all_gather(self, out, inp):
         host_in = inp.cpu()  # synchronises on the current (auxiliary) stream
-        host_out = torch.empty(out.shape, dtype=out.dtype)
+        host_out = torch.empty((out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:]), dtype=out.dtype)
         self.dist.all_gather_into_tensor(host_out, host_in)
-        out.copy_(host_out)
+        out.copy_(host_out.view(out.shape))
 
 
 class RcclGather:
@@ -380,7 +380,8 @@ class RcclGather:
         self.dist = dist
 
     def all_gather(self, out, inp):
-        work = self.dist.all_gather_into_tensor(out, inp, async_op=True)
+        # the concatenated form (world * G rows of [S, 8]); `out` [world, G, S, 8] is the same memory
+        work = self.dist.all_gather_into_tensor(out.view((out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:])), inp, async_op=True)
         work.wait()  # stream-side: the current (auxiliary) stream waits for the communicator's stream
 
 

@@ -55,10 +55,12 @@ class LmParams(ctypes.Structure):
         ("tol_pos_m", _f),
         ("tol_rot_rad", _f),
         ("shape", _i32),
+        ("solver", _i32),
     ]
 
 
 SHAPE_AUTO, SHAPE_ROW, SHAPE_QUAD = 0, 1, 2
+SOLVER_F32, SOLVER_F64 = 0, 1
 
 
 class Constraints(ctypes.Structure):
@@ -114,6 +116,8 @@ SIGNATURES = {
     "cppf_robot_specialization": (ctypes.c_int, [_vp]),
     "cppf_debug_force_generic": (None, [ctypes.c_int]),
     "cppf_debug_set_pcr_max_rows": (None, [ctypes.c_int]),
+    "cppf_debug_set_quad_max_rows": (None, [ctypes.c_int]),
+    "cppf_debug_set_quad_mfma": (None, [ctypes.c_int]),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_forward_kinematics": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),

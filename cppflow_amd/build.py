@@ -7,7 +7,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["cppflow_hip.hip"]
-HEADERS = ["lmik_device.h", "robots_gen.h", "kernels_chain.h", "kernels_collision.h", "kernels_fused.h", "kernels_eval.h",
+HEADERS = ["lmik_device.h", "robots_gen.h", "kernels_chain.h", "kernels_collision.h", "kernels_fused.h", "kernels_quad.h", "kernels_eval.h",
            "kernels_coupled.h", "kernels_dp.h", os.path.join("..", "..", "include", "cppflow_hip.h")]  # fmt: skip
 OUT = os.path.join(CSRC, "libcppflow_hip.so")
 

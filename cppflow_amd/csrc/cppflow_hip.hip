@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "lmik_device.h"
 #include "robots_gen.h"
@@ -44,6 +45,7 @@ constexpr int kBlock = CPPF_BLOCK;
 #include "kernels_chain.h"
 #include "kernels_collision.h"
 #include "kernels_fused.h"
+#include "kernels_quad.h"
 #include "kernels_eval.h"
 #include "kernels_coupled.h"
 #include "kernels_dp.h"
@@ -80,6 +82,7 @@ struct cppf_robot {
     int device;
     int static_id;     // index into robots_gen.h when the description equals a generated table, else -1
     size_t lds_bytes;  // generic path only: capsule end points, 6 floats per capsule per lane
+    void* d_quad;      // device: QuadPairRec[CPPF_MAX_PAIRS] then QuadCapRec[CPPF_MAX_CAPSULES] (quad shape's striped collision stage)
 };
 
 namespace {
@@ -168,6 +171,9 @@ int find_static_robot(const cppf_robot_desc& d) {
         }                                                                                                             \
     }
 
+int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
+                                // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
+bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
 int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows (measured crossover)
 
@@ -305,11 +311,40 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
     rb->static_id = find_static_robot(*desc);
+    // device tables of the quad shape (static per robot: pair list, thresholds)
+    {
+        std::vector<uint4> host(CPPF_MAX_PAIRS + CPPF_MAX_CAPSULES, uint4{0, 0, 0, 0});
+        for (int p = 0; p < co.npairs; ++p) {
+            QuadPairRec r{co.pair_a[p], co.pair_b[p], co.pair_thr[p], co.pair_cull4[p]};
+            std::memcpy(&host[p], &r, sizeof r);
+        }
+        for (int c = 0; c < co.ncaps; ++c) {
+            QuadCapRec r{co.cap_thr[c], co.cap_cull4[c], co.cap_r[c], 0.f};
+            std::memcpy(&host[CPPF_MAX_PAIRS + c], &r, sizeof r);
+        }
+        DeviceGuard guard(device);
+        hipError_t e = guard.err;
+        rb->d_quad = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&rb->d_quad, host.size() * sizeof(uint4));
+        if (e == hipSuccess) e = hipMemcpy(rb->d_quad, host.data(), host.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (rb->d_quad) (void)hipFree(rb->d_quad);
+            delete rb;
+            return fail(CPPF_ERR_HIP, std::string("cppflow_hip: device tables: ") + hipGetErrorString(e));
+        }
+    }
     *out = rb;
     return CPPF_OK;
 }
 
-void cppf_robot_destroy(cppf_robot* robot) { delete robot; }
+void cppf_robot_destroy(cppf_robot* robot) {
+    if (!robot) return;
+    if (robot->d_quad) {
+        DeviceGuard guard(robot->device);
+        (void)hipFree(robot->d_quad);
+    }
+    delete robot;
+}
 
 int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
 
@@ -318,6 +353,10 @@ int cppf_robot_specialization(const cppf_robot* robot) { return robot ? robot->s
 void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 
 void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n; }
+
+void cppf_debug_set_quad_max_rows(int n) { g_quad_max_rows = n; }
+
+void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
 int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
     CPPF_REQUIRE(robot, "robot handle is NULL");
@@ -438,24 +477,96 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                      "seed_summary with W not in {64, 128, 256} needs x_out, pos_err_m, rot_err_rad, the three masks and ext_cost");
         outk.seed_summary = nullptr;
     }
-    out = &outk;
+    // kernel shape: four lanes per row for batches that cannot fill the chip (kernels_quad.h), one row per lane otherwise
+    const int d = robot->desc.ndof;
+    const bool quad_can = d >= 6 && !out->J_out && !out->e_out && !out->min_self && !out->min_env &&
+                          (!out->seed_summary || (out->x_out && out->pos_err_m && out->rot_err_rad && out->self_mask &&
+                                                  out->env_mask && out->jlim_mask && out->ext_cost));
+    CPPF_REQUIRE(params->shape == CPPF_SHAPE_AUTO || params->shape == CPPF_SHAPE_ROW || params->shape == CPPF_SHAPE_QUAD,
+                 "unknown kernel shape");
+    CPPF_REQUIRE(params->solver == CPPF_SOLVER_F32 || params->solver == CPPF_SOLVER_F64, "unknown solver");
+    CPPF_REQUIRE(!(params->solver == CPPF_SOLVER_F64 && params->shape == CPPF_SHAPE_QUAD),
+                 "CPPF_SOLVER_F64 is built for the row shape");
+    CPPF_REQUIRE(params->shape != CPPF_SHAPE_QUAD || quad_can,
+                 "CPPF_SHAPE_QUAD needs ndof >= 6, no J_out / e_out / min_self / min_env, and (with seed_summary) every per-row output");
+    // AUTO: the quad shape when the batch is at most one of its wavefronts per SIMD AND no per-seed summary is asked for (in
+    // this shape a seed's rows span several workgroups, so the summary needs the separate reduction launch, which costs more
+    // than the shape saves: measured 28.5 against 26.2 us for K = 10 + collision + summary at <= 16 384 rows)
+    const bool quad = params->shape == CPPF_SHAPE_QUAD ||
+                      (params->shape == CPPF_SHAPE_AUTO && quad_can && !out->seed_summary && n <= (size_t)g_quad_max_rows &&
+                       params->solver == CPPF_SOLVER_F32);
+    if (quad) {
+        cppf_lm_outputs oq = *out;
+        oq.seed_summary = nullptr;  // rows of a seed span several workgroups in this shape: the reduction kernel follows
+        const unsigned grid = (unsigned)((n + kQuadRows - 1) / kQuadRows);
+        const size_t lds_q = coll ? sizeof(float) * (4 * (CPPF_MAX_PAIRS + CPPF_MAX_CAPSULES) +
+                                                     (size_t)kQuadRows * quad_row_stride(robot->coll.ncaps))
+                                  : 0;
+        const uint4* tab = static_cast<const uint4*>(robot->d_quad);
+        const bool mfma = g_quad_mfma && robot->static_id >= 0 && !g_force_generic;
+#define CPPF_BODY                                                                                                          \
+    if constexpr (RB::D >= 6) {                                                                                            \
+        if (coll) {                                                                                                        \
+            if constexpr (RB::kStatic) {                                                                                   \
+                if (mfma)                                                                                                  \
+                    hipLaunchKernelGGL((lm_quad_kernel<RB, 1, true>), dim3(grid), dim3(kBlock), lds_q, st, robot->chain,    \
+                                       robot->coll, prm, x_in, target, oq, tab);                                           \
+                else                                                                                                       \
+                    hipLaunchKernelGGL((lm_quad_kernel<RB, 1, false>), dim3(grid), dim3(kBlock), lds_q, st, robot->chain,   \
+                                       robot->coll, prm, x_in, target, oq, tab);                                           \
+            } else {                                                                                                       \
+                hipLaunchKernelGGL((lm_quad_kernel<RB, 1, false>), dim3(grid), dim3(kBlock), lds_q, st, robot->chain,       \
+                                   robot->coll, prm, x_in, target, oq, tab);                                               \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            if constexpr (RB::kStatic) {                                                                                   \
+                if (mfma)                                                                                                  \
+                    hipLaunchKernelGGL((lm_quad_kernel<RB, 0, true>), dim3(grid), dim3(kBlock), 0, st, robot->chain,        \
+                                       robot->coll, prm, x_in, target, oq, tab);                                           \
+                else                                                                                                       \
+                    hipLaunchKernelGGL((lm_quad_kernel<RB, 0, false>), dim3(grid), dim3(kBlock), 0, st, robot->chain,       \
+                                       robot->coll, prm, x_in, target, oq, tab);                                           \
+            } else {                                                                                                       \
+                hipLaunchKernelGGL((lm_quad_kernel<RB, 0, false>), dim3(grid), dim3(kBlock), 0, st, robot->chain,           \
+                                   robot->coll, prm, x_in, target, oq, tab);                                               \
+            }                                                                                                              \
+        }                                                                                                                  \
+    }
+        CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
+        if (int rc = check_launch(robot)) return rc;
+        if (summary_dst)
+            return cppf_seed_summary(robot, oq.x_out, S, W, oq.ext_cost, oq.pos_err_m, oq.rot_err_rad, oq.self_mask, oq.env_mask,
+                                     oq.jlim_mask, summary_dst, stream);
+        return CPPF_OK;
+    }
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
+    const bool f64 = params->solver == CPPF_SOLVER_F64;
     if (coll && (out->min_self || out->min_env)) {
+        CPPF_REQUIRE(!f64, "CPPF_SOLVER_F64 is built for the launches without min_self / min_env");
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
                        prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else if (coll) {
-#define CPPF_BODY                                                                                                 \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
-                       prm, x_in, target, *out)
+#define CPPF_BODY                                                                                                          \
+    if (f64)                                                                                                               \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain,          \
+                           robot->coll, prm, x_in, target, *out);                                                          \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll,   \
+                           prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else {
-#define CPPF_BODY                                                                                               \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
-                       prm, x_in, target, *out)
+#define CPPF_BODY                                                                                                          \
+    if (f64)                                                                                                               \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 0, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain,            \
+                           robot->coll, prm, x_in, target, *out);                                                          \
+    else                                                                                                                   \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll,     \
+                           prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     }

@@ -219,6 +219,77 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
     }
 }
 
+// The same dual solve with everything after the Jacobian in fp64 (cppf_lm_params.solver = CPPF_SOLVER_F64).  In fp32 the step is
+// exact to rounding only while cond(J J^T + lambda S^-2) * 6e-8 << 1: with y = A^-1 e of size |e| / (sigma_min^2 + lambda), a
+// backward error eps |A| |y| of the factorisation reaches the TASK-space step J delta as eps |A| |e| / (sigma_min^2 + lambda) --
+// 1e-4 .. 1e-2 on the 1 - 10 % of rows of a 7-DoF arm with sigma_min(J_s) < 2e-2 (the reference's own fp32 primal LU loses
+// 1e-5 .. 7e-4 there; measured tables in DESIGN.md 5.1).  The entries of J are fp32, their products are exact in fp64, so
+// this path's step equals the exactly solved step of the fp32 Jacobian to ~1e-13: |J_s (delta - delta_fp64 oracle)| <= 6e-7 on
+// ALL rows.  It needs A (21 sums), the factorisation, the BACK substitution and J^T y in fp64 (measured: leaving any of them in
+// fp32 gives the fp32 tail back); ~300 v_fma_f64 at half the fp32 rate plus 84 conversions: ~1.5x the iteration time.
+template <int D>
+__device__ __forceinline__ void lm_dual_solve_f64(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
+                                                  float a_rot, float (&delta)[D]) {
+    const double lam_r = (double)lambda / ((double)a_rot * (double)a_rot), lam_p = (double)lambda / ((double)a_pos * (double)a_pos);
+    double A[6][6];  // lower triangle
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[i][j] = (i == j) ? (i < 3 ? lam_r : lam_p) : 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        double c[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c[i] = (double)J[i][k];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) A[i][j] = __builtin_fma(c[i], c[j], A[i][j]);
+    }
+    double inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double lam = j < 3 ? lam_r : lam_p;
+#pragma unroll
+        for (int i = j; i < 6; ++i) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = __builtin_fma(-A[i][k], A[j][k], s);
+            if (i == j) {
+                s = s > lam ? s : lam;
+                double r = __builtin_amdgcn_rsq(s);  // v_rsq_f64 (~2^-26), two Newton steps on r = s^-1/2
+                r = __builtin_fma(r * 0.5, __builtin_fma(-s * r, r, 1.0), r);
+                r = __builtin_fma(r * 0.5, __builtin_fma(-s * r, r, 1.0), r);
+                inv[j] = r;
+            } else {
+                A[i][j] = s * inv[j];  // L overwrites A
+            }
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = (double)e[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s = __builtin_fma(-A[i][k], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) s = __builtin_fma(-A[k][i], y[k], s);
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = __builtin_fma((double)J[i][k], y[i], s);
+        delta[k] = (float)s;
+    }
+}
+
 // Fewer than 6 joints: J J^T (6x6) is rank-deficient and the dual form loses its conditioning advantage, while J^T J (d x d)
 // is well conditioned -- solve the reference's primal system (optimization.py:85-88) by Cholesky.
 template <int D>
@@ -264,11 +335,13 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
     }
 }
 
-template <int D>
+template <int D, bool F64 = false>
 __device__ __forceinline__ void lm_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos, float a_rot,
                                          float (&delta)[D]) {
     if constexpr (D < 6)
         lm_primal_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+    else if constexpr (F64)
+        lm_dual_solve_f64<D>(J, e, lambda, a_pos, a_rot, delta);
     else
         lm_dual_solve<D>(J, e, lambda, a_pos, a_rot, delta);
 }

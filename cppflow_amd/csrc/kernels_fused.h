@@ -114,7 +114,7 @@ __device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restr
 // One LM iteration of one row.  Returns true when the row was ALREADY converged at this linearisation point (early-out
 // tolerances of cppf_lm_params, off when 0): such a row is left untouched -- the reference's loop likewise stops stepping
 // once the pose is valid (cppflow/optimization.py:251-258, 326-358).
-template <class RB>
+template <class RB, bool F64>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
                                                const float (&Rt)[9], const float (&tt)[3], float (&q)[RB::D]) {
     constexpr int D = RB::D;
@@ -127,7 +127,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
         if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
     }
     jacobian_from_axes<RB>(rb, p, ax, og, J);
-    lm_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+    lm_solve<D, F64>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
     if (last) {
         // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
         if (out.J_out) {
@@ -212,7 +212,8 @@ __device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, con
 
 // COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
 // out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
-template <class RB, int COLL>
+// F64: the damped solve in double precision (lm_dual_solve_f64).
+template <class RB, int COLL, bool F64 = false>
 __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const C
         const bool bad = !(fabsf(chk) < INFINITY);
         int iters = 0;
         for (int it = 0; it < prm.n_steps; ++it) {
-            const bool conv = lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+            const bool conv = lm_row_iterate<RB, F64>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
             iters += conv ? 0 : 1;
             if (prm.tol_pos2 > 0.f && __builtin_amdgcn_ballot_w64(!conv) == 0ull) break;
         }

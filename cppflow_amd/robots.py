@@ -310,6 +310,7 @@ class Robot:
         tol_rot_rad: float = 0.0,
         want_iters: bool = False,
         shape: int = _hip.SHAPE_AUTO,
+        solver: int = _hip.SOLVER_F32,
     ) -> Dict[str, torch.Tensor]:
         """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
         (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7].
@@ -325,7 +326,9 @@ class Robot:
         `tol_pos_m` / `tol_rot_rad` (both or neither) switch on the in-launch early-out: rows already below tolerance at the
         start of an iteration are left untouched and a wavefront of such rows leaves the loop (cppflow/optimization.py:326-358
         stops the same way once the pose is valid); `want_iters` returns the per-row number of steps applied.  `shape` picks
-        the kernel shape (`_hip.SHAPE_ROW`: one row per lane; `_hip.SHAPE_QUAD`: four lanes per row; default: by batch size)."""
+        the kernel shape (`_hip.SHAPE_ROW`: one row per lane; `_hip.SHAPE_QUAD`: four lanes per row; default: by batch size);
+        `solver` the precision of the damped solve (`_hip.SOLVER_F32`, the reference's dtype, or `_hip.SOLVER_F64`: exact to
+        rounding on near-singular rows too, ~1.5x the iteration time)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
@@ -374,7 +377,7 @@ class Robot:
             res["n_iters"] = torch.empty(n, dtype=torch.int32, device=dev)
             out.n_iters = res["n_iters"].data_ptr()
         prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)),
-                            float(tol_pos_m), float(tol_rot_rad), int(shape))
+                            float(tol_pos_m), float(tol_rot_rad), int(shape), int(solver))
         _hip.check(
             _hip.lib().cppf_lm_pose_steps(
                 self._handle(dev), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(prm), ctypes.byref(out),
@@ -386,11 +389,11 @@ class Robot:
     def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
                        alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
                        clamp: bool = True, summary_out: Optional[torch.Tensor] = None,
-                       shape: int = _hip.SHAPE_AUTO) -> "LmLaunchPlan":  # fmt: skip
+                       shape: int = _hip.SHAPE_AUTO, solver: int = _hip.SOLVER_F32) -> "LmLaunchPlan":  # fmt: skip
         """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
         holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation."""
         return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                            summary_out, shape)
+                            summary_out, shape, solver)
 
     def select_valid_seed(self, seed_summary: torch.Tensor, constraints, self_collisions_ignored: bool = False,
                           env_collisions_ignored: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -623,7 +626,7 @@ def _check_summary_buffer(t: torch.Tensor, S: int, dev) -> None:
 
 class LmLaunchPlan:
     def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                 summary_out=None, shape=_hip.SHAPE_AUTO):  # fmt: skip
+                 summary_out=None, shape=_hip.SHAPE_AUTO, solver=_hip.SOLVER_F32):  # fmt: skip
         x = robot._x2d(x)
         x_out = _require_output_tensor(x_out, "x_out")
         target = _require_device_tensor(target, "target_path")
@@ -650,7 +653,7 @@ class LmLaunchPlan:
             self.outputs["seed_summary"] = summary_out
         self._out = out
         self._prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)),
-                                  0.0, 0.0, int(shape))
+                                  0.0, 0.0, int(shape), int(solver))
         self._fn = _hip.lib().cppf_lm_pose_steps
         self._args = (robot._handle(x.device), x.data_ptr(), target.data_ptr(), n // W, W, ctypes.byref(self._prm),
                       ctypes.byref(self._out))  # fmt: skip

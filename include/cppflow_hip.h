@@ -76,7 +76,15 @@ typedef struct cppf_lm_params {
     /* Kernel shape: CPPF_SHAPE_AUTO picks by batch size; CPPF_SHAPE_ROW = one (seed, waypoint) row per lane (throughput
      * shape); CPPF_SHAPE_QUAD = four lanes cooperate on one row (latency shape for batches that cannot fill the chip). */
     int32_t shape;
+    /* Precision of the damped solve: CPPF_SOLVER_F32 (default; the reference's dtype) or CPPF_SOLVER_F64 -- J J^T, its
+     * factorisation, the substitutions and J^T y in double precision: the step then equals the exactly solved step of the fp32
+     * Jacobian on EVERY row, near-singular ones included (task-space difference to the fp64 oracle <= 6e-7), at ~1.5x the
+     * iteration time.  Row shape, ndof >= 6, launches without min_self / min_env. */
+    int32_t solver;
 } cppf_lm_params;
+
+#define CPPF_SOLVER_F32 0
+#define CPPF_SOLVER_F64 1
 
 #define CPPF_SHAPE_AUTO 0
 #define CPPF_SHAPE_ROW 1
@@ -120,6 +128,12 @@ void cppf_debug_force_generic(int on);
  * trajectory) when S*W <= n rows (and W <= 512, d <= 8, no pose block), waypoint after waypoint (one wavefront per
  * trajectory) otherwise; default 131072, the measured crossover (process-wide). */
 void cppf_debug_set_pcr_max_rows(int n);
+/* Tuning hooks (process-wide): CPPF_SHAPE_AUTO runs four lanes per row up to n rows (default 16384 = one wavefront of that shape
+ * per SIMD, the measured crossover) unless a per-seed summary is requested;
+ * non-zero `on` forms J J^T of that shape with v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
+ * measured comparison of DESIGN.md section 4; default off). */
+void cppf_debug_set_quad_max_rows(int n);
+void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
  * cuboids [O,6] = (-sx/2,-sy/2,-sz/2, sx/2,sy/2,sz/2); Rt [O,12] = rotation row-major (9) then translation (3), HOST

@@ -70,7 +70,7 @@ def test_struct_layouts_match_header_constants():
         assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == val
     # sizeof(cppf_robot_desc): 4 + 16*48 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
     assert ctypes.sizeof(_hip.RobotDesc) == 4 + 768 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
-    assert ctypes.sizeof(_hip.LmParams) == 32
+    assert ctypes.sizeof(_hip.LmParams) == 36
     assert ctypes.sizeof(_hip.LmOutputs) == 13 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_hip.Constraints) == 24
 

@@ -1,0 +1,247 @@
+"""Parity on ALL rows, without a conditioning filter (VERDICT r1 "What's weak" 1-4; pytest -m gpu).
+
+What can be asserted on every row, and why the bars differ by solver precision (DESIGN.md 5.1 has the measured tables):
+
+  * joint space is the wrong place to compare: for ndof >= 7 the reference's normal matrix is rank-deficient and its own fp32
+    LU carries 0.02-0.04 rad of null-space noise.  The meaningful quantity is the TASK-space difference of
+    the step, |J_s (x_gpu - x_fp64)|, with J_s the scaled Jacobian of the fp64 reference-order oracle.
+  * CPPF_SOLVER_F64 (what `levenberg_marquardt_only_pose`-style single steps can afford): <= 2e-5 on every row, near-singular
+    ones included, and the pose error after ONE step within 1e-5 of the oracle's wherever the oracle's own step is not a jump
+    through a singularity.
+  * CPPF_SOLVER_F32 (the reference's dtype; what the fused K-step launches run): the step is exact to rounding only while
+    cond(J J^T + lambda S^-2) * eps << 1; its error is bounded row by row by  2e-5 + 2e-7 * cond * |e_s|,  it is <= 1e-4 on
+    the rows with sigma_min(J_s) >= 2e-2, and its distribution is held against the reference-order fp32 arithmetic
+    (oracle/lmik_oracle.c, LU with partial pivoting in the reference's operation order) quantile by quantile.
+  * after K steps the comparison is on the pose error: converged rows within 1e-5, non-converged rows never worse than the
+    oracle's by more than a stated factor; validity flags at the Constraints thresholds agree with the reference-order fp32
+    formula outside that formula's own quantisation band.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+ROBOTS = ["panda", "fetch", "fetch_arm", "chain12"]
+LM = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+QS = (0.5, 0.9, 0.99, 1.0)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def robots():
+    from cppflow_amd.robots import get_robot
+
+    return {n: get_robot(n) for n in ROBOTS}
+
+
+def _task_space(Js, dx):
+    return np.abs(np.einsum("nij,nj->ni", Js, dx)).max(axis=1)
+
+
+def _one_step_case(name, source):
+    if source == "golden":
+        z = np.load(os.path.join(GOLDEN, f"lm_golden_{name}.npz"))
+        x0, target = H.f32(z["x0"]), H.f32(z["target"])
+        return x0, target, int(z["S"])
+    S, W = 64, 64
+    x0, target = H.lm_problem(name, S, W, seed=3)
+    return x0, target, S
+
+
+@pytest.mark.parametrize("source", ["seeded", "golden"])
+@pytest.mark.parametrize("name", ROBOTS)
+def test_one_step_task_space_parity_on_all_rows(robots, name, source):
+    from cppflow_amd import _hip
+
+    x0, target, S = _one_step_case(name, source)
+    tgt = H.stacked(target, S)
+    o64, o32 = H.oracle64(name), H.oracle32(name)
+    x64, Js, es, fails = o64.lm_step(x0, tgt, solver=0, **LM)  # reference order: primal normal equations, LU, fp64
+    assert fails == 0
+    x32, _, _, _ = o32.lm_step(x0, tgt, solver=0, **LM)  # the same in the reference's own dtype
+    sv = np.linalg.svd(Js, compute_uv=False)
+    smin, smax = sv[:, -1], sv[:, 0]
+    well = smin >= 2e-2
+    pe64, re64 = o64.pose_metrics_exact(x64, tgt)
+    ts32 = _task_space(Js, x32 - x64)
+    xs = {}
+    for solver in (_hip.SOLVER_F64, _hip.SOLVER_F32):
+        for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
+            if solver == _hip.SOLVER_F64 and shape == _hip.SHAPE_QUAD:
+                continue
+            r = robots[name].lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, solver=solver, shape=shape, **LM)
+            xs[(solver, shape)] = host(r["x"])
+            assert np.isfinite(xs[(solver, shape)]).all()
+    # ---- fp64 solve: every row ----
+    x = xs[(_hip.SOLVER_F64, _hip.SHAPE_ROW)]
+    ts = _task_space(Js, x - x64)
+    assert ts.max() <= 2e-5, (name, source, ts.max())
+    pe, re = o64.pose_metrics_exact(x, tgt)
+    # pose error after ONE step: the step itself is nonlinear in x, so a joint-space difference d moves the pose by |J| d +
+    # O(|delta| d); rows whose oracle step is a jump of radians (near-singular linearisation) are compared in task space above
+    calm = np.abs(x64 - x0).max(axis=1) < 1.0
+    assert calm.mean() > 0.9
+    assert np.abs(pe - pe64)[calm].max() <= 1e-5, (name, source, np.abs(pe - pe64)[calm].max())
+    assert np.abs(re - re64)[calm].max() <= 1e-5, (name, source, np.abs(re - re64)[calm].max())
+    # joint space on the well-conditioned rows: the reference's own bar between its two formulations (tests/optimization_test.py:99)
+    assert np.abs(x - x64)[well].max() < 5e-3
+    # ---- fp32 solve (both kernel shapes): conditioning-aware bound on every row, hard bars where fp32 can meet them ----
+    cond = smax**2 / (smin**2 + LM["lm_lambda"])
+    bound = 2e-5 + 2e-7 * cond * np.linalg.norm(es, axis=1)
+    for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
+        x = xs[(_hip.SOLVER_F32, shape)]
+        ts = _task_space(Js, x - x64)
+        assert (ts <= bound).all(), (name, source, shape, np.max(ts / bound))
+        assert ts[well].max() <= 1e-4, (name, source, shape, ts[well].max())
+        assert np.median(ts) <= 1e-6 and np.quantile(ts, 0.9) <= 2e-5, (name, source, shape, np.quantile(ts, QS))
+        pe, re = o64.pose_metrics_exact(x, tgt)
+        ok = well & calm
+        assert np.abs(pe - pe64)[ok].max() <= 2e-4 and np.abs(re - re64)[ok].max() <= 5e-4
+        # against the reference-order fp32 arithmetic: same accuracy class up to the 90th percentile; beyond it the dual
+        # form trades task-space accuracy for the absence of null-space noise (|dx| below), as DESIGN.md 5.1 tabulates
+        assert np.quantile(ts, 0.5) <= 2.0 * max(np.quantile(ts32, 0.5), 2e-7)
+        assert np.quantile(ts, 0.9) <= 8.0 * max(np.quantile(ts32, 0.9), 5e-7)
+        dx, dx32 = np.abs(x - x64).max(axis=1), np.abs(x32 - x64).max(axis=1)
+        assert np.median(dx[well]) <= np.median(dx32[well]) + 1e-6  # no null-space noise: closer to fp64 than the reference's fp32 is
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_k_step_pose_error_on_all_rows_including_unconverged(robots, name):
+    """K = 10 fused steps: converged rows (by the oracle) within 1e-5 of the oracle's pose error; on the rest the build is
+    never worse than the oracle by more than 10x + 1e-4 m / 1e-3 rad on 99 % of them and not worse in the median."""
+    from cppflow_amd import _hip
+
+    S, W, K = 32, 64, 10
+    x0, target = H.lm_problem(name, S, W, seed=4)
+    tgt = H.stacked(target, S)
+    o64 = H.oracle64(name)
+    x_orc = o64.lm_steps(x0, tgt, K, solver=0, **LM)
+    pe_o, re_o = o64.pose_metrics_exact(x_orc, tgt)
+    conv = (pe_o < 1e-4) & (re_o < 1.2e-3)
+    assert 0.9 < conv.mean() < 1.0 or name in ("chain12",)  # the case does contain rows that do not converge in K steps
+    for shape, solver in ((_hip.SHAPE_ROW, _hip.SOLVER_F32), (_hip.SHAPE_QUAD, _hip.SOLVER_F32), (_hip.SHAPE_ROW, _hip.SOLVER_F64)):
+        r = robots[name].lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, shape=shape, solver=solver, **LM)
+        pe, re = host(r["pos_err_m"]), host(r["rot_err_rad"])
+        pe_at, re_at = o64.pose_metrics_exact(host(r["x"]), tgt)
+        assert np.abs(pe - pe_at).max() < 1e-5 and np.abs(re - re_at).max() < 1e-5  # reported errors are those of its own x
+        assert np.abs(pe - pe_o)[conv].max() < 1e-5 and np.abs(re - re_o)[conv].max() < 1e-5
+        rest = ~conv
+        if rest.sum() >= 8:
+            worse_p = pe[rest] > 10.0 * pe_o[rest] + 1e-4
+            worse_r = re[rest] > 10.0 * re_o[rest] + 1e-3
+            assert worse_p.mean() <= 0.02 and worse_r.mean() <= 0.02, (name, shape, worse_p.mean(), worse_r.mean())
+            assert np.median(pe[rest]) <= 2.0 * np.median(pe_o[rest]) + 1e-5
+            # and the build converges on (nearly) every row the oracle converges on, plus possibly more
+            assert ((pe < 1e-4) & (re < 1.2e-3))[conv].mean() > 0.999
+
+
+@pytest.mark.parametrize("name", ROBOTS)
+def test_validity_flags_agree_with_reference_order_fp32_formula(robots, name):
+    """x_is_valid thresholds (Constraints: 0.01 cm, 0.1 deg -- scripts/evaluate.py:51-56) on the kernel's rotation error
+    (atan2 form) against the reference-order fp32 evaluation 2*acos(clamp(q_t . q_c)) (oracle32.pose_metrics): the flags agree
+    on every row outside the acos formula's quantisation band around the threshold; rows inside the band are counted."""
+    S, W, K = 32, 64, 6  # K = 6: a spread of rotation errors around 0.1 deg
+    x0, target = H.lm_problem(name, S, W, seed=9)
+    tgt = H.stacked(target, S)
+    r = robots[name].lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, **LM)
+    x = host(r["x"])
+    pe, re = host(r["pos_err_m"]), host(r["rot_err_rad"])
+    pe32, re32 = H.oracle32(name).pose_metrics(x, tgt)  # reference order, reference dtype
+    thr_p, thr_r = 1e-4, np.deg2rad(0.1)
+    flag_p, flag_p32 = pe < thr_p, pe32 < thr_p
+    flag_r, flag_r32 = re < thr_r, re32 < thr_r
+    # position: plain norm, fp32 rounding only
+    band_p = np.abs(pe32 - thr_p) < 2e-7
+    assert np.array_equal(flag_p[~band_p], flag_p32[~band_p])
+    # rotation: 2*acos(dot) in fp32 moves in steps of ~2*sqrt(2*6e-8 / (1 - dot)) ~ 4e-4 rad at 0.1 deg and is floored at
+    # 8.944e-4 by the clamp; outside +-4.5e-4 rad of the threshold the two evaluations must agree
+    band_r = np.abs(re32 - thr_r) < 4.5e-4
+    assert np.array_equal(flag_r[~band_r], flag_r32[~band_r]), int((flag_r != flag_r32)[~band_r].sum())
+    n_band = int(band_r.sum())
+    n_disagree = int((flag_r != flag_r32).sum())
+    assert n_disagree <= n_band
+    # the fp64 evaluation sides with the kernel inside the band (the kernel's formula is the accurate one)
+    _, re64 = H.oracle64(name).pose_metrics_exact(x, tgt)
+    assert np.array_equal(flag_r, re64 < thr_r) or np.abs(re64 - thr_r)[flag_r != (re64 < thr_r)].max() < 1e-5
+    print(f"{name}: {n_band} of {S * W} rows inside the acos quantisation band, {n_disagree} flag disagreements, all inside it")
+
+
+CONFIGS = {
+    "C2": ("panda", "panda__1cube_first64", 128, []),
+    "C3": ("fetch", "fetch__hello_first256", 512, []),
+}
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_full_size_configs_sampled_against_the_oracle(robots, cfg):
+    """BASELINE.json configs 2-4 at FULL size on the reference's target paths; 4096 sampled rows are re-done by the oracle:
+    K-step LM result (pose error of converged rows within 1e-5), one-step task-space parity (fp64 solve <= 2e-5 on every sampled
+    row), metrics at the kernel's x (1e-5) and masks / cost at the kernel's x (bit-exact vs the fp32 oracle)."""
+    from cppflow_amd import _hip
+    from cppflow_amd.data_type_utils import problem_from_arrays
+    from cppflow_amd.optimization import run_lm_pose_refinement
+    from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES
+
+    cfgs = dict(CONFIGS, C4=("panda", "panda__2cubes_resampled256", 1024, PANDA_2CUBES_OBSTACLES))
+    name, key, S, obs = cfgs[cfg]
+    rb = robots[name]
+    target = np.load(os.path.join(GOLDEN, "reference_paths.npz"))[key]
+    W, K = target.shape[0], 10
+    problem = problem_from_arrays(rb, target, obs, device=DEV)
+    ch = H.chain(name)
+    g = torch.Generator().manual_seed(1)
+    lo, hi = torch.tensor(ch.lo, dtype=torch.float32), torch.tensor(ch.hi, dtype=torch.float32)
+    x_rand = (lo + (hi - lo) * (0.15 + 0.7 * torch.rand((S * W, rb.ndof), generator=g))).to(DEV)
+    ik = rb.lm_pose_steps(x_rand, problem.target_path, 1e-2, 3.5, 0.35, n_steps=60)
+    x0 = torch.minimum(torch.maximum(ik["x"] + 0.1 * torch.randn((S * W, rb.ndof), generator=g).to(DEV), lo.to(DEV)), hi.to(DEV)).contiguous()
+    r = run_lm_pose_refinement(problem, x0, n_steps=K)  # binds the obstacles and the default joint-limit padding
+    rows = torch.randperm(S * W, generator=g)[:4096]
+    rows_d = rows.to(DEV)
+    x0_s = host(x0[rows_d])
+    tgt_s = H.f32(target)[(rows % W).numpy()]
+    o64, o32 = H.oracle64(name), H.oracle32(name)
+    # K fused steps
+    x_o = o64.lm_steps(x0_s, tgt_s, K, solver=0, **LM)
+    pe_o, re_o = o64.pose_metrics_exact(x_o, tgt_s)
+    conv = (pe_o < 1e-4) & (re_o < 1.2e-3)
+    assert conv.mean() > 0.5, conv.mean()
+    pe_g, re_g = host(r.pos_err_m.view(-1)[rows_d]), host(r.rot_err_rad.view(-1)[rows_d])
+    assert np.abs(pe_g - pe_o)[conv].max() < 1e-5 and np.abs(re_g - re_o)[conv].max() < 1e-5
+    # metrics and masks at the kernel's own x
+    x_g = host(r.x[rows_d])
+    pe_at, re_at = o64.pose_metrics_exact(x_g, tgt_s)
+    assert np.abs(pe_g - pe_at).max() < 1e-5 and np.abs(re_g - re_at).max() < 1e-5
+    lo_b, hi_b = H.box_corners([c.numpy() for c in problem.obstacles_cuboids], [T.numpy() for T in problem.obstacles_Tcuboids])
+    jl_lo, jl_hi = rb.padded_joint_limits()
+    m = o32.masks(x_g, lo_b if len(obs) else None, hi_b if len(obs) else None, jl_lo, jl_hi)
+    assert np.array_equal(r.self_mask.view(-1)[rows_d].cpu().numpy().astype(np.uint8), m["self_mask"])
+    assert np.array_equal(r.env_mask.view(-1)[rows_d].cpu().numpy().astype(np.uint8), m["env_mask"])
+    assert np.array_equal(r.jlim_mask.view(-1)[rows_d].cpu().numpy().astype(np.uint8), m["jlim_mask"])
+    assert np.array_equal(host(r.ext_cost.view(-1)[rows_d]), m["ext_cost"])
+    # one step on the sampled rows: task space, fp64 solve on every row, fp32 solve by its bound
+    x64, Js, es, _ = o64.lm_step(x0_s, tgt_s, solver=0, **LM)
+    sv = np.linalg.svd(Js, compute_uv=False)
+    bound = 2e-5 + 2e-7 * sv[:, 0] ** 2 / (sv[:, -1] ** 2 + 1e-6) * np.linalg.norm(es, axis=1)
+    full64 = rb.lm_pose_steps(x0, problem.target_path, n_steps=1, clamp=False, solver=_hip.SOLVER_F64, **LM)["x"]
+    full32 = rb.lm_pose_steps(x0, problem.target_path, n_steps=1, clamp=False, **LM)["x"]
+    ts64 = _task_space(Js, host(full64[rows_d]) - x64)
+    ts32 = _task_space(Js, host(full32[rows_d]) - x64)
+    assert ts64.max() <= 2e-5, ts64.max()
+    assert (ts32 <= bound).all() and np.quantile(ts32, 0.9) <= 2e-5, (np.max(ts32 / bound), np.quantile(ts32, QS))
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)

@@ -164,3 +164,111 @@ def test_output_buffers_must_be_contiguous(panda):
     ptr = x.data_ptr()
     res = panda.lm_pose_steps(x, dev(target), n_steps=2, x_out=x, **LM)
     assert res["x"].data_ptr() == ptr and not np.array_equal(host(x), x0)
+
+
+# ---- the quad shape (four lanes per row) against the row shape and the oracle ------------------------------------------------------
+QUAD_ROBOTS = ["panda", "fetch", "fetch_arm", "chain12"]
+
+
+def _obstacles_for(name):
+    if name in ("panda", "chain12"):
+        return H.PANDA_2CUBES
+    return [H.cuboid_obstacle(0.7, 0.1, 0.8, 0.3, 0.3, 0.3)]
+
+
+@pytest.fixture(scope="module")
+def robots():
+    from cppflow_amd.robots import get_robot
+
+    return {n: get_robot(n) for n in QUAD_ROBOTS}
+
+
+@pytest.mark.parametrize("mfma", [False, True])
+@pytest.mark.parametrize("name", QUAD_ROBOTS)
+def test_quad_shape_agrees_with_row_shape_and_oracle(robots, name, mfma):
+    """Same launch, both kernel shapes (and J J^T by MFMA in the quad shape): x agrees to fp32 rounding of the iteration; the
+    metrics are those of each shape's own x (1e-5 vs the fp64 oracle); masks / cost are bit-exact vs the fp32 oracle at that x."""
+    from cppflow_amd import _hip
+
+    rb = robots[name]
+    obs = _obstacles_for(name)
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+    lo, hi = H.box_corners([c for c, _ in obs], [T for _, T in obs])
+    jl_lo, jl_hi = rb.padded_joint_limits()
+    o64, o32 = H.oracle64(name), H.oracle32(name)
+    _hip.lib().cppf_debug_set_quad_mfma(int(mfma))
+    try:
+        for S, W, K in ((3, 50, 1), (8, 64, 5), (5, 256, 10)):  # 150 rows: a partly filled last workgroup
+            x0, target = H.lm_problem(name, S, W, seed=40 + K)
+            tgt = H.stacked(target, S)
+            out = {}
+            for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
+                summ = torch.full((S, 8), -1.0, dtype=torch.float32, device="cuda:0")
+                out[shape] = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_collisions=True,
+                                              summary_out=summ, want_iters=True, shape=shape, **LM)  # fmt: skip
+            r, q = out[_hip.SHAPE_ROW], out[_hip.SHAPE_QUAD]
+            xr, xq = host(r["x"]), host(q["x"])
+            assert np.isfinite(xq).all()
+            # per-step differences are fp32 rounding of a 6x6 solve with cond <~ 1e5, amplified over K steps on rows that
+            # have not converged; on converged rows the two agree to 1e-5
+            d = np.abs(xr - xq).max(axis=1)
+            pe_r = host(r["pos_err_m"])
+            conv = pe_r < 1e-4
+            assert np.median(d) < 2e-5, np.median(d)
+            if K >= 5:
+                assert d[conv].max() < 5e-3, d[conv].max()  # null-space freedom of a redundant arm: the reference's own x bar (tests/optimization_test.py:99)
+            # the quad shape's own outputs against the oracle at its own x
+            pe, re = o64.pose_metrics_exact(xq, tgt)
+            assert np.abs(host(q["pos_err_m"]) - pe).max() < 1e-5
+            assert np.abs(host(q["rot_err_rad"]) - re).max() < 1e-5
+            want = o32.masks(xq, lo, hi, jl_lo, jl_hi)
+            for kx in ("self_mask", "env_mask", "jlim_mask"):
+                assert np.array_equal(q[kx].cpu().numpy().astype(np.uint8), want[kx]), (kx, S, W, K)
+            assert np.array_equal(host(q["ext_cost"]), want["ext_cost"])
+            assert (q["n_iters"].cpu().numpy() == K).all()
+            # convergence quality: same as the row shape's
+            pe_q = host(q["pos_err_m"])
+            if K >= 10:
+                assert (pe_q < 1e-4).mean() > 0.9 and abs((pe_q < 1e-4).mean() - conv.mean()) < 0.02
+                both = conv & (pe_q < 1e-4)
+                assert np.abs(pe_q - pe_r)[both].max() < 1e-5
+            # the per-seed summary (separate reduction kernel in this shape) equals the one of its per-row outputs
+            want_summ = host(rb.seed_summary(q["x"], torch.cat([q["ext_cost"].view(torch.uint8), q["pos_err_m"].view(torch.uint8),
+                                                                   q["rot_err_rad"].view(torch.uint8), q["self_mask"], q["env_mask"],
+                                                                   q["jlim_mask"]]), S, W))  # fmt: skip
+            assert np.array_equal(host(q["seed_summary"]), want_summ)
+    finally:
+        _hip.lib().cppf_debug_set_quad_mfma(0)
+        rb.set_obstacles([], [])
+        rb.set_joint_limit_padding(None, None)
+
+
+def test_quad_shape_single_step_matches_reference_order_oracle(robots):
+    """One bare step (clamp off) in the quad shape vs the fp64 reference-order oracle: the same bars as the row shape's test."""
+    from cppflow_amd import _hip
+
+    for name in QUAD_ROBOTS:
+        S, W = 16, 64
+        x0, target = H.lm_problem(name, S, W, seed=3)
+        res = robots[name].lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, shape=_hip.SHAPE_QUAD, **LM)
+        xo, Jo, eo, fails = H.oracle64(name).lm_step(x0, H.stacked(target, S), solver=0, **LM)
+        smin = np.linalg.svd(Jo, compute_uv=False)[:, -1]
+        ok = smin >= 2e-2
+        diff = np.abs(host(res["x"]) - xo)
+        assert diff[ok].max() < 5e-3, (name, diff[ok].max())
+        # task space, ALL rows: J_s (delta_gpu - delta_oracle) is what fp32 can be held to (SURVEY.md fact 0.5)
+        Js = Jo  # the oracle returns the scaled Jacobian
+        ts = np.abs(np.einsum("nij,nj->ni", Js, host(res["x"]) - xo))
+        assert ts.max() < 2e-4, (name, ts.max())
+
+
+def test_quad_shape_refuses_what_it_cannot_produce(robots):
+    from cppflow_amd import _hip
+
+    x0, target = H.lm_problem("panda", 2, 64, seed=1)
+    with pytest.raises(AssertionError, match="CPPF_SHAPE_QUAD"):
+        robots["panda"].lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, return_residual=True, shape=_hip.SHAPE_QUAD, **LM)
+    with pytest.raises(AssertionError, match="CPPF_SHAPE_QUAD"):
+        robots["panda"].lm_pose_steps(dev(x0), dev(target), n_steps=2, want_collisions=True, want_min_dists=True,
+                                      shape=_hip.SHAPE_QUAD, **LM)  # fmt: skip
