@@ -117,6 +117,7 @@ SIGNATURES = {
     "cppf_debug_force_generic": (None, [ctypes.c_int]),
     "cppf_debug_set_pcr_max_rows": (None, [ctypes.c_int]),
     "cppf_debug_set_quad_max_rows": (None, [ctypes.c_int]),
+    "cppf_debug_set_dp_persistent": (None, [ctypes.c_int]),
     "cppf_debug_set_quad_mfma": (None, [ctypes.c_int]),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
@@ -149,6 +150,15 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FullParams), _vp, _vp, _vp, _vp, _vp],
     ),
+    "cppf_comm_unique_id": (ctypes.c_int, [_vp]),
+    "cppf_comm_init_rank": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "cppf_comm_init_all": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_vp)]),
+    "cppf_comm_rank": (ctypes.c_int, [_vp]),
+    "cppf_comm_world": (ctypes.c_int, [_vp]),
+    "cppf_allgather_bytes": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "cppf_comm_group_begin": (ctypes.c_int, []),
+    "cppf_comm_group_end": (ctypes.c_int, []),
+    "cppf_comm_destroy": (None, [_vp]),
     "cppf_dp_search": (
         ctypes.c_int,
         [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -14,6 +14,8 @@
 // hands to LU, and cheaper than the primal form for ndof >= 6.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -173,6 +175,7 @@ int find_static_robot(const cppf_robot_desc& d) {
 
 int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
+bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 1024), else one launch per waypoint
 bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
 int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows (measured crossover)
@@ -355,6 +358,8 @@ void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n; }
 
 void cppf_debug_set_quad_max_rows(int n) { g_quad_max_rows = n; }
+
+void cppf_debug_set_dp_persistent(int on) { g_dp_persistent = on != 0; }
 
 void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
@@ -853,10 +858,20 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     hipStream_t st = (hipStream_t)stream;
     const int d = robot->desc.ndof;
     const size_t total = (size_t)k * T * d;
+    const bool persistent = g_dp_persistent && k <= 1024 && T >= 2;
+    if (persistent)  // every cost word starts as "not yet" (kernels_dp.h); 16-byte multiple, from the allocation's start
+        CPPF_HIP(hipMemsetAsync(work_costsT, 0xFF, sizeof(float) * (size_t)k * T, st));
     hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
                        ext_cost, k, T, d, work_qT, work_costsT);
     // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
+    if (persistent) {
+        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost, k,
+                                             T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT));
+        hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
+                           best_path);
+        return check_launch(robot);
+    }
     const int bpb = k >= 2048 ? 4 : (k >= 512 ? 2 : 1);
     const unsigned blocks = (unsigned)((k + bpb - 1) / bpb);
     for (int t = 1; t < T; ++t) {
@@ -878,6 +893,132 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
                        best_path);
     return check_launch(robot);
+}
+
+// ---- RCCL behind the C ABI ------------------------------------------------------------------------------------------------------
+// Declared here instead of including <rccl/rccl.h>: the library is loaded with dlopen so that libcppflow_hip.so has no link-time
+// dependency on it (a process that already holds PyTorch's copy must not get a second one).
+namespace {
+struct RcclUid {
+    char bytes[CPPF_COMM_ID_BYTES];
+};
+typedef void* RcclComm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(RcclUid*) = nullptr;
+    int (*CommInitRank)(RcclComm*, int, RcclUid, int) = nullptr;
+    int (*CommInitAll)(RcclComm*, int, const int*) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl() {
+    if (g_rccl.handle) return CPPF_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(CPPF_ERR_UNSUPPORTED, std::string("cppflow_hip: cannot load RCCL (librccl.so.1): ") + dlerror());
+    RcclApi api;
+    api.handle = h;
+#define CPPF_SYM(field, name)                                                                        \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name));                               \
+    if (!api.field) return fail(CPPF_ERR_UNSUPPORTED, std::string("cppflow_hip: RCCL lacks ") + name)
+    CPPF_SYM(GetUniqueId, "ncclGetUniqueId");
+    CPPF_SYM(CommInitRank, "ncclCommInitRank");
+    CPPF_SYM(CommInitAll, "ncclCommInitAll");
+    CPPF_SYM(CommDestroy, "ncclCommDestroy");
+    CPPF_SYM(AllGather, "ncclAllGather");
+    CPPF_SYM(GroupStart, "ncclGroupStart");
+    CPPF_SYM(GroupEnd, "ncclGroupEnd");
+    CPPF_SYM(GetErrorString, "ncclGetErrorString");
+#undef CPPF_SYM
+    g_rccl = api;
+    return CPPF_OK;
+}
+
+#define CPPF_RCCL(call)                                                                                          \
+    do {                                                                                                         \
+        int r__ = (call);                                                                                        \
+        if (r__ != 0)                                                                                            \
+            return fail(CPPF_ERR_HIP, std::string("cppflow_hip: " #call " failed: ") + g_rccl.GetErrorString(r__)); \
+    } while (0)
+}  // namespace
+
+struct cppf_comm {
+    RcclComm comm;
+    int rank, world, device;
+};
+
+int cppf_comm_unique_id(void* id_out) {
+    CPPF_REQUIRE(id_out, "id_out is NULL");
+    if (int rc = load_rccl()) return rc;
+    RcclUid id;
+    CPPF_RCCL(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, id.bytes, CPPF_COMM_ID_BYTES);
+    return CPPF_OK;
+}
+
+int cppf_comm_init_rank(const void* id, int rank, int world, int device, cppf_comm** out) {
+    CPPF_REQUIRE(id && out, "id / out is NULL");
+    CPPF_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank / world out of range");
+    *out = nullptr;
+    if (int rc = load_rccl()) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the device failed: ") + hipGetErrorString(guard.err));
+    RcclUid uid;
+    std::memcpy(uid.bytes, id, CPPF_COMM_ID_BYTES);
+    RcclComm c = nullptr;
+    CPPF_RCCL(g_rccl.CommInitRank(&c, world, uid, rank));
+    *out = new cppf_comm{c, rank, world, device};
+    return CPPF_OK;
+}
+
+int cppf_comm_init_all(int n_devices, const int* devices, cppf_comm** out) {
+    CPPF_REQUIRE(n_devices >= 1 && devices && out, "n_devices < 1 or NULL pointer");
+    if (int rc = load_rccl()) return rc;
+    std::vector<RcclComm> comms((size_t)n_devices, nullptr);
+    CPPF_RCCL(g_rccl.CommInitAll(comms.data(), n_devices, devices));
+    for (int i = 0; i < n_devices; ++i) out[i] = new cppf_comm{comms[(size_t)i], i, n_devices, devices[i]};
+    return CPPF_OK;
+}
+
+int cppf_comm_rank(const cppf_comm* comm) { return comm ? comm->rank : CPPF_ERR_INVALID; }
+
+int cppf_comm_world(const cppf_comm* comm) { return comm ? comm->world : CPPF_ERR_INVALID; }
+
+int cppf_allgather_bytes(cppf_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+    CPPF_REQUIRE(comm, "comm is NULL");
+    if (bytes_per_rank == 0) return CPPF_OK;
+    CPPF_REQUIRE(send && recv, "send / recv is NULL");
+    DeviceGuard guard(comm->device);
+    if (guard.err != hipSuccess) return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the device failed: ") + hipGetErrorString(guard.err));
+    CPPF_RCCL(g_rccl.AllGather(send, recv, bytes_per_rank, /* ncclUint8 */ 1, comm->comm, (hipStream_t)stream));
+    return CPPF_OK;
+}
+
+int cppf_comm_group_begin(void) {
+    if (int rc = load_rccl()) return rc;
+    CPPF_RCCL(g_rccl.GroupStart());
+    return CPPF_OK;
+}
+
+int cppf_comm_group_end(void) {
+    if (int rc = load_rccl()) return rc;
+    CPPF_RCCL(g_rccl.GroupEnd());
+    return CPPF_OK;
+}
+
+void cppf_comm_destroy(cppf_comm* comm) {
+    if (!comm) return;
+    if (g_rccl.handle && comm->comm) (void)g_rccl.CommDestroy(comm->comm);
+    delete comm;
 }
 
 }  // extern "C"

@@ -18,7 +18,10 @@ __global__ __launch_bounds__(256) void dp_transpose_kernel(const float* __restri
         const int t = (int)(r % T), a = (int)(r / T);
         qT[((size_t)t * k + a) * d + j] = q[i];
     }
-    if (i < (size_t)k) costsT[i] = ext[i * T];  // costs[:,0] = q_costs_external[:,0]  (search.py:151)
+    if (i < (size_t)k) {  // costs[:,0] = q_costs_external[:,0]  (search.py:151); 0xFFFFFFFF is the persistent kernel's "not yet" word
+        const float c = ext[i * T];
+        costsT[i] = __float_as_uint(c) == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : c;
+    }
 }
 
 // BPB = destination candidates per workgroup: fewer for small k so that a step still fills the chip with workgroups
@@ -99,6 +102,123 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
         if (b0 + i < k) {
             cost_cur[b0 + i] = v;
             memo_cur[b0 + i] = a;
+        }
+    }
+}
+
+// ---- the whole recurrence in ONE launch ------------------------------------------------------------------------------------------
+// T-1 dependent launches of a few microseconds each are launch-bound (1.05 ms at the reference's k = 175, T = 256).  Here
+// k single-wavefront workgroups stay resident for all T-1 steps; workgroup b owns destination b.  The only thing step t
+// needs from the other workgroups is the cost row of step t-1 -- k floats -- and that row is its own flag: the cost table is
+// pre-filled with a sentinel bit pattern (0xFFFFFFFF, which no cost can be: costs are sums of finite non-negative numbers,
+// and a NaN computed by the hardware is 0x7FC00000), every cost is stored ONCE with an agent-scope (write-through, sc1)
+// store, and a lane that needs costs[t-1][a] re-reads that one word with agent-scope loads until it is no longer the sentinel
+// (MI355X_MICROARCH.md, hand-off form R2 "the data is the flag": a naturally aligned word written by one sc1 store needs no
+// fence, no counter and no barrier).  No grid barrier: a lane waits exactly for the sources it reads.  The part of a step
+// that does not depend on the costs -- the max joint change for this lane's (source, destination) pairs -- is computed BEFORE
+// the wait, so the exposed time per step is the hand-off latency plus the argmin reduction.
+// Same arithmetic, same reduction order as dp_step_kernel: the table, the argmins and the path stay bit-exact with the oracle.
+// Every spin is bounded (a workgroup that never gets its inputs falls through with +inf costs instead of hanging the GPU).
+constexpr uint32_t kDpSentinel = 0xFFFFFFFFu;
+constexpr uint32_t kDpQuietNan = 0x7FC00000u;
+
+__device__ __forceinline__ float dp_wait_cost(const float* p) {
+    uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t spins = 0; bits == kDpSentinel && spins < (1u << 22); ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return bits == kDpSentinel ? INFINITY : __uint_as_float(bits);
+}
+
+__device__ __forceinline__ void dp_publish_cost(float* p, float v) {
+    uint32_t bits = __float_as_uint(v);
+    bits = bits == kDpSentinel ? kDpQuietNan : bits;
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// order-preserving bits of a float (every non-NaN value; a NaN sorts above +inf, where the scalar rule `v < best` also leaves it)
+__device__ __forceinline__ unsigned long long dp_key(float v, int a) {
+    uint32_t b = __float_as_uint(v);
+    b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((unsigned long long)b << 32) | (uint32_t)a;
+}
+__device__ __forceinline__ float dp_key_value(unsigned long long key) {
+    uint32_t b = (uint32_t)(key >> 32);
+    b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(b);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dp_dpp_min(unsigned long long x) {  // lanes without a source lane keep their own value
+    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)(x >> 32);
+    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < x ? o : x;
+}
+__device__ __forceinline__ unsigned long long dp_wave_min_to_lane63(unsigned long long x) {
+    x = dp_dpp_min<0x111>(x);  // row_shr:1
+    x = dp_dpp_min<0x112>(x);  // row_shr:2
+    x = dp_dpp_min<0x114>(x);  // row_shr:4
+    x = dp_dpp_min<0x118>(x);  // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
+    x = dp_dpp_min<0x142>(x);  // row_bcast:15 -> lanes 31 / 63 hold rows 0-1 / 2-3
+    x = dp_dpp_min<0x143>(x);  // row_bcast:31 -> lane 63 holds the wavefront's minimum
+    return x;
+}
+
+// One wavefront per destination b (grid = k single-wave workgroups): lane l handles sources l, l+64, ... (at most 16 per lane,
+// k <= 1024), so a step needs neither LDS nor a workgroup barrier, and the cost-independent part (the joint changes to this
+// destination from the lane's sources, ~40 instructions per source and joint... hidden behind the ~1 us it takes the previous
+// step's costs to arrive) is small enough to finish before the hand-off does.
+template <int D>
+__global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
+                                                           int T, uint32_t pris_mask, float pscale, float* costsT,
+                                                           int32_t* __restrict__ memoT) {
+    constexpr int AMAX = 16;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = (k + 63) >> 6;  // sources per lane (wave-uniform)
+    for (int t = 1; t < T; ++t) {
+        const float* q_prev = qT + (size_t)(t - 1) * k * D;
+        const float* cost_prev = costsT + (size_t)(t - 1) * k;
+        // ---- independent of the costs ----
+        float qb[D], m[AMAX];
+#pragma unroll
+        for (int j = 0; j < D; ++j) qb[j] = qT[((size_t)t * k + b) * D + j];
+        const float eb = ext[(size_t)b * T + t];
+#pragma unroll
+        for (int s = 0; s < AMAX; ++s) {
+            m[s] = 0.f;
+            if (s < A) {  // wave-uniform
+                const int a = min(lane + 64 * s, k - 1);
+                float mm = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    float dq = qb[j] - q_prev[(size_t)a * D + j];
+                    if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
+                    mm = fmaxf(mm, fabsf(wrap_pi(dq)));
+                }
+                m[s] = mm;
+            }
+        }
+        // ---- dependent: wait for exactly the costs this lane reads; sources ascend per lane, so `<` keeps the first minimum ----
+        float best = INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int s = 0; s < AMAX; ++s) {
+            const int a = lane + 64 * s;
+            if (s < A && a < k) {
+                const float c = dp_wait_cost(cost_prev + a);
+                const float v = fmaxf(m[s], c) + eb;  // search.py:157-158
+                if (v < best) {
+                    best = v;
+                    arg = a;
+                }
+            }
+        }
+        const unsigned long long key = dp_wave_min_to_lane63(dp_key(best, arg));
+        if (lane == 63) {
+            memoT[(size_t)t * k + b] = (int32_t)(uint32_t)key;  // read only by the back-trace launch
+            dp_publish_cost(costsT + (size_t)t * k + b, dp_key_value(key));
         }
     }
 }

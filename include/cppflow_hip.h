@@ -21,6 +21,7 @@
 #ifndef CPPFLOW_HIP_H
 #define CPPFLOW_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -133,6 +134,8 @@ void cppf_debug_set_pcr_max_rows(int n);
  * non-zero `on` forms J J^T of that shape with v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
  * measured comparison of DESIGN.md section 4; default off). */
 void cppf_debug_set_quad_max_rows(int n);
+/* Test hook: 0 makes cppf_dp_search issue one launch per waypoint instead of the single resident launch (k <= 1024). */
+void cppf_debug_set_dp_persistent(int on);
 void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
@@ -273,10 +276,38 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
  * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,
  * 5.0 in the reference), then the back-trace.  Outputs best_path [T,d] and best_idx [T] (which candidate each waypoint
  * came from).  The caller supplies the workspace (device): work_qT [T*k*d] floats, work_costsT [T*k] floats (on return:
- * the cost table, time-major), work_memoT [T*k] int32.  T-1 small launches on `stream`, no host synchronisation. */
+ * the cost table, time-major), work_memoT [T*k] int32.  For k <= 1024 the whole recurrence runs in ONE resident launch
+ * (k single-wavefront workgroups; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are their
+ * own flags, no grid barrier), else one small launch per waypoint; no host synchronisation either way. */
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
                    void* stream);
+
+/* ---- seed sharding across the GPUs of one node: RCCL behind the C ABI ---------------------------------------
+ * The reference is one process on one device (no collective anywhere in its tree); the MI355X build shards the candidate seeds
+ * of cppflow/planners.py:231-251 over the GPUs and needs ONE collective: an all-gather of each rank's packed per-row / per-seed
+ * outputs, so that every rank holds what cppflow/search.py:146-151 consumes.  The library loads RCCL lazily (dlopen of
+ * librccl.so.1: the copy already in the process -- e.g. PyTorch's -- or the ROCm one), so a caller that never shards needs no
+ * RCCL at all.  Two process models:
+ *   - one process (or thread) per GPU: rank 0 calls cppf_comm_unique_id, ships the 128 bytes to the other ranks by any means,
+ *     every rank calls cppf_comm_init_rank;
+ *   - one process, all GPUs: cppf_comm_init_all creates one communicator per listed device.
+ * cppf_allgather_bytes is asynchronous on `stream` (the stream of the communicator's device); with cppf_comm_init_all, issue
+ * the calls for all communicators between cppf_comm_group_begin / cppf_comm_group_end. */
+typedef struct cppf_comm cppf_comm;
+#define CPPF_COMM_ID_BYTES 128
+
+int cppf_comm_unique_id(void* id_out /* CPPF_COMM_ID_BYTES */);
+int cppf_comm_init_rank(const void* id, int rank, int world, int device, cppf_comm** out);
+int cppf_comm_init_all(int n_devices, const int* devices, cppf_comm** out /* [n_devices] */);
+int cppf_comm_rank(const cppf_comm* comm);
+int cppf_comm_world(const cppf_comm* comm);
+/* recv [world * bytes_per_rank] <- every rank's send [bytes_per_rank] in rank order (DEVICE pointers; the packed buffer of
+ * cppf_lm_outputs: ext_cost | pos_err_m | rot_err_rad | the three masks, or the [S,8] per-seed summaries). */
+int cppf_allgather_bytes(cppf_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int cppf_comm_group_begin(void);
+int cppf_comm_group_end(void);
+void cppf_comm_destroy(cppf_comm* comm);
 
 #ifdef __cplusplus
 }

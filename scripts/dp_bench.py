@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""dp_search latency (developer tool): the resident single-launch form against one launch per waypoint, HIP events, medians."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cppflow_amd import _hip
+from cppflow_amd.robots import get_robot
+dev = torch.device("cuda:0")
+for name in ("panda", "fetch", "chain12"):
+    rb = get_robot(name)
+    for k, T in ((175, 256), (64, 256), (175, 64), (300, 256), (1024, 256)):
+        q = torch.rand((k, T, rb.ndof), device=dev)
+        ext = torch.zeros((k, T), device=dev)
+        qT = torch.empty((T, k, rb.ndof), device=dev); cT = torch.empty((T, k), device=dev); mT = torch.empty((T, k), dtype=torch.int32, device=dev)
+        bp = torch.empty((T, rb.ndof), device=dev); bi = torch.empty(T, dtype=torch.int32, device=dev)
+        h = rb._handle(dev)
+        def call():
+            _hip.check(_hip.lib().cppf_dp_search(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), bp.data_ptr(), bi.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        out = []
+        for mode in (1, 0):
+            _hip.lib().cppf_debug_set_dp_persistent(mode)
+            for _ in range(5): call()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(15):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); call(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
+            out.append(np.median(ts))
+        _hip.lib().cppf_debug_set_dp_persistent(1)
+        print(f"{name:8s} dp_search k={k:5d} T={T:4d}   single launch {out[0]:8.1f} us   per-waypoint launches {out[1]:8.1f} us")

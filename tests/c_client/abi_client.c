@@ -126,6 +126,58 @@ int main(int argc, char** argv) {
     if (!fo || fwrite(h_out, 1, out_bytes, fo) != out_bytes) return 1;
     fclose(fo);
 
+    /* ---- seed sharding through the C ABI: R communicators in this one process (cppf_comm_init_all), R = CPPF_CLIENT_RANKS capped
+     * by the visible devices (1 on a one-GPU box).  Rank r holds the external cost of seeds [r S/R, (r+1) S/R) on device r; ONE
+     * all-gather per rank inside a group; every rank must end up with all S*W costs in seed order. ---- */
+    {
+        int ndev = 0, R = 1;
+        HIP_OK(hipGetDeviceCount(&ndev));
+        const char* env = getenv("CPPF_CLIENT_RANKS");
+        if (env) R = atoi(env);
+        if (R > ndev) R = ndev;
+        while (R > 1 && S % R != 0) --R;
+        int devs[8];
+        cppf_comm* comms[8];
+        float* d_send[8];
+        float* d_recv[8];
+        hipStream_t st[8];
+        if (R > 8) R = 8;
+        for (int r = 0; r < R; ++r) devs[r] = r;
+        CPPF_OK_OR_DIE(cppf_comm_init_all(R, devs, comms));
+        const size_t per = n / R;
+        const float* h_cost = (const float*)(h_out + sizeof(float) * n * d);
+        for (int r = 0; r < R; ++r) {
+            HIP_OK(hipSetDevice(r));
+            HIP_OK(hipStreamCreate(&st[r]));
+            HIP_OK(hipMalloc((void**)&d_send[r], sizeof(float) * per));
+            HIP_OK(hipMalloc((void**)&d_recv[r], sizeof(float) * n));
+            HIP_OK(hipMemcpyAsync(d_send[r], h_cost + r * per, sizeof(float) * per, hipMemcpyHostToDevice, st[r]));
+            if (cppf_comm_rank(comms[r]) != r || cppf_comm_world(comms[r]) != R) return 5;
+        }
+        CPPF_OK_OR_DIE(cppf_comm_group_begin());
+        for (int r = 0; r < R; ++r) CPPF_OK_OR_DIE(cppf_allgather_bytes(comms[r], d_send[r], d_recv[r], sizeof(float) * per, st[r]));
+        CPPF_OK_OR_DIE(cppf_comm_group_end());
+        float* h_back = (float*)malloc(sizeof(float) * n);
+        for (int r = 0; r < R; ++r) {
+            HIP_OK(hipSetDevice(r));
+            HIP_OK(hipMemcpyAsync(h_back, d_recv[r], sizeof(float) * n, hipMemcpyDeviceToHost, st[r]));
+            HIP_OK(hipStreamSynchronize(st[r]));
+            if (memcmp(h_back, h_cost, sizeof(float) * n) != 0) {
+                fprintf(stderr, "rank %d: gathered costs differ\n", r);
+                return 6;
+            }
+        }
+        for (int r = 0; r < R; ++r) {
+            HIP_OK(hipSetDevice(r));
+            cppf_comm_destroy(comms[r]);
+            hipFree(d_send[r]), hipFree(d_recv[r]);
+            hipStreamDestroy(st[r]);
+        }
+        free(h_back);
+        HIP_OK(hipSetDevice(0));
+        printf("allgather ok on %d rank(s)\n", R);
+    }
+
     cppf_robot_destroy(robot);
     hipFree(x_in), hipFree(x_out), hipFree(target), hipFree(cost), hipFree(pe), hipFree(re), hipFree(summary), hipFree(fk);
     hipFree(m_self), hipFree(m_env), hipFree(m_jl);
