@@ -114,6 +114,8 @@ SIGNATURES = {
     "cppf_robot_destroy": (None, [_vp]),
     "cppf_robot_ndof": (ctypes.c_int, [_vp]),
     "cppf_robot_specialization": (ctypes.c_int, [_vp]),
+    "cppf_robot_specialize": (ctypes.c_int, [_vp, ctypes.c_char_p]),
+    "cppf_debug_rtc_compile": (ctypes.c_int, [ctypes.POINTER(RobotDesc), ctypes.c_char_p]),
     "cppf_debug_force_generic": (None, [ctypes.c_int]),
     "cppf_debug_set_pcr_max_rows": (None, [ctypes.c_int]),
     "cppf_debug_set_quad_max_rows": (None, [ctypes.c_int]),

@@ -77,6 +77,10 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 
 }  // namespace
 
+namespace {
+struct RtcModule;  // rtc_specialize.h
+}
+
 struct cppf_robot {
     cppf_robot_desc desc;
     ChainK chain;
@@ -85,7 +89,10 @@ struct cppf_robot {
     int static_id;     // index into robots_gen.h when the description equals a generated table, else -1
     size_t lds_bytes;  // generic path only: capsule end points, 6 floats per capsule per lane
     void* d_quad;      // device: QuadPairRec[CPPF_MAX_PAIRS] then QuadCapRec[CPPF_MAX_CAPSULES] (quad shape's striped collision stage)
+    RtcModule* rtc;    // kernels compiled for this description by cppf_robot_specialize (hipRTC), else NULL
 };
+
+#include "rtc_specialize.h"
 
 namespace {
 
@@ -175,7 +182,8 @@ int find_static_robot(const cppf_robot_desc& d) {
 
 int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
-bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 1024), else one launch per waypoint
+constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
+bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 256, the measured range in which it wins), else one launch per waypoint
 bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
 int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows (measured crossover)
@@ -194,6 +202,11 @@ int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up t
         case 12: { constexpr int D = 12; __VA_ARGS__; } break;                                                \
         default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {3..10, 12}");  \
     }
+
+// launch one of the run-time-specialised kernels of a handle (same argument lists as the compiled-in instantiations)
+int rtc_launch(const cppf_robot* rb, RtcKernel which, unsigned grid, size_t lds, hipStream_t st, void** args);
+
+inline bool use_rtc(const cppf_robot* rb) { return rb->rtc != nullptr && !g_force_generic; }
 
 int check_launch(const cppf_robot* rb) {
     CPPF_HIP(hipGetLastError());
@@ -228,6 +241,15 @@ struct DeviceGuard {
         return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the robot's device failed: ") +               \
                                       hipGetErrorString(device_guard__.err))
 
+}  // namespace
+
+namespace {
+int rtc_launch(const cppf_robot* rb, RtcKernel which, unsigned grid, size_t lds, hipStream_t st, void** args) {
+    hipFunction_t f = rb->rtc->fn[which];
+    if (!f) return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: this kernel is not part of the handle's specialised module");
+    CPPF_HIP(hipModuleLaunchKernel(f, grid, 1, 1, (unsigned)kBlock, 1, 1, (unsigned)lds, st, args, nullptr));
+    return CPPF_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -266,9 +288,11 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         const int a = desc->pairs[p][0], b = desc->pairs[p][1];
         CPPF_REQUIRE(a >= 0 && a < desc->n_capsules && b >= 0 && b < desc->n_capsules && a != b, "bad capsule pair");
     }
-    int ndev = 0;
-    CPPF_HIP(hipGetDeviceCount(&ndev));
-    CPPF_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    if (device != kNoDevice) {  // (kNoDevice: the host-only handle cppf_debug_rtc_compile builds)
+        int ndev = 0;
+        CPPF_HIP(hipGetDeviceCount(&ndev));
+        CPPF_REQUIRE(device >= 0 && device < ndev, "device index out of range");
+    }
 
     cppf_robot* rb = new (std::nothrow) cppf_robot();
     if (!rb) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
@@ -314,8 +338,10 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
     rb->static_id = find_static_robot(*desc);
+    rb->rtc = nullptr;
+    rb->d_quad = nullptr;
     // device tables of the quad shape (static per robot: pair list, thresholds)
-    {
+    if (device != kNoDevice) {
         std::vector<uint4> host(CPPF_MAX_PAIRS + CPPF_MAX_CAPSULES, uint4{0, 0, 0, 0});
         for (int p = 0; p < co.npairs; ++p) {
             QuadPairRec r{co.pair_a[p], co.pair_b[p], co.pair_thr[p], co.pair_cull4[p]};
@@ -342,16 +368,75 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
 
 void cppf_robot_destroy(cppf_robot* robot) {
     if (!robot) return;
-    if (robot->d_quad) {
+    {
         DeviceGuard guard(robot->device);
-        (void)hipFree(robot->d_quad);
+        if (robot->d_quad) (void)hipFree(robot->d_quad);
+        if (robot->rtc) {
+            if (robot->rtc->module) (void)hipModuleUnload(robot->rtc->module);
+            delete robot->rtc;
+        }
     }
     delete robot;
 }
 
+int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
+    CPPF_REQUIRE(robot != nullptr, "robot handle is NULL");
+    if (robot->static_id >= 0 || robot->rtc) return CPPF_OK;
+    const bool with_quad = robot->desc.ndof >= 6;  // the quad shape solves the dual 6x6 system
+    const std::string source = rtc_program_source(*robot);
+    if (const char* dump = std::getenv("CPPF_RTC_DUMP")) {  // developer aid: the generated program, for scripts/rtc_try.py
+        std::ofstream f(dump);
+        f << source;
+    }
+    uint64_t key = fnv1a(source);
+    for (int i = 0; i < kEmbeddedCount; ++i) key = fnv1a(kEmbeddedSources[i], key);
+    for (int i = 0; i < kRtcOptionCount; ++i) key = fnv1a(kRtcOptions[i], key);
+    char hex[32];
+    std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)key);
+    const std::string dir = rtc_cache_dir(cache_dir), file = dir + "/robot_" + hex + ".cppfrtc";
+    std::vector<std::string> names;
+    std::string code;
+    if (!rtc_cache_read(file, names, code)) {
+        if (int rc = rtc_compile(source, names, code)) return rc;
+        rtc_cache_write(dir, file, names, code);
+    }
+    // (compiling and caching need no device; loading does)
+    DeviceGuard device_guard__(robot->device);
+    if (device_guard__.err != hipSuccess)
+        return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the robot's device failed: ") + hipGetErrorString(device_guard__.err));
+    RtcModule* m = new (std::nothrow) RtcModule();
+    if (!m) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
+    hipError_t e = hipModuleLoadData(&m->module, code.data());
+    for (int i = 0; e == hipSuccess && i < RTC_COUNT; ++i) {
+        if (!with_quad && (i == RTC_QUAD0 || i == RTC_QUAD1)) continue;
+        e = hipModuleGetFunction(&m->fn[i], m->module, names[(size_t)i].c_str());
+    }
+    if (e != hipSuccess) {
+        if (m->module) (void)hipModuleUnload(m->module);
+        delete m;
+        return fail(CPPF_ERR_HIP, std::string("cppflow_hip: loading the specialised code object failed: ") + hipGetErrorString(e));
+    }
+    robot->rtc = m;
+    return CPPF_OK;
+}
+
 int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
 
-int cppf_robot_specialization(const cppf_robot* robot) { return robot ? robot->static_id : CPPF_ERR_INVALID; }
+int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir) {
+    cppf_robot* rb = nullptr;
+    if (int rc = cppf_robot_create(desc, kNoDevice, &rb)) return rc;
+    rb->static_id = -1;  // compile even a shipped description: this hook exercises the run-time path itself
+    rb->device = kNoDevice;
+    const int rc = cppf_robot_specialize(rb, cache_dir);
+    delete rb;
+    // without a device the last stage (loading the code object) fails by design; the compile + cache stages have run
+    return rc;
+}
+
+int cppf_robot_specialization(const cppf_robot* robot) {
+    if (!robot) return CPPF_ERR_INVALID;
+    return robot->static_id >= 0 ? robot->static_id : (robot->rtc ? CPPF_SPECIALIZATION_RTC : -1);
+}
 
 void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 
@@ -509,6 +594,10 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                   : 0;
         const uint4* tab = static_cast<const uint4*>(robot->d_quad);
         const bool mfma = g_quad_mfma && robot->static_id >= 0 && !g_force_generic;
+        if (use_rtc(robot) && robot->rtc->fn[RTC_QUAD0]) {
+            void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&oq, (void*)&tab};
+            if (int rc = rtc_launch(robot, coll ? RTC_QUAD1 : RTC_QUAD0, grid, lds_q, st, args)) return rc;
+        } else {
 #define CPPF_BODY                                                                                                          \
     if constexpr (RB::D >= 6) {                                                                                            \
         if (coll) {                                                                                                        \
@@ -539,6 +628,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     }
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
+        }
         if (int rc = check_launch(robot)) return rc;
         if (summary_dst)
             return cppf_seed_summary(robot, oq.x_out, S, W, oq.ext_cost, oq.pos_err_m, oq.rot_err_rad, oq.self_mask, oq.env_mask,
@@ -547,7 +637,11 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     }
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
     const bool f64 = params->solver == CPPF_SOLVER_F64;
-    if (coll && (out->min_self || out->min_env)) {
+    if (use_rtc(robot) && !f64) {
+        void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)out};
+        const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
+        if (int rc = rtc_launch(robot, which, grid_for(n), 0, st, args)) return rc;
+    } else if (coll && (out->min_self || out->min_env)) {
         CPPF_REQUIRE(!f64, "CPPF_SOLVER_F64 is built for the launches without min_self / min_env");
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
@@ -592,6 +686,12 @@ int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, 
     CPPF_REQUIRE(q, "q is NULL");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
+    if (use_rtc(robot)) {
+        int n_i = (int)n;
+        void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&n_i, (void*)&q, (void*)&self_mask, (void*)&env_mask,
+                        (void*)&jlim_mask, (void*)&ext_cost, (void*)&min_self, (void*)&min_env};
+        return rtc_launch(robot, (min_self || min_env) ? RTC_COLL_MIN : RTC_COLL_MASK, grid_for(n), 0, st, args);
+    }
     if (min_self || min_env) {
 #define CPPF_BODY                                                                                                    \
     hipLaunchKernelGGL((collision_kernel<RB, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
@@ -858,7 +958,7 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     hipStream_t st = (hipStream_t)stream;
     const int d = robot->desc.ndof;
     const size_t total = (size_t)k * T * d;
-    const bool persistent = g_dp_persistent && k <= 1024 && T >= 2;
+    const bool persistent = g_dp_persistent && k <= 256 && T >= 2;
     if (persistent)  // every cost word starts as "not yet" (kernels_dp.h); 16-byte multiple, from the allocation's start
         CPPF_HIP(hipMemsetAsync(work_costsT, 0xFF, sizeof(float) * (size_t)k * T, st));
     hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
@@ -866,8 +966,14 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
     if (persistent) {
-        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost, k,
-                                             T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT));
+        if (k <= 64) {
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost,
+                                                 k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT));
+        } else {
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
+                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
+                                                 work_memoT));
+        }
         hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
                            best_path);
         return check_launch(robot);

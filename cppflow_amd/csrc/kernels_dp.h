@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
 
 // ---- the whole recurrence in ONE launch ------------------------------------------------------------------------------------------
 // T-1 dependent launches of a few microseconds each are launch-bound (1.05 ms at the reference's k = 175, T = 256).  Here
-// k single-wavefront workgroups stay resident for all T-1 steps; workgroup b owns destination b.  The only thing step t
+// the workgroups stay resident for all T-1 steps, each owning one (k <= 64) or four (k <= 256) destinations.  The only thing step t
 // needs from the other workgroups is the cost row of step t-1 -- k floats -- and that row is its own flag: the cost table is
 // pre-filled with a sentinel bit pattern (0xFFFFFFFF, which no cost can be: costs are sums of finite non-negative numbers,
 // and a NaN computed by the hardware is 0x7FC00000), every cost is stored ONCE with an agent-scope (write-through, sc1)
@@ -166,15 +166,14 @@ __device__ __forceinline__ unsigned long long dp_wave_min_to_lane63(unsigned lon
     return x;
 }
 
-// One wavefront per destination b (grid = k single-wave workgroups): lane l handles sources l, l+64, ... (at most 16 per lane,
-// k <= 1024), so a step needs neither LDS nor a workgroup barrier, and the cost-independent part (the joint changes to this
-// destination from the lane's sources, ~40 instructions per source and joint... hidden behind the ~1 us it takes the previous
-// step's costs to arrive) is small enough to finish before the hand-off does.
+// One wavefront per destination b (grid = k single-wave workgroups): lane l handles sources l, l+64, ..., so a step needs neither
+// LDS nor a workgroup barrier and the cost-independent part finishes before the hand-off does; every wavefront polls the whole
+// cost row, though (k^2 flag reads per step), which is what its step time grows with: used for k <= 64.
 template <int D>
 __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
                                                            int T, uint32_t pris_mask, float pscale, float* costsT,
                                                            int32_t* __restrict__ memoT) {
-    constexpr int AMAX = 16;
+    constexpr int AMAX = 2;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = (k + 63) >> 6;  // sources per lane (wave-uniform)
     for (int t = 1; t < T; ++t) {
@@ -219,6 +218,72 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
         if (lane == 63) {
             memoT[(size_t)t * k + b] = (int32_t)(uint32_t)key;  // read only by the back-trace launch
             dp_publish_cost(costsT + (size_t)t * k + b, dp_key_value(key));
+        }
+    }
+}
+
+// The same recurrence with FOUR destinations per workgroup: half of the polling traffic of the one-wavefront-per-destination
+// form (k^2 / 2 instead of k^2 flag reads per step, which is what bounds that form from k ~ 64 up), at the price of one LDS
+// transpose + barrier per step (wavefront i reduces destination i by DPP; the image is double-buffered by the parity of t).
+template <int D>
+__global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
+                                                             int T, uint32_t pris_mask, float pscale, float* costsT,
+                                                             int32_t* __restrict__ memoT) {
+    // 512 lanes: lane (h, a) = (tid >> 8, tid & 255) handles source a for destinations 2h and 2h + 1 of the workgroup's four, so
+    // the cost-independent part is two (source, destination) pairs per lane on two wavefronts per SIMD -- short enough to finish
+    // inside the hand-off latency for every ndof -- while each cost word is still polled by only two lanes per workgroup.
+    constexpr int BP = 4;
+    __shared__ unsigned long long keys[2][BP][256];
+    const int b0 = blockIdx.x * BP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = tid >> 8, a = tid & 255;  // k <= 256: one source per lane
+    const int asrc = min(a, k - 1);
+    for (int t = 1; t < T; ++t) {
+        const float* q_prev = qT + (size_t)(t - 1) * k * D;
+        const float* q_cur = qT + (size_t)t * k * D;
+        const float* cost_prev = costsT + (size_t)(t - 1) * k;
+        // ---- independent of the costs ----
+        float qa[D], m[2], eb[2];
+#pragma unroll
+        for (int j = 0; j < D; ++j) qa[j] = q_prev[(size_t)asrc * D + j];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int b = min(b0 + 2 * h + u, k - 1);
+            eb[u] = ext[(size_t)b * T + t];
+            float mm = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float dq = q_cur[(size_t)b * D + j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
+                mm = fmaxf(mm, fabsf(wrap_pi(dq)));
+            }
+            m[u] = mm;
+        }
+        // ---- dependent: wait for exactly the cost this lane reads ----
+        unsigned long long (*img)[256] = keys[t & 1];
+        {
+            float c = INFINITY;
+            if (a < k) c = dp_wait_cost(cost_prev + a);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float v = fmaxf(m[u], c) + eb[u];  // search.py:157-158
+                // lanes beyond k carry (+inf, 0), like the idle lanes of the per-waypoint kernel
+                img[2 * h + u][a] = a < k ? dp_key(v < INFINITY ? v : INFINITY, v < INFINITY ? a : 0) : dp_key(INFINITY, 0);
+            }
+        }
+        __syncthreads();
+        if (wave < BP) {
+            const int i = wave;
+            unsigned long long key = img[i][lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const unsigned long long o = img[i][lane + 64 * w];
+                key = o < key ? o : key;
+            }
+            key = dp_wave_min_to_lane63(key);
+            if (lane == 63 && b0 + i < k) {
+                memoT[(size_t)t * k + b0 + i] = (int32_t)(uint32_t)key;  // read only by the back-trace launch
+                dp_publish_cost(costsT + (size_t)t * k + b0 + i, dp_key_value(key));
+            }
         }
     }
 }

@@ -11,9 +11,15 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #include "../../include/cppflow_hip.h"
+
+#ifndef INFINITY
+#define INFINITY __builtin_huge_valf()
+#endif
 
 #define CPPF_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 

@@ -51,7 +51,12 @@ def _stream_ptr(device: torch.device) -> int:
 class Robot:
     PACKED_BYTES_PER_ROW = 15  # 3 x fp32 (ext_cost, pos_err_m, rot_err_rad) + 3 x u8 (self, env, jlim masks)
 
-    def __init__(self, spec: RobotSpec):
+    def __init__(self, spec: RobotSpec, specialize: Optional[bool] = None):
+        """`specialize` (default: on unless CPPF_SPECIALIZE=0): a robot that is not one of the shipped tables gets its kernels
+        compiled for it with hipRTC when its first handle is created (a few seconds once; the code object is cached on disk)."""
+        import os
+
+        self.specialize: bool = (os.environ.get("CPPF_SPECIALIZE", "1") != "0") if specialize is None else bool(specialize)
         self.spec: RobotSpec = spec
         self.chain: CanonicalChain = canonicalize(spec)
         self.name: str = spec.name
@@ -109,7 +114,22 @@ class Robot:
             self._handles[idx] = h
             self._apply_obstacles(h)
             self._apply_jl_padding(h)
+            if self.specialize and _hip.lib().cppf_robot_specialization(h) < 0:
+                # a description that matches none of the generated tables: compile-time tables through hipRTC (cached on disk)
+                rc = _hip.lib().cppf_robot_specialize(h, None)
+                if rc != _hip.CPPF_OK:
+                    import warnings
+
+                    warnings.warn(
+                        f"robot '{self.name}': run-time specialisation failed, running the generic kernels: "
+                        + _hip.lib().cppf_last_error().decode("utf-8", "replace")[:500]
+                    )
         return h
+
+    def specialization(self, device=None) -> int:
+        """>= 0: index of the generated table this robot runs; 1000: kernels compiled for it at run time (hipRTC); -1: generic."""
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        return int(_hip.lib().cppf_robot_specialization(self._handle(dev)))
 
     def __del__(self):
         try:

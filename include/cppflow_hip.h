@@ -21,8 +21,18 @@
 #ifndef CPPFLOW_HIP_H
 #define CPPFLOW_HIP_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else /* hipRTC (cppf_robot_specialize compiles this header too) has no <stdint.h>: the compiler's own fixed-width types */
+typedef __INT8_TYPE__ int8_t;
+typedef __UINT8_TYPE__ uint8_t;
+typedef __INT32_TYPE__ int32_t;
+typedef __UINT32_TYPE__ uint32_t;
+typedef __UINT64_TYPE__ uint64_t;
+typedef __SIZE_TYPE__ size_t;
+typedef __UINTPTR_TYPE__ uintptr_t;
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -123,6 +133,19 @@ int cppf_robot_ndof(const cppf_robot* robot);
 /* >= 0: index of the robot-specialised kernel set (generated tables, csrc/robots_gen.h) this handle runs; -1: the generic
  * kernels, driven by the description in the kernel-argument segment. */
 int cppf_robot_specialization(const cppf_robot* robot);
+/* Compile-time tables for a description that matches none of the generated ones (any real robot a caller brings): the fused,
+ * collision and quad kernels are compiled for THIS robot with hipRTC -- chain constants become literals, capsule end points
+ * stay in registers, exactly as for the shipped robots -- and cached on disk under `cache_dir` (NULL: $CPPF_CACHE_DIR, else
+ * $HOME/.cache/cppflow_amd) keyed by a hash of the description and of the kernel sources, so that later processes load the code
+ * object without compiling.  Results are bit-identical to the generic kernels.  After success cppf_robot_specialization()
+ * returns CPPF_SPECIALIZATION_RTC.  Stands in for jrl.robots.get_robot returning a robot class with baked-in kinematics
+ * (cppflow/data_type_utils.py:197).  A no-op (CPPF_OK) for a handle that already runs a generated table. */
+#define CPPF_SPECIALIZATION_RTC 1000
+int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir);
+/* Test hook that needs no GPU: generates the table for `desc`, compiles it with hipRTC and writes the cache entry (everything
+ * cppf_robot_specialize does before it loads the code object); returns the error of the load stage (CPPF_ERR_HIP) on a machine
+ * without a device and CPPF_OK never -- look for the cache file. */
+int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
 /* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
 void cppf_debug_force_generic(int on);
 /* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
@@ -134,7 +157,7 @@ void cppf_debug_set_pcr_max_rows(int n);
  * non-zero `on` forms J J^T of that shape with v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
  * measured comparison of DESIGN.md section 4; default off). */
 void cppf_debug_set_quad_max_rows(int n);
-/* Test hook: 0 makes cppf_dp_search issue one launch per waypoint instead of the single resident launch (k <= 1024). */
+/* Test hook: 0 makes cppf_dp_search issue one launch per waypoint instead of the single resident launch (k <= 256). */
 void cppf_debug_set_dp_persistent(int on);
 void cppf_debug_set_quad_mfma(int on);
 
@@ -276,8 +299,8 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
  * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,
  * 5.0 in the reference), then the back-trace.  Outputs best_path [T,d] and best_idx [T] (which candidate each waypoint
  * came from).  The caller supplies the workspace (device): work_qT [T*k*d] floats, work_costsT [T*k] floats (on return:
- * the cost table, time-major), work_memoT [T*k] int32.  For k <= 1024 the whole recurrence runs in ONE resident launch
- * (k single-wavefront workgroups; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are their
+ * the cost table, time-major), work_memoT [T*k] int32.  For k <= 256 (the reference plans with k = 175) the whole recurrence runs in ONE
+ * resident launch (one or four destinations per workgroup; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are their
  * own flags, no grid barrier), else one small launch per waypoint; no host synchronisation either way. */
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,

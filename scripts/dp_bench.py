@@ -8,7 +8,7 @@ from cppflow_amd.robots import get_robot
 dev = torch.device("cuda:0")
 for name in ("panda", "fetch", "chain12"):
     rb = get_robot(name)
-    for k, T in ((175, 256), (64, 256), (175, 64), (300, 256), (1024, 256)):
+    for k, T in ((175, 256), (64, 256), (96, 256), (128, 256), (175, 64), (256, 256), (1024, 256)):
         q = torch.rand((k, T, rb.ndof), device=dev)
         ext = torch.zeros((k, T), device=dev)
         qT = torch.empty((T, k, rb.ndof), device=dev); cT = torch.empty((T, k), device=dev); mT = torch.empty((T, k), dtype=torch.int32, device=dev)

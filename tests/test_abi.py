@@ -122,3 +122,31 @@ def test_graft_entry_build_runs():
 
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_run_time_specialisation_compiles_without_a_gpu(lib, tmp_path):
+    """cppf_robot_specialize's generate -> hipRTC -> cache stages need no device (cppf_debug_rtc_compile): a random 7-DoF chain
+    compiles for gfx950, the cache entry appears, and a second call finds it (no recompilation)."""
+    import time
+
+    from cppflow_amd import _hip
+    from cppflow_amd.robot_model import canonicalize
+    from tests import helpers as H
+
+    desc = _hip.chain_to_desc(canonicalize(H.random_chain_spec(7, seed=21)))
+    t0 = time.perf_counter()
+    rc = lib.cppf_debug_rtc_compile(ctypes.byref(desc), str(tmp_path).encode())
+    t_compile = time.perf_counter() - t0
+    msg = lib.cppf_last_error().decode()
+    assert rc == _hip.CPPF_ERR_HIP and "device" in msg and "compilation failed" not in msg, msg[:2000]
+    files = list(tmp_path.glob("robot_*.cppfrtc"))
+    assert len(files) == 1 and files[0].stat().st_size > 50_000
+    head = files[0].read_bytes()[:4096].split(b"\n")
+    assert head[0] == b"CPPFRTC1" and b"lm_fused_kernel" in head[1] and b"Custom" in head[1]
+    t0 = time.perf_counter()
+    lib.cppf_debug_rtc_compile(ctypes.byref(desc), str(tmp_path).encode())
+    assert time.perf_counter() - t0 < 0.5 * t_compile + 0.05  # served from the cache
+    # a different robot gets a different entry
+    desc2 = _hip.chain_to_desc(canonicalize(H.random_chain_spec(7, seed=22)))
+    lib.cppf_debug_rtc_compile(ctypes.byref(desc2), str(tmp_path).encode())
+    assert len(list(tmp_path.glob("robot_*.cppfrtc"))) == 2

