@@ -48,6 +48,15 @@ import numpy as np
 
 torch = None  # imported by main() AFTER the launcher decision: the parent of an N > 1 run never loads a GPU runtime
 
+
+def _ensure_torch():
+    """helpers below are also imported by scripts/ (which never go through main()'s launcher decision)"""
+    global torch
+    if torch is None:
+        import torch as _torch
+
+        torch = _torch
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -108,6 +117,7 @@ def issue_record_from_profiles(robot, S, W, K, collide, inputs):
 
 
 def make_inputs(robot, S, W, device, seed):
+    _ensure_torch()
     g = torch.Generator(device="cpu").manual_seed(seed)
     lo = torch.tensor([l for l, _ in robot.actuated_joints_limits], dtype=torch.float32)
     hi = torch.tensor([u for _, u in robot.actuated_joints_limits], dtype=torch.float32)
@@ -133,6 +143,7 @@ def make_inputs_problem(robot, S, W, device, seed):
     warm-started from its predecessor, a branch that loses the path continuing on one that did not -- what IKFlow + dp_search
     hand to the optimiser), then x0 = clamp(q*_s + 0.1 randn)
     (the construction of the reference's tests/optimization_test.py:82).  Returns (x0 [S*W,d], target [W,7], description)."""
+    _ensure_torch()
     g = torch.Generator(device="cpu").manual_seed(seed)
     lo = torch.tensor([l for l, _ in robot.actuated_joints_limits], dtype=torch.float32)
     hi = torch.tensor([u for _, u in robot.actuated_joints_limits], dtype=torch.float32)
@@ -195,6 +206,7 @@ def cpu_baseline_torch(robot_name, obstacles, d, W, K, budget_s=12.0):
     (cppflow/optimization.py:73-92: in-place row scaling, bmm x2, eye.repeat, torch.linalg.solve, python-loop clamp;
     cppflow/collision_detection.py:27-69: distance tensors -> min -> "< 0") with batched-torch kinematics standing in for
     the un-vendored jrl.  fp32, torch's default CPU threads, on a bounded sample of the same workload."""
+    _ensure_torch()
     from cppflow_amd.robot_model import canonicalize
     from cppflow_amd.robot_zoo import ROBOT_SPECS
     from oracle import ref_torch
@@ -298,6 +310,9 @@ def parse_args(argv=None):
                     help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
                     "fill the chip with two launches in flight)")  # fmt: skip
     ap.add_argument("--shape", choices=["auto", "row", "quad"], default="auto", help="kernel shape (cppf_lm_params.shape)")
+    ap.add_argument("--solver", choices=["f32", "f64"], default="f32",
+                    help="precision of the damped solve (cppf_lm_params.solver): f32 = the reference's dtype (the headline); f64 = "
+                    "exact to rounding on near-singular rows too")  # fmt: skip
     ap.add_argument("--inputs", choices=["problem", "random"], default="problem",
                     help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); "
                     "random: independent random configurations per waypoint (the 8d fall-back, worst case for the broad phase)")  # fmt: skip
@@ -390,7 +405,7 @@ class Runner:
     sets, `n_streams` launch streams, and -- with a transport -- the bucketed all-gather of the per-seed summaries on an
     auxiliary stream followed by the seed selection over every rank's seeds."""
 
-    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device):
+    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0):
         from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
 
         self.robot, self.x0, self.target, self.K, self.collide, self.device = robot, x0, target, K, collide, device
@@ -405,10 +420,10 @@ class Runner:
                         for _ in range(NBUF)]  # fmt: skip
         self.summ_all = torch.empty((NBUF, self.S, 8), dtype=torch.float32, device=device) if collide else None
         self.transport = transport if collide else None
-        self.shape = shape
+        self.shape, self.solver = shape, solver
         if collide:
             self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=self.summ_all[b],
-                                               shape=shape, **prm)
+                                               shape=shape, solver=solver, **prm)
                           for b, (xo, pk) in enumerate(zip(self.x_outs, self.packeds))]  # fmt: skip
             self.outputs = self.plans[0].outputs
         else:
@@ -434,7 +449,7 @@ class Runner:
             self.plans[0].launch()
         else:
             self.robot.lm_pose_steps(self.x0, self.target, n_steps=self.K, clamp=True, x_out=self.x_outs[0], want_errors=True,
-                                     shape=self.shape, **self.prm)  # fmt: skip
+                                     shape=self.shape, solver=self.solver, **self.prm)  # fmt: skip
 
     def step(self):
         if not self.collide:
@@ -623,6 +638,7 @@ def main():
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
     shape = {"auto": _hip.SHAPE_AUTO, "row": _hip.SHAPE_ROW, "quad": _hip.SHAPE_QUAD}[args.shape]
+    solver = {"f32": _hip.SOLVER_F32, "f64": _hip.SOLVER_F64}[args.solver]
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
     S_cfg = args.seeds
@@ -662,7 +678,7 @@ def main():
     n_streams = args.streams if args.streams > 0 else (4 if (scaling == "strong" and world > 1) else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
-    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device)
+    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver)
     n = run.n
     elapsed = max_over_ranks(run.timed(args.steps, args.warmup, args.prewarm_ms, barrier))
     host_us = run.host_enqueue_us()
@@ -671,7 +687,8 @@ def main():
     # sanity on the result of the last step (not timed): most rows converged
     outputs = run.outputs
     if outputs is None:
-        outputs = robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=run.x_outs[0], want_errors=True, shape=shape, **run.prm)
+        outputs = robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=run.x_outs[0], want_errors=True, shape=shape,
+                                      solver=solver, **run.prm)
     conv_frac = float((outputs["pos_err_m"] < 1e-4).float().mean().item())
     selected = None
     if run.selected is not None:
@@ -708,7 +725,7 @@ def main():
     def measure_sibling(S_local, mode, kind, streams, steps):
         """a second workload / pipeline depth measured like the headline (same barriers, same max over ranks)"""
         xs, tg, _ = inputs_for(S_local, mode, kind)
-        r2 = Runner(robot, xs, tg, K, collide, streams, G, transport, world, shape, device)
+        r2 = Runner(robot, xs, tg, K, collide, streams, G, transport, world, shape, device, solver)
         el = max_over_ranks(r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier))
         km = r2.kernel_ms(min(max(steps, 50), 500))
         rows = float(r2.n) * world
@@ -741,7 +758,7 @@ def main():
         t_k = kernel_ms * 1e-3
         alg_tflops = alg_flops / t_k / 1e12
         ach_gbps = bytes_launch / t_k / 1e9
-        rec = issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs)
+        rec = issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs) if args.solver == "f32" else None
         roof = {
             # the binding resource is the fp32 VALU issue rate (157.3 TFLOP/s of FMAs = one wave-instruction per SIMD per 2
             # cycles); the contract's vocabulary has no word for it, so `bound` says what it is and `mfma_used` that no
@@ -807,6 +824,7 @@ def main():
                 "inputs": inputs_desc,
                 "streams": run.n_streams,
                 "kernel_shape": args.shape,
+                "solver": args.solver + (" (the reference's dtype)" if args.solver == "f32" else " (J J^T, factorisation, substitutions, J^T y in double precision)"),
                 "early_out": "off (every row runs all K iterations: the metric counts K iterations per row)",
                 "prewarm_ms": args.prewarm_ms,
                 "host_enqueue_us_per_step": host_us,

@@ -397,7 +397,7 @@ int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
     std::vector<std::string> names;
     std::string code;
     if (!rtc_cache_read(file, names, code)) {
-        if (int rc = rtc_compile(source, names, code)) return rc;
+        if (int rc = rtc_compile(source, with_quad, names, code)) return rc;
         rtc_cache_write(dir, file, names, code);
     }
     // (compiling and caching need no device; loading does)

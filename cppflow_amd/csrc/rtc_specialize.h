@@ -228,12 +228,14 @@ void rtc_cache_write(const std::string& dir, const std::string& file, const std:
     (void)std::rename(tmp.c_str(), file.c_str());
 }
 
-int rtc_compile(const std::string& source, std::vector<std::string>& names, std::string& code) {
+int rtc_compile(const std::string& source, bool with_quad, std::vector<std::string>& names, std::string& code) {
     if (int rc = load_hiprtc()) return rc;
     RtcProgram prog = nullptr;
     int r = g_rtc.CreateProgram(&prog, source.c_str(), "cppf_custom_robot.hip", kEmbeddedCount, kEmbeddedSources, kEmbeddedNames);
     if (r != 0) return fail(CPPF_ERR_HIP, std::string("cppflow_hip: hiprtcCreateProgram: ") + g_rtc.GetErrorString(r));
-    for (int i = 0; i < RTC_COUNT; ++i) (void)g_rtc.AddNameExpression(prog, kRtcNameExpr[i]);
+    auto wanted = [&](int i) { return with_quad || (i != RTC_QUAD0 && i != RTC_QUAD1); };  // the quad shape needs ndof >= 6
+    for (int i = 0; i < RTC_COUNT; ++i)
+        if (wanted(i)) (void)g_rtc.AddNameExpression(prog, kRtcNameExpr[i]);
     r = g_rtc.CompileProgram(prog, kRtcOptionCount, kRtcOptions);
     if (r != 0) {
         size_t n = 0;
@@ -248,6 +250,10 @@ int rtc_compile(const std::string& source, std::vector<std::string>& names, std:
     names.clear();
     for (int i = 0; i < RTC_COUNT; ++i) {
         const char* low = nullptr;
+        if (!wanted(i)) {
+            names.push_back("-");
+            continue;
+        }
         r = g_rtc.GetLoweredName(prog, kRtcNameExpr[i], &low);
         if (r != 0 || !low) {
             (void)g_rtc.DestroyProgram(&prog);

@@ -1,11 +1,28 @@
 #!/usr/bin/env python3
-"""Launch a few labelled variants once each (after warm-up) so that a rocprofv3 --pmc pass attributes counters per dispatch."""
-import os, sys
-import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import make_inputs, make_inputs_problem
-from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays
-from cppflow_amd.robots import get_robot
+"""Launch a fixed list of labelled variants (three rounds; the last one is summarised) so that a rocprofv3 --pmc pass attributes
+counters per dispatch.  The labels, in dispatch order, go to gpurun_out/rec/pmc_labels.json for scripts/summarize_profiles.py.
+
+Variants (Panda, 2 cuboids, K = 10 unless stated):
+  A  row shape, 262 144 rows, no collision (random inputs)          B  the same, K = 20
+  C  row shape + collision, random inputs                             D  collision_masks alone, random inputs
+  E  the bench launch: row + collision + summary, problem inputs     F  E with the fp64 solve
+  G  C2 (128 x 64 rows), row shape                                    H  C2, quad shape       I  C2, quad shape + MFMA J J^T
+  J  16 384 rows (64 x 256), K = 20, row    K  quad    L  quad + MFMA (the measured MFMA question)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import make_inputs, make_inputs_problem  # noqa: E402
+from cppflow_amd import _hip  # noqa: E402
+from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arrays  # noqa: E402
+from cppflow_amd.robots import get_robot  # noqa: E402
+
 name = sys.argv[1] if len(sys.argv) > 1 else "panda"
 rb = get_robot(name)
 obs = obstacle_arrays(PANDA_2CUBES_OBSTACLES)
@@ -13,16 +30,54 @@ rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
 rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
 dev = torch.device("cuda:0")
 S, W = 1024, 256
+LM = (1e-6, 3.5, 0.35)
 x0, target = make_inputs(rb, S, W, dev, 0)
 xo = torch.empty_like(x0)
 pk = torch.empty(rb.PACKED_BYTES_PER_ROW * S * W, dtype=torch.uint8, device=dev)
 xp, tp, _ = make_inputs_problem(rb, S, W, dev, 0) if name == "panda" else (x0, target, "")
 sm = torch.empty((S, 8), dtype=torch.float32, device=dev)
+xc2, tc2, _ = make_inputs_problem(rb, 128, 64, dev, 0) if name == "panda" else (x0[: 128 * 64], target[:64], "")
+xo2 = torch.empty_like(xc2)
+x16 = xp[: 64 * 256].contiguous()
+xo16 = torch.empty_like(x16)
+ROW, QUAD = _hip.SHAPE_ROW, _hip.SHAPE_QUAD
+mfma = _hip.lib().cppf_debug_set_quad_mfma
+
+variants = [
+    ("A: row, 262144 rows, K=10, no collision (random inputs)", lambda: rb.lm_pose_steps(x0, target, *LM, n_steps=10, x_out=xo, want_errors=True, shape=ROW)),
+    ("B: row, 262144 rows, K=20, no collision (random inputs)", lambda: rb.lm_pose_steps(x0, target, *LM, n_steps=20, x_out=xo, want_errors=True, shape=ROW)),
+    ("C: row, K=10 + collision (random inputs, no summary)", lambda: rb.lm_pose_steps(x0, target, *LM, n_steps=10, x_out=xo, packed_out=pk, shape=ROW)),
+    ("D: collision_masks alone (random inputs)", lambda: rb.collision_masks(x0.reshape(S, W, -1))),
+    ("E: the bench launch: row, K=10 + collision + per-seed summary, problem inputs", lambda: rb.lm_pose_steps(xp, tp, *LM, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=ROW)),
+    ("F: E with the fp64 solve (CPPF_SOLVER_F64)", lambda: rb.lm_pose_steps(xp, tp, *LM, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=ROW, solver=_hip.SOLVER_F64)),
+    ("G: C2 = 128 x 64 rows, K=10, no collision, row shape", lambda: rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=ROW)),
+    ("H: C2, quad shape (VALU J J^T)", lambda: (mfma(0), rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=QUAD))),
+    ("I: C2, quad shape, J J^T by v_mfma_f32_4x4x1", lambda: (mfma(1), rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=QUAD), mfma(0))),
+    ("J: 16384 rows, K=20, no collision, row shape", lambda: rb.lm_pose_steps(x16, tp, *LM, n_steps=20, x_out=xo16, shape=ROW)),
+    ("K: 16384 rows, K=20, quad shape (VALU J J^T)", lambda: (mfma(0), rb.lm_pose_steps(x16, tp, *LM, n_steps=20, x_out=xo16, shape=QUAD))),
+    ("L: 16384 rows, K=20, quad shape, J J^T by v_mfma_f32_4x4x1", lambda: (mfma(1), rb.lm_pose_steps(x16, tp, *LM, n_steps=20, x_out=xo16, shape=QUAD), mfma(0))),
+]
+# the bench launches of BASELINE configs C3 and C5 (bench.py --config C3 / C5): keys of profiles/r2_issue.json
+if name == "panda":
+    fetch = get_robot("fetch")
+    fetch.set_obstacles([], [])
+    fetch.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    x3, t3, _ = make_inputs_problem(fetch, 512, 256, dev, 0)
+    xo3, pk3, sm3 = torch.empty_like(x3), torch.empty(fetch.PACKED_BYTES_PER_ROW * 512 * 256, dtype=torch.uint8, device=dev), torch.empty((512, 8), device=dev)
+    variants.append(("M: bench --config C3: fetch 512 x 256, row, K=10 + self-collision + summary, problem inputs",
+                     lambda: fetch.lm_pose_steps(x3, t3, *LM, n_steps=10, x_out=xo3, packed_out=pk3, summary_out=sm3, shape=ROW)))
+    c12 = get_robot("chain12")
+    c12.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    c12.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    x5, t5, _ = make_inputs_problem(c12, 4096, 512, dev, 0)
+    xo5, pk5, sm5 = torch.empty_like(x5), torch.empty(c12.PACKED_BYTES_PER_ROW * 4096 * 512, dtype=torch.uint8, device=dev), torch.empty((4096, 8), device=dev)
+    variants.append(("N: bench --config C5: chain12 4096 x 512, row, K=10 + collision + summary, problem inputs",
+                     lambda: c12.lm_pose_steps(x5, t5, *LM, n_steps=10, x_out=xo5, packed_out=pk5, summary_out=sm5, shape=ROW)))
+os.makedirs(os.path.join(ROOT, "gpurun_out", "rec"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "rec", "pmc_labels.json"), "w") as f:
+    json.dump([v[0] for v in variants], f, indent=1)
 torch.cuda.synchronize()
 for rep in range(3):
-    rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=10, x_out=xo, want_errors=True)      # dispatch A: K=10 no coll
-    rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=20, x_out=xo, want_errors=True)      # dispatch B: K=20 no coll
-    rb.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=10, x_out=xo, packed_out=pk)         # dispatch C: K=10 coll
-    rb.collision_masks(x0.reshape(S, W, -1))                                                    # dispatch D: collision only
-    rb.lm_pose_steps(xp, tp, 1e-6, 3.5, 0.35, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm)  # dispatch E: the bench launch (problem inputs, + summary)
+    for _, fn in variants:
+        fn()
 torch.cuda.synchronize()

@@ -1,42 +1,62 @@
 #!/usr/bin/env bash
 # Round-end measurement pass on the MI355X box (run from the repo root through gpurun); everything lands in gpurun_out/rec/.
 # Counter passes are separate rocprofv3 runs with --pmc only (no trace domains), as MI355X_MICROARCH.md prescribes.
+#   bash scripts/record_pass.sh [quick]        ("quick" skips the test suite and the slow side benches)
 set -eo pipefail
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out/rec"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-echo "== pytest -m gpu"
-timeout -k 10 600 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$OUT/pytest_gpu.txt"
-echo "== bench (default)"
+QUICK="${1:-}"
+if [ -z "$QUICK" ]; then
+    echo "== pytest -m gpu"
+    timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$OUT/pytest_gpu.txt"
+fi
+echo "== bench (default: N = 1, C4, + one_stream / random_inputs siblings, + cpu baselines)"
 timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"
-echo "== bench, one stream"
-timeout -k 10 300 python bench.py --no-cpu-baseline --streams 1 > "$OUT/bench_streams1.json" 2>> "$OUT/bench.err"
-echo "== bench, random inputs (SURVEY 8d fall-back; worst case for the broad phase)"
-timeout -k 10 300 python bench.py --no-cpu-baseline --inputs random > "$OUT/bench_random_inputs.json" 2>> "$OUT/bench.err"
-echo "== bench, one-rank RCCL group"
-CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > "$OUT/bench_dist1.json" 2>> "$OUT/bench.err"
+echo "== bench, one-rank RCCL group (collective + seed selection on the dependency path)"
+CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings > "$OUT/bench_dist1.json" 2>> "$OUT/bench.err"
+echo "== bench, two ranks sharing the one GPU (host-staged gloo: choreography rehearsal, NOT a multi-GPU result)"
+CPPF_BENCH_SHARE_GPU=1 timeout -k 10 300 python bench.py --gpus 2 --steps 300 --warmup 48 > "$OUT/bench_2ranks_rehearsal.json" 2>> "$OUT/bench.err"
+echo "== bench, the fp64 solve"
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings --solver f64 > "$OUT/bench_solver_f64.json" 2>> "$OUT/bench.err"
 for c in C2 C3 C5; do
     echo "== bench --config $c"
-    timeout -k 10 300 python bench.py --no-cpu-baseline --config $c > "$OUT/bench_$c.json" 2>> "$OUT/bench.err"
+    timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings --config $c > "$OUT/bench_$c.json" 2>> "$OUT/bench.err"
 done
-echo "== kbench"
-timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
-echo "== launch model"
-timeout -k 10 300 python scripts/launch_model.py > "$OUT/launch_model.txt" 2>&1
-echo "== iterations per launch (steady state)"
-for k in 10 20 30; do timeout -k 10 300 python bench.py --no-cpu-baseline --lm-steps $k | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('K =', d['config']['lm_iterations_per_step'], ' step', round(d['ms_per_step']*1e3,2), 'us  isolated kernel', round(d['roofline']['kernel_ms']*1e3,2), 'us')" >> "$OUT/launch_model.txt"; done
+echo "== strong-scaling shards on one GPU (what each of 2 / 4 / 8 GPUs runs under --scaling strong), 2 / 4 / 8 launches in flight"
+for s in 512 256 128; do for st in 2 4 8; do
+    timeout -k 10 200 python bench.py --seeds $s --steps 1000 --warmup 100 --streams $st --no-cpu-baseline --no-siblings 2>> "$OUT/bench.err" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('seeds/GPU', d['config']['seeds_per_gpu'], ' streams', d['config']['streams'], ' us/step %.2f' % (d['ms_per_step']*1e3), ' isolated kernel %.2f us' % (d['roofline']['kernel_ms']*1e3), ' host %.1f us/step' % d['config']['host_enqueue_us_per_step'])" >> "$OUT/shard_streams.txt"
+done; done
+cat "$OUT/shard_streams.txt"
+echo "== shard_bench (isolated latency by kernel shape)"
+timeout -k 10 300 python scripts/shard_bench.py --shapes row,quad --sizes 8,32,64,128,256,512,1024 > "$OUT/shard_bench.txt" 2>&1
+timeout -k 10 300 python scripts/shard_bench.py --shapes quad --mfma 1 --sizes 8,32,64 > "$OUT/shard_bench_mfma.txt" 2>&1
+timeout -k 10 200 python scripts/ksweep.py > "$OUT/ksweep.txt" 2>&1
+echo "== dp_search"
+timeout -k 10 300 python scripts/dp_bench.py > "$OUT/dp_bench.txt" 2>&1
+if [ -z "$QUICK" ]; then
+    echo "== kbench"
+    timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
+    timeout -k 10 300 python scripts/kbench_small.py > "$OUT/kbench_small.txt" 2>&1
+    echo "== launch model"
+    timeout -k 10 300 python scripts/launch_model.py > "$OUT/launch_model.txt" 2>&1
+    echo "== run-time specialisation"
+    timeout -k 10 300 python scripts/rtc_bench.py > "$OUT/rtc_bench.txt" 2>&1
+fi
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --no-siblings --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
 echo "== rocprofv3 pmc FETCH_SIZE"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
 echo "== rocprofv3 pmc WRITE_SIZE"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
-echo "== rocprofv3 pmc SQ instruction counters (two passes)"
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_valu" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu_stderr.txt"
-timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu2" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_valu2_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
+echo "== rocprofv3 pmc SQ counters over scripts/pmc_probe.py (four passes)"
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_p1" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p1_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_p2" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p2_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 --output-format csv -d "$OUT/pmc_p3" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p3_stderr.txt"
+timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_p4" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p4_stderr.txt"
 cd "$ROOT"
 if [ -x build_var/valu_rate ]; then
     echo "== VALU issue-rate calibration (hipcc --offload-arch=gfx950 -O3 scripts/ubench/valu_rate.hip -o build_var/valu_rate)"

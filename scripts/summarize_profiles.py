@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 databases of scripts/record_pass.sh (gpurun_out/rec/) into the small summaries kept under profiles/.
 
-    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r1]
+    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r2]
+
+Writes  <tag>_fused_kernel_stats.csv (rocprofv3's own kernel_stats), <tag>_pmc_summary.json (kernel-trace duration of the bench
+launch, FETCH / WRITE_SIZE, and per labelled variant of scripts/pmc_probe.py every SQ counter of the four counter passes with the
+derived per-row / per-iteration figures), <tag>_traffic.json and <tag>_issue.json (what bench.py's roofline object reads), the
+MFMA comparison <tag>_mfma_quad.json, and copies of the text / JSON outputs of the pass.
 """
 import csv
 import json
@@ -12,8 +17,9 @@ import sys
 
 REC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/rec"
 OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-TAG = sys.argv[3] if len(sys.argv) > 3 else "r1"
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r2"
 FUSED = "lm_fused_kernel"
+PROBE_KERNELS = ("lm_fused_kernel", "lm_quad_kernel", "collision_kernel")
 
 
 def read_csv(rel):
@@ -35,6 +41,29 @@ def counter(rel, name, grid):
             if r["Counter_Name"] == name and FUSED in r["Kernel_Name"] and int(r["Grid_Size"]) == grid]  # fmt: skip
 
 
+def probe_dispatches(rel, n_variants):
+    """The last round of scripts/pmc_probe.py: one dict of counters per labelled variant, in dispatch order."""
+    by_id = {}
+    for r in read_csv(rel):
+        if any(k in r["Kernel_Name"] for k in PROBE_KERNELS):
+            e = by_id.setdefault(int(r["Dispatch_Id"]), {"kernel": r["Kernel_Name"][:110], "grid": int(r["Grid_Size"]),
+                                                          "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})  # fmt: skip
+            e[r["Counter_Name"]] = float(r["Counter_Value"])
+    return [by_id[k] for k in sorted(by_id)][-n_variants:]
+
+
+ROWS = {"A": 262144, "B": 262144, "C": 262144, "D": 262144, "E": 262144, "F": 262144, "G": 8192, "H": 8192, "I": 8192, "J": 16384,
+        "K": 16384, "L": 16384, "M": 131072, "N": 2097152}  # fmt: skip
+ITERS = {"A": 10, "B": 20, "C": 10, "D": 0, "E": 10, "F": 10, "G": 10, "H": 10, "I": 10, "J": 20, "K": 20, "L": 20, "M": 10, "N": 10}
+ISSUE_KEYS = {  # variant -> key of bench.py's workload_key()
+    "E": "panda_S1024_W256_K10_coll1",
+    "C": "panda_S1024_W256_K10_coll1_random",
+    "G": "panda_S128_W64_K10_coll0",
+    "M": "fetch_S512_W256_K10_coll1",
+    "N": "chain12_S4096_W512_K10_coll1",
+}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     bench = json.load(open(os.path.join(REC, "bench.json")))
@@ -45,34 +74,79 @@ def main():
     write = counter("pmc_write/pmc_counter_collection.csv", "WRITE_SIZE", grid)
     for key, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         summary[key] = {"dispatches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
-    # scripts/pmc_probe.py: variants A..E, three rounds; keep the last round.  Two counter passes over the same script.
-    labels = ("A: K=10, no collision (random inputs)", "B: K=20, no collision (random inputs)",
-              "C: K=10 + collision (random inputs, no summary)", "D: collision_masks alone (random inputs)",
-              "E: the bench launch: K=10 + collision + per-seed summary, problem inputs")  # fmt: skip
+    labels = json.load(open(os.path.join(REC, "pmc_labels.json")))
     disp = [{"variant": lab} for lab in labels]
-    for rel in ("pmc_valu/pmc_counter_collection.csv", "pmc_valu2/pmc_counter_collection.csv"):
+    for p in ("pmc_p1", "pmc_p2", "pmc_p3", "pmc_p4"):
+        rel = f"{p}/pmc_counter_collection.csv"
         if not os.path.exists(os.path.join(REC, rel)):
             continue
-        sq = {}
-        for r in read_csv(rel):
-            if "cppf" in r["Kernel_Name"] and int(r["Grid_Size"]) == 1024 * 256:
-                e = sq.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"][:100],
-                                                          "dur_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})  # fmt: skip
-                e[r["Counter_Name"]] = float(r["Counter_Value"])
-        last = [sq[k] for k in sorted(sq)][-len(labels):]
-        for d, e in zip(disp, last):
+        for d, e in zip(disp, probe_dispatches(rel, len(labels))):
             for k, v in e.items():
-                d[k if k not in ("dur_ns",) or k not in d else "dur_ns_pass2"] = v
+                if k == "dur_ns":
+                    d.setdefault("dur_ns_by_pass", {})[p] = v
+                elif k in ("kernel", "grid"):
+                    assert d.setdefault(k, v) == v, (d["variant"], k, d[k], v)  # the four passes see the same dispatches
+                else:
+                    d[k] = v
+    issue, SIMDS, GHZ = {}, 1024, 2.4
     for d in disp:
-        d["valu_per_row"] = d["SQ_INSTS_VALU"] * 64 / (1024 * 256) if "SQ_INSTS_VALU" in d else None
+        tag = d["variant"][0]
+        rows, its = ROWS[tag], ITERS[tag]
+        if "SQ_INSTS_VALU" in d:
+            d["valu_per_row"] = d["SQ_INSTS_VALU"] * 64 / rows
+            d["valu_issue_us_at_peak"] = d["SQ_INSTS_VALU"] * 2 / SIMDS / (GHZ * 1e3)
+            d["valu_issue_frac"] = d["valu_issue_us_at_peak"] / (d["dur_ns_by_pass"]["pmc_p1"] * 1e-3)
+        if "SQ_INSTS_VALU_FMA_F32" in d and "SQ_INSTS_VALU" in d:
+            f32 = 2 * d["SQ_INSTS_VALU_FMA_F32"] + d["SQ_INSTS_VALU_ADD_F32"] + d["SQ_INSTS_VALU_MUL_F32"] + d["SQ_INSTS_VALU_TRANS_F32"]
+            f64 = 2 * d.get("SQ_INSTS_VALU_FMA_F64", 0) + d.get("SQ_INSTS_VALU_ADD_F64", 0) + d.get("SQ_INSTS_VALU_MUL_F64", 0)
+            d["executed_flops_per_row"] = (f32 + f64) * 64 / rows
+            d["flops_per_valu_lane_op"] = (f32 + f64) / d["SQ_INSTS_VALU"]
+            d["executed_tflops"] = (f32 + f64) * 64 / (d["dur_ns_by_pass"]["pmc_p1"] * 1e-9) / 1e12
+        if "SQ_WAIT_INST_ANY" in d and "SQ_WAVE_CYCLES" in d:
+            d["issue_stall_frac_of_wave_cycles"] = d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"]
+        if tag in ISSUE_KEYS and "flops_per_valu_lane_op" in d:
+            issue[ISSUE_KEYS[tag]] = {
+                "valu_insts_per_launch": d["SQ_INSTS_VALU"],
+                "flops_per_valu_lane_op": round(d["flops_per_valu_lane_op"], 4),
+                "fma_f32": d["SQ_INSTS_VALU_FMA_F32"], "add_f32": d["SQ_INSTS_VALU_ADD_F32"], "mul_f32": d["SQ_INSTS_VALU_MUL_F32"],
+                "trans_f32": d["SQ_INSTS_VALU_TRANS_F32"], "kernel_us_profiled": d["dur_ns_by_pass"]["pmc_p1"] * 1e-3,
+                "variant": d["variant"],
+            }  # fmt: skip
+    by = {d["variant"][0]: d for d in disp}
+    if "A" in by and "B" in by and "SQ_INSTS_VALU" in by["A"]:
+        summary["row_shape_valu_per_row_iteration"] = (by["B"]["SQ_INSTS_VALU"] - by["A"]["SQ_INSTS_VALU"]) * 64 / ROWS["A"] / 10
     summary["sq_counters_scripts_pmc_probe_last_round"] = disp
     with open(os.path.join(OUT, f"{TAG}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    issue["_how"] = ("rocprofv3 --pmc SQ_INSTS_VALU ... / --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 "
+                     "-- python3 scripts/pmc_probe.py (scripts/record_pass.sh): wave-instruction counts of ONE launch of the matching workload.  "
+                     "flops_per_valu_lane_op = (2 FMA + ADD + MUL + TRANS) / VALU: executed flops per VALU lane-operation, measured, not modelled.")  # fmt: skip
+    with open(os.path.join(OUT, f"{TAG}_issue.json"), "w") as f:
+        json.dump(issue, f, indent=1)
+    # the MFMA question: quad shape, J J^T on the VALU (rotated operands, FMAs) vs v_mfma_f32_4x4x1
+    mf = {}
+    for a, b, what in (("H", "I", "C2: Panda 128 x 64 = 8192 rows, K = 10, no collision"), ("K", "L", "Panda 64 x 256 = 16384 rows, K = 20, no collision")):
+        if a in by and b in by and "SQ_INSTS_VALU" in by[a]:
+            keep = ("dur_ns_by_pass", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU",
+                    "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES",
+                    "SQ_INSTS_VALU_MFMA_F32", "SQ_WAIT_ANY", "valu_per_row", "issue_stall_frac_of_wave_cycles")  # fmt: skip
+            its = ITERS[a]
+            mf[what] = {
+                "valu": {k: by[a].get(k) for k in keep},
+                "mfma": {k: by[b].get(k) for k in keep},
+                "us_per_launch_valu": by[a]["dur_ns_by_pass"]["pmc_p1"] * 1e-3,
+                "us_per_launch_mfma": by[b]["dur_ns_by_pass"]["pmc_p1"] * 1e-3,
+                "valu_insts_per_row_iteration_valu": by[a]["SQ_INSTS_VALU"] * 64 / ROWS[a] / its / 4 * 4,
+                "valu_insts_per_row_iteration_mfma": by[b]["SQ_INSTS_VALU"] * 64 / ROWS[b] / its / 4 * 4,
+                "note": "per ROW, i.e. summed over the four lanes of the quad: divide by 4 for the instructions one wavefront issues per iteration",
+            }
+    with open(os.path.join(OUT, f"{TAG}_mfma_quad.json"), "w") as f:
+        json.dump(mf, f, indent=1)
     key = f"{cfg['robot']}_S{cfg['seeds_per_gpu']}_W{cfg['waypoints']}_K{cfg['lm_iterations_per_step']}_coll{int(cfg['collision_fused'])}"
     fk, wk = summary["FETCH_SIZE"]["mean_KB"], summary["WRITE_SIZE"]["mean_KB"]
     traffic = {
-        "_how": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --streams 1 ; rocprofv3 --pmc "
-        "WRITE_SIZE -- (same): scripts/record_pass.sh.  Mean over the lm_fused_kernel dispatches.  FETCH_SIZE (KB) is doubled "
+        "_how": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 ; "
+        "rocprofv3 --pmc WRITE_SIZE -- (same): scripts/record_pass.sh.  Mean over the lm_fused_kernel dispatches.  FETCH_SIZE (KB) is doubled "
         "(gfx950 reports half the bytes of a coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) is exact.",
         key: {
             "FETCH_SIZE_KB": round(fk, 2),
@@ -84,13 +158,15 @@ def main():
     }
     with open(os.path.join(OUT, f"{TAG}_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=2)
-    for src, dst in (("bench.json", "bench.json"), ("bench_streams1.json", "bench_streams1.json"), ("bench_dist1.json", "bench_dist1.json"),
-                     ("bench_random_inputs.json", "bench_random_inputs.json"), ("valu_issue_rate_calibration.txt", "valu_issue_rate_calibration.txt"),
-                     ("bench_C2.json", "bench_C2.json"), ("bench_C3.json", "bench_C3.json"), ("bench_C5.json", "bench_C5.json"),
-                     ("kbench.txt", "kbench.txt"), ("launch_model.txt", "launch_model.txt"), ("pytest_gpu.txt", "pytest_gpu.txt")):  # fmt: skip
+    for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_C2.json", "bench_C3.json",
+                "bench_C5.json", "shard_streams.txt", "shard_bench.txt", "shard_bench_mfma.txt", "ksweep.txt", "dp_bench.txt", "kbench.txt",
+                "kbench_small.txt", "launch_model.txt", "rtc_bench.txt", "pytest_gpu.txt", "valu_issue_rate_calibration.txt"):  # fmt: skip
         if os.path.exists(os.path.join(REC, src)):
-            shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{dst}"))
-    print(json.dumps(summary, indent=1)[:3000])
+            shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{src}"))
+    print(json.dumps({k: v for k, v in summary.items() if k != "sq_counters_scripts_pmc_probe_last_round"}, indent=1))
+    for d in disp:
+        print(d["variant"][:60].ljust(62), {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()
+                                            if k in ("valu_per_row", "valu_issue_frac", "flops_per_valu_lane_op", "executed_tflops", "issue_stall_frac_of_wave_cycles")})  # fmt: skip
 
 
 if __name__ == "__main__":
