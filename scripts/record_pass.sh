@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round-end measurement pass on the MI355X box (run from the repo root through gpurun); everything lands in gpurun_out/rec/.
 # Counter passes are separate rocprofv3 runs with --pmc only (no trace domains), as MI355X_MICROARCH.md prescribes.
-#   bash scripts/record_pass.sh [quick]        ("quick" skips the test suite and the slow side benches)
+#   bash scripts/record_pass.sh [quick|pmc]    ("quick" skips the test suite and the slow side benches, "pmc" runs the profiler passes only)
 set -eo pipefail
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out/rec"
@@ -12,6 +12,7 @@ if [ -z "$QUICK" ]; then
     echo "== pytest -m gpu"
     timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$OUT/pytest_gpu.txt"
 fi
+if [ "$QUICK" != "pmc" ]; then
 echo "== bench (default: N = 1, C4, + one_stream / random_inputs siblings, + cpu baselines)"
 timeout -k 10 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"
@@ -45,6 +46,7 @@ if [ -z "$QUICK" ]; then
     echo "== run-time specialisation"
     timeout -k 10 300 python scripts/rtc_bench.py > "$OUT/rtc_bench.txt" 2>&1
 fi
+fi
 echo "== rocprofv3 kernel trace"
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --no-siblings --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
@@ -54,9 +56,13 @@ echo "== rocprofv3 pmc WRITE_SIZE"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"
 echo "== rocprofv3 pmc SQ counters over scripts/pmc_probe.py (four passes)"
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_p1" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p1_stderr.txt"
+python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p1/pmc_counter_collection.csv" 14
 timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_p2" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p2_stderr.txt"
+python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p2/pmc_counter_collection.csv" 14
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 --output-format csv -d "$OUT/pmc_p3" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p3_stderr.txt"
+python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p3/pmc_counter_collection.csv" 14
 timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_p4" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p4_stderr.txt"
+python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p4/pmc_counter_collection.csv" 14
 cd "$ROOT"
 if [ -x build_var/valu_rate ]; then
     echo "== VALU issue-rate calibration (hipcc --offload-arch=gfx950 -O3 scripts/ubench/valu_rate.hip -o build_var/valu_rate)"
