@@ -304,8 +304,10 @@ def parse_args(argv=None):
                     "is measured in the same run and reported as a sibling key")  # fmt: skip
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps, to reach sustained clocks (0 disables)")
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective); "
+                    "0 = 8, or 32 for shards of <= 65 536 rows, whose step is shorter than an eighth of the ~60 us of host time one "
+                    "collective call costs")  # fmt: skip
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
                     "fill the chip with two launches in flight)")  # fmt: skip
@@ -400,10 +402,56 @@ class RcclGather:
         work.wait()  # stream-side: the current (auxiliary) stream waits for the communicator's stream
 
 
+class CAbiGather:
+    """RCCL through the library's own C ABI (cppf_comm_init_rank / cppf_allgather_bytes): one ncclAllGather enqueued on the
+    auxiliary stream itself -- no second stream, no c10d bookkeeping (3 us of host time and 6 us on the stream against 28 / 33 us
+    for torch.distributed's call on one rank, scripts/gather_latency.py).  The communicator's unique id travels to the other
+    ranks through the torch.distributed group that is up anyway."""
+
+    def __init__(self, dist, rank, world, device_index):
+        import ctypes
+
+        from cppflow_amd import _hip
+
+        self._hip, self._ct = _hip, ctypes
+        lib = _hip.lib()
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            _hip.check(lib.cppf_comm_unique_id(uid))
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        self.comm = ctypes.c_void_p()
+        _hip.check(lib.cppf_comm_init_rank(uid, rank, world, device_index, ctypes.byref(self.comm)))
+        assert lib.cppf_comm_world(self.comm) == world
+
+    def all_gather(self, out, inp):
+        nbytes = inp.numel() * inp.element_size()
+        assert out.numel() * out.element_size() == nbytes * self._hip.lib().cppf_comm_world(self.comm)
+        self._hip.check(self._hip.lib().cppf_allgather_bytes(self.comm, inp.data_ptr(), out.data_ptr(), nbytes,
+                                                              torch.cuda.current_stream(inp.device).cuda_stream))
+
+    def close(self):
+        self._hip.lib().cppf_comm_destroy(self.comm)
+
+
+class NoGather:
+    """diagnostic (CPPF_BENCH_TRANSPORT=none): everything of the exchange step except the collective itself"""
+
+    def all_gather(self, out, inp):
+        out.view((out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:]))[: inp.shape[0]].copy_(inp)
+
+
 class Runner:
     """One workload (a batch of S seeds x W waypoints on this rank) and the machinery that steps it: a ring of output-buffer
-    sets, `n_streams` launch streams, and -- with a transport -- the bucketed all-gather of the per-seed summaries on an
-    auxiliary stream followed by the seed selection over every rank's seeds."""
+    sets and `n_streams` launch streams.
+
+    Without a transport (N = 1) consecutive steps alternate between the streams.  With one, the ring is `n_streams` BUCKETS of G
+    steps; a bucket's launches all go to ONE stream and its exchange step -- the all-gather of the G [S,8] summaries and the seed
+    selection over every rank's seeds -- is enqueued on that same stream right behind them, so producer -> collective -> consumer
+    -> reuse of the bucket's buffers are ordered by the stream itself.  No cross-stream event anywhere: measured on a 32 768-row
+    shard, making an auxiliary stream wait on events of four launch streams cost 22.5 us per step against 7.2 us without the
+    waits (the kernels stopped overlapping), while buckets on their own streams keep the full overlap, `n_streams` buckets deep."""
 
     def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0):
         from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
@@ -411,15 +459,16 @@ class Runner:
         self.robot, self.x0, self.target, self.K, self.collide, self.device = robot, x0, target, K, collide, device
         n, W = x0.shape[0], target.shape[0]
         self.n, self.S, self.W, self.world = n, n // W, W, world
-        self.G = G = max(1, G)
-        self.NBUF = NBUF = max(4, 2 * G)  # two buckets of G slots: one being filled while the other is on the wire
+        self.transport = transport if collide else None
+        self.n_streams = max(1, n_streams)
+        self.G = G = max(1, G) if self.transport is not None else 1
+        self.NBUF = NBUF = self.n_streams * G if self.transport is not None else max(4, self.n_streams)
         prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
         self.prm = prm
         self.x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
         self.packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
                         for _ in range(NBUF)]  # fmt: skip
         self.summ_all = torch.empty((NBUF, self.S, 8), dtype=torch.float32, device=device) if collide else None
-        self.transport = transport if collide else None
         self.shape, self.solver = shape, solver
         if collide:
             self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=self.summ_all[b],
@@ -429,18 +478,14 @@ class Runner:
         else:
             self.plans, self.outputs = None, None
         if self.transport is not None:
-            self.gathered = [torch.empty((world, G, self.S, 8), dtype=torch.float32, device=device) for _ in range(NBUF // G)]
-            self.selected = [torch.empty((G, 4), dtype=torch.int32, device=device) for _ in range(NBUF // G)]
+            self.gathered = [torch.empty((world, G, self.S, 8), dtype=torch.float32, device=device) for _ in range(self.n_streams)]
+            self.selected = [torch.empty((G, 4), dtype=torch.int32, device=device) for _ in range(self.n_streams)]
             self.constraints = DEFAULT_CONSTRAINTS
-            self.aux = torch.cuda.Stream(device=device)
         else:
-            self.gathered = self.selected = self.aux = None
-        self.n_streams = max(1, min(n_streams, NBUF))
+            self.gathered = self.selected = None
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(device))
-        self.launched = [torch.cuda.Event() for _ in self.streams]  # "this stream's launches of the bucket are enqueued"
-        self.bucket_done = [None] * (NBUF // G)  # recorded on aux when the bucket's collective + selection have completed
         self.step_no = 0
 
     def launch(self):
@@ -456,36 +501,26 @@ class Runner:
             return self.launch()
         b = self.step_no % self.NBUF
         self.step_no += 1
-        st = self.streams[b % self.n_streams]
         if self.transport is None:
-            self.plans[b].launch_on(st)
+            self.plans[b].launch_on(self.streams[b % self.n_streams])
             return
         bucket = b // self.G
-        if self.bucket_done[bucket] is not None:
-            st.wait_event(self.bucket_done[bucket])  # this bucket's slots were on the wire 2 G steps ago
-        self.plans[b].launch_on(st)
+        self.plans[b].launch_on(self.streams[bucket])
         if b % self.G == self.G - 1:  # the bucket is complete: gather its G summaries from every rank and consume them
-            self.gather_bucket(bucket)
+            self.exchange(bucket)
 
-    def gather_bucket(self, bucket):
+    def exchange(self, bucket):
         G = self.G
-        for k, s_k in enumerate(self.streams):
-            self.launched[k].record(s_k)
-            self.aux.wait_event(self.launched[k])
-        with torch.cuda.stream(self.aux):
+        with torch.cuda.stream(self.streams[bucket]):
             self.transport.all_gather(self.gathered[bucket], self.summ_all[bucket * G : (bucket + 1) * G])
             # the consumer (cppflow/optimization_utils.py:856-909 over ALL ranks' seeds, one row of `selected` per step)
             self.robot.select_valid_seed(self.gathered[bucket], self.constraints, out=self.selected[bucket])
-            done = self.bucket_done[bucket] if self.bucket_done[bucket] is not None else torch.cuda.Event()
-            done.record(self.aux)
-            self.bucket_done[bucket] = done
 
     def drain(self):
-        if self.aux is not None:
-            if self.step_no % self.G != 0:  # a partly filled bucket: its summaries are exchanged too before the clock stops
-                self.gather_bucket((self.step_no % self.NBUF) // self.G)
-                self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
-            self.aux.synchronize()
+        if self.transport is not None and self.step_no % self.G != 0:
+            # a partly filled bucket: its summaries are exchanged too before the clock stops
+            self.exchange((self.step_no % self.NBUF) // self.G)
+            self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
 
     def timed(self, steps, warmup, prewarm_ms, barrier):
         """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then exactly `steps`
@@ -587,6 +622,13 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus N` (it starts its own "
                  f"ranks) or launch N ranks with torch.distributed.run and pass the same --gpus N")  # fmt: skip
 
+    # Independent launches on different HIP streams only overlap when the streams map to different hardware queues; the
+    # runtime's default of 4 queues per process pairs them up (measured, scripts/hwq_sweep.sh: a 32 768-row shard steps in
+    # 13.1 us on 4 streams with the default and in 7.1 us with 16 queues; the full-size launch is unaffected).  Must be set before
+    # the HIP runtime initialises, i.e. before torch is imported.
+    if os.environ.get("CPPF_BENCH_KEEP_HWQ", "0") != "1":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
     global torch
     import torch
 
@@ -622,7 +664,9 @@ def main():
             transport = HostStagedGather(dist)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
-            transport = RcclGather(dist)
+            which = os.environ.get("CPPF_BENCH_TRANSPORT", "cabi")
+            transport = {"c10d": lambda: RcclGather(dist), "cabi": lambda: CAbiGather(dist, rank, world, dev_index),
+                         "none": lambda: NoGather()}[which]()  # fmt: skip
         assert dist.get_world_size() == world
 
     from cppflow_amd import _hip
@@ -673,9 +717,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    G = max(1, args.gather_every)
-    # a strong-scaling shard is a fraction of a wavefront per SIMD: two launches in flight cannot fill the chip, four can
-    n_streams = args.streams if args.streams > 0 else (4 if (scaling == "strong" and world > 1) else 2)
+    rows_main = S_main * W
+    G = args.gather_every if args.gather_every > 0 else (32 if rows_main <= 65536 else 8)
+    # a shard of <= 2 wavefronts per SIMD: two launches in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
+    n_streams = args.streams if args.streams > 0 else (4 if rows_main <= 131072 else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
     run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver)
@@ -823,6 +868,7 @@ def main():
                 + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
                 "inputs": inputs_desc,
                 "streams": run.n_streams,
+                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 "kernel_shape": args.shape,
                 "solver": args.solver + (" (the reference's dtype)" if args.solver == "f32" else " (J J^T, factorisation, substitutions, J^T y in double precision)"),
                 "early_out": "off (every row runs all K iterations: the metric counts K iterations per row)",
@@ -837,7 +883,9 @@ def main():
                 "collision_fused": collide,
                 "obstacles": len(obstacles),
                 "world_size": dist.get_world_size() if dist is not None else 1,
-                "collective_backend": (None if dist is None else ("gloo, host-staged (one-GPU rehearsal: NOT a multi-GPU result)" if share_gpu else "nccl (RCCL)")),
+                "collective_backend": (None if dist is None else ("gloo, host-staged (one-GPU rehearsal: NOT a multi-GPU result)" if share_gpu else
+                                                                  {"RcclGather": "nccl (RCCL) through torch.distributed", "CAbiGather": "RCCL through the C ABI "
+                                                                   "(cppf_allgather_bytes on the auxiliary stream)", "NoGather": "none (diagnostic)", "NoneType": "none (diagnostic)"}[type(transport).__name__])),
                 "per_step": "one fused launch incl. the per-seed summary reduction"
                 + (f" + async all-gather of the [S,8] summaries, {G} steps per collective, + x_is_valid seed selection over all "
                    f"{run.S * world} seeds of every step on each rank" if run.gathered is not None else ""),

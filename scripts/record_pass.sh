@@ -27,10 +27,17 @@ for c in C2 C3 C5; do
     timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings --config $c > "$OUT/bench_$c.json" 2>> "$OUT/bench.err"
 done
 echo "== strong-scaling shards on one GPU (what each of 2 / 4 / 8 GPUs runs under --scaling strong), 2 / 4 / 8 launches in flight"
+rm -f "$OUT/shard_streams.txt"
 for s in 512 256 128; do for st in 2 4 8; do
     timeout -k 10 200 python bench.py --seeds $s --steps 1000 --warmup 100 --streams $st --no-cpu-baseline --no-siblings 2>> "$OUT/bench.err" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('seeds/GPU', d['config']['seeds_per_gpu'], ' streams', d['config']['streams'], ' us/step %.2f' % (d['ms_per_step']*1e3), ' isolated kernel %.2f us' % (d['roofline']['kernel_ms']*1e3), ' host %.1f us/step' % d['config']['host_enqueue_us_per_step'])" >> "$OUT/shard_streams.txt"
 done; done
 cat "$OUT/shard_streams.txt"
+echo "== hardware queues x streams"
+timeout -k 10 600 bash scripts/hwq_sweep.sh > "$OUT/hwq_sweep.txt" 2>&1
+echo "== a 32 768-row shard with the collective + seed selection on the dependency path (one-rank RCCL group), 8 / 32 steps per collective"
+for g in 8 32; do
+    CPPF_BENCH_FORCE_DIST=1 timeout -k 10 200 python bench.py --seeds 128 --steps 2048 --warmup 256 --gather-every $g --no-cpu-baseline --no-siblings 2>> "$OUT/bench.err" | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('seeds/GPU 128 + RCCL(1 rank) + select, steps per collective', d['config']['steps_per_allgather'], ' streams', d['config']['streams'], ' us/step %.2f' % (d['ms_per_step']*1e3), ' host %.1f us/step' % d['config']['host_enqueue_us_per_step'])" >> "$OUT/shard_streams.txt"
+done
 echo "== shard_bench (isolated latency by kernel shape)"
 timeout -k 10 300 python scripts/shard_bench.py --shapes row,quad --sizes 8,32,64,128,256,512,1024 > "$OUT/shard_bench.txt" 2>&1
 timeout -k 10 300 python scripts/shard_bench.py --shapes quad --mfma 1 --sizes 8,32,64 > "$OUT/shard_bench_mfma.txt" 2>&1
