@@ -110,6 +110,7 @@ class LmOutputs(ctypes.Structure):
 SIGNATURES = {
     "cppf_abi_version": (ctypes.c_int, []),
     "cppf_last_error": (ctypes.c_char_p, []),
+    "cppf_build_id": (ctypes.c_char_p, []),
     "cppf_robot_create": (ctypes.c_int, [ctypes.POINTER(RobotDesc), ctypes.c_int, ctypes.POINTER(_vp)]),
     "cppf_robot_destroy": (None, [_vp]),
     "cppf_robot_ndof": (ctypes.c_int, [_vp]),
@@ -189,6 +190,17 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        # provenance: the binary must be the one the sources next to it produce (it is git-ignored and travels to the GPU
+        # box as a built artefact; the hash is compiled in by cppflow_amd/build.py)
+        if "CPPFLOW_HIP_LIB" not in os.environ:
+            from cppflow_amd import build as _build
+
+            want, have = _build.source_hash(), handle.cppf_build_id().decode()
+            if want != have:
+                raise RuntimeError(
+                    f"{LIB_PATH} was built from other sources (build id {have}, sources on disk hash to {want}): "
+                    "rebuild it (python -m cppflow_amd.build)"
+                )
         _lib = handle
     return _lib
 

@@ -256,6 +256,13 @@ extern "C" {
 
 int cppf_abi_version(void) { return CPPF_ABI_VERSION; }
 
+#ifndef CPPF_BUILD_ID
+#define CPPF_BUILD_ID "unversioned"
+#endif
+// (the marker lets cppflow_amd/build.py read the id out of the file without loading the library)
+static const char kBuildIdMarker[] = "CPPF_BUILD_ID=" CPPF_BUILD_ID;
+const char* cppf_build_id(void) { return kBuildIdMarker + 14; }
+
 const char* cppf_last_error(void) { return g_err.c_str(); }
 
 int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out) {

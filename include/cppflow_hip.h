@@ -124,6 +124,9 @@ typedef struct cppf_lm_outputs {
 typedef struct cppf_robot cppf_robot; /* opaque: host copy of the description + launch state for one device */
 
 int cppf_abi_version(void);
+/* sha256 prefix of the sources this binary was compiled from (cppflow_amd/build.py:source_hash); the Python binding refuses a
+ * library whose id differs from the sources next to it. */
+const char* cppf_build_id(void);
 const char* cppf_last_error(void);
 
 /* Replaces jrl.robots.get_robot(name) (cppflow/data_type_utils.py:197): validates and binds a description to `device`. */

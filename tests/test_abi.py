@@ -150,3 +150,12 @@ def test_run_time_specialisation_compiles_without_a_gpu(lib, tmp_path):
     desc2 = _hip.chain_to_desc(canonicalize(H.random_chain_spec(7, seed=22)))
     lib.cppf_debug_rtc_compile(ctypes.byref(desc2), str(tmp_path).encode())
     assert len(list(tmp_path.glob("robot_*.cppfrtc"))) == 2
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib):
+    """Build provenance: the binary is git-ignored and travels to the GPU box as a built artefact; its build id is the
+    sha256 of the sources next to it, read both through the ABI and out of the file, and `_hip.lib()` refuses a mismatch."""
+    from cppflow_amd import build
+
+    assert lib.cppf_build_id().decode() == build.source_hash() == build.built_id()
+    assert not build.needs_build()
