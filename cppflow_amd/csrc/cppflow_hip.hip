@@ -183,10 +183,14 @@ int find_static_robot(const cppf_robot_desc& d) {
 int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
+bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
+                               // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
 bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 256, the measured range in which it wins), else one launch per waypoint
 bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
-int g_pcr_max_rows = 131072;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows (measured crossover)
+constexpr int kPcrMaxRowsDefault = 90112;  // 352 trajectories x 256 waypoints
+int g_pcr_max_rows = kPcrMaxRowsDefault;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows
+                                          // (measured crossover with the two-ended row-per-lane kernels at d <= 7; x 0.64 at d = 8)
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -447,11 +451,13 @@ int cppf_robot_specialization(const cppf_robot* robot) {
 
 void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 
-void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n; }
+void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n < 0 ? kPcrMaxRowsDefault : n; }
 
 void cppf_debug_set_quad_max_rows(int n) { g_quad_max_rows = n; }
 
 void cppf_debug_set_dp_persistent(int on) { g_dp_persistent = on != 0; }
+
+void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
 
 void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
@@ -897,17 +903,24 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.use_env = params->use_env_collisions;
     prm.S = S;
     prm.W = W;
+    // which elimination kernel: see the comments at the launches below
+    const size_t pcr_limit = g_pcr_max_rows > 0 ? (size_t)g_pcr_max_rows * (robot->desc.ndof <= 7 ? 100 : 64) / 100 : 0;
+    const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
+    const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 8 &&
+                          W <= (1 << 20);
+    prm.fold = use_rows;
     hipStream_t st = (hipStream_t)stream;
-    CPPF_DISPATCH_D(robot->desc.ndof,
-                    hipLaunchKernelGGL((full_blocks_kernel<D>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st,
-                                       robot->chain, robot->coll, prm, x_in, target, work_blocks));
+#define CPPF_BODY                                                                                                     \
+    hipLaunchKernelGGL((full_blocks_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, robot->chain, \
+                       robot->coll, prm, x_in, target, virtual_configs, work_blocks)
+    CPPF_DISPATCH_RB(robot)
+#undef CPPF_BODY
     // Trajectories are eliminated one per wavefront (8 x 8 lane tile) up to 8 joints, one per lane beyond.  With the pose
     // block the d x d blocks are J^T J + a small diagonal (rank 6 of 7, cond ~1e7): the per-lane kernel's Cholesky with
     // floored pivots copes with that better than the explicit Gauss-Jordan inverse, so it keeps that case.
     // Up to ~128k rows (the planner's cadence is one trajectory): parallel cyclic reduction, one workgroup per trajectory, one
     // lane per waypoint; beyond that its O(T log T) work and traffic lose against the waypoint-after-waypoint kernels
-    if (!prm.use_pose && W <= 512 && n <= (size_t)(g_pcr_max_rows > 0 ? g_pcr_max_rows : 0) && robot->desc.ndof >= 3 &&
-        robot->desc.ndof <= 8) {
+    if (use_pcr) {
         switch (robot->desc.ndof) {
 #define CPPF_PCR_CASE(DD)                                                                                              \
     case DD:                                                                                                           \
@@ -924,11 +937,29 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
         }
         return check_launch(robot);
     }
+    // row-per-lane kernels: 8 trajectories per one-wavefront workgroup and two workgroups (the two ends of the path) per 8
+    // trajectories; the LDS reservation caps the workgroups per compute unit at ceil(#workgroups / 256) (160 KB per compute
+    // unit), which spreads a small launch over distinct compute units
+    const unsigned rows_wgs = 2u * (unsigned)((S + 7) / 8);
+    const unsigned rows_per_cu = (rows_wgs + 255) / 256;
+    const size_t rows_lds = rows_per_cu == 1 ? 96 * 1024 : rows_per_cu == 2 ? 64 * 1024 : rows_per_cu == 3 ? 48 * 1024 : 0;
     switch (prm.use_pose ? 0 : robot->desc.ndof) {
-#define CPPF_WAVE_CASE(DD)                                                                                          \
-    case DD:                                                                                                        \
-        hipLaunchKernelGGL((full_solve_wave_kernel<DD>), dim3((unsigned)S), dim3(64), 0, st, robot->chain, prm, x_in, \
-                           virtual_configs, work_blocks, work_G, work_y, x_out);                                    \
+#define CPPF_WAVE_CASE(DD)                                                                                              \
+    case DD:                                                                                                            \
+        if (use_rows) {                                                                                                 \
+            if (rows_lds > 64 * 1024) { /* per device: set whenever it is needed, a host-side table update */           \
+                CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_rows_eliminate_kernel<DD>),            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                   \
+                CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_rows_substitute_kernel<DD>),           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                   \
+            }                                                                                                           \
+            hipLaunchKernelGGL((full_rows_eliminate_kernel<DD>), dim3(rows_wgs), dim3(64), rows_lds, st, prm,           \
+                               robot->chain.pris_mask, work_blocks, work_G, work_y);                                    \
+            hipLaunchKernelGGL((full_rows_substitute_kernel<DD>), dim3(rows_wgs), dim3(64), rows_lds, st, prm,          \
+                               robot->chain.pris_mask, x_in, work_blocks, work_G, work_y, x_out);                       \
+        } else                                                                                                          \
+            hipLaunchKernelGGL((full_solve_wave_kernel<DD>), dim3((unsigned)S), dim3(64), 0, st, robot->chain, prm,      \
+                               x_in, virtual_configs, work_blocks, work_G, work_y, x_out);                              \
         break;
         CPPF_WAVE_CASE(3) CPPF_WAVE_CASE(4) CPPF_WAVE_CASE(5) CPPF_WAVE_CASE(6) CPPF_WAVE_CASE(7) CPPF_WAVE_CASE(8)
 #undef CPPF_WAVE_CASE

@@ -18,6 +18,8 @@ struct FullK {
     float lm_lambda, a_pos, a_rot, a_diff, a_diff_pris, a_vq, a_self, a_env;
     int32_t use_pose, use_diff, use_vq, n_vq, use_self, use_env;
     int32_t S, W;
+    int32_t fold;  // full_blocks_kernel also adds the differencing / virtual-config / lambda terms of its own waypoint (what
+                   // full_rows_eliminate_kernel expects ready-made; the other elimination kernels add them in their own loops)
 };
 
 // gradient of a point rigidly attached to moving link `link`, projected on n:  n . d(c)/dq_j  for every joint j
@@ -138,21 +140,106 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
+// A_tt's diagonal and b_t's differencing / virtual-config terms (optimization_utils.py:574-640) of one row, in the same
+// operation order as the elimination kernels' own loops (prm.fold), then the row's packed block goes out
+template <class RB>
+__device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm, size_t row, const float (&q)[RB::D],
+                                                 const float* __restrict__ x, const float* __restrict__ xv,
+                                                 float (&M)[RB::D * (RB::D + 1) / 2], float (&m)[RB::D],
+                                                 float* __restrict__ blocks) {
+    constexpr int D = RB::D, NT = D * (D + 1) / 2;
+    if (prm.fold) {
+        const int t = (int)(row % (size_t)prm.W), T = prm.W;
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float a = prm.use_diff ? prm.a_diff * (rb.pris(j) ? prm.a_diff_pris : 1.f) : 0.f;
+            const float a2 = a * a;
+            M[k] += ((has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f)) * a2 + (vq ? beta2 : 0.f) + prm.lm_lambda;
+            k += D - j;
+            if (has_next) m[j] = CPPF_FMA(a2, wrap_pi(x[(row + 1) * D + j] - q[j]), m[j]);
+            if (has_prev) m[j] = CPPF_FMA(-a2, wrap_pi(q[j] - x[(row - 1) * D + j]), m[j]);
+            if (vq && xv) m[j] = CPPF_FMA(-beta2, wrap_pi(q[j] - xv[row * D + j]), m[j]);
+        }
+    }
+    float* o = blocks + row * (NT + D);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) o[k] = M[k];
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[NT + j] = m[j];
+}
+
+// RB = StaRobot<...>: a screening pass first -- capsule FK in registers, the wave-uniform broad phase, then the cheap squared
+// distance against the (slightly widened) tabulated thresholds -- leaves two wavefront-uniform bit sets of the pairs /
+// (cuboid, capsule) tests in which SOME lane may penetrate.  A wavefront with none (the common case on a planner's paths)
+// writes its blocks straight away; the others run the general pass below over the flagged tests only (joint axes, closest
+// points, gradients: ~3x the registers).  The general pass decides penetration exactly as before, so the screening changes no
+// result -- it only has to be a superset, which the 1e-3 widening of the thresholds makes it.
+template <class RB>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RB::D <= 8 ? 4 : 1, RB::D <= 8 ? 4 : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ target,
-                                                             float* __restrict__ blocks) {
+                                                             const float* __restrict__ xv, float* __restrict__ blocks) {
     extern __shared__ float lds[];
-    using RB = DynRobot<D>;
+    constexpr int D = RB::D;
     constexpr int NT = D * (D + 1) / 2;
     const RB rb{ch, co};
     const int tid = threadIdx.x;
     const size_t row = (size_t)blockIdx.x * kBlock + tid;
     const size_t n = (size_t)prm.S * prm.W;
     if (row >= n) return;
-    float q[D], R[9], p[3], ax[D][3], og[D][3], M[NT], m[D];
+    float q[D];
     load_x<D>(x, row, q);
+    unsigned long long near_self = ~0ull, near_env = ~0ull;  // wavefront-uniform
+    if constexpr (RB::kStatic) {
+        using T = typename RB::Table;
+        constexpr int L = T::L > 0 ? T::L : 1;
+        static_assert(T::P <= 64, "pair set is a 64-bit mask");
+        near_self = 0ull;
+        const bool env_bits = prm.use_env && co.nobs * T::L <= 64;
+        if (env_bits || !prm.use_env) near_env = 0ull;
+        if (prm.use_self || env_bits) {
+            float R[9], p[3], w0[L][3], w1[L][3];
+            capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+            if (prm.use_self) {
+#pragma unroll
+                for (int pi = 0; pi < T::P; ++pi) {
+                    const int a = T::pair_a[pi], b = T::pair_b[pi];
+                    float ma[3], mb[3];
+                    capsule_mid(w0[a], w1[a], ma);
+                    capsule_mid(w0[b], w1[b], mb);
+                    if (cull_far(mid_dist2(ma, mb), 4.f * T::pair_cull[pi])) continue;
+                    const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
+                    if (__builtin_amdgcn_ballot_w64(d2 < 1.001f * T::pair_thr[pi] + 1e-12f)) near_self |= 1ull << pi;
+                }
+            }
+            if (env_bits) {
+                for (int o = 0; o < co.nobs; ++o) {
+#pragma unroll
+                    for (int c = 0; c < T::L; ++c) {
+                        float mm[3];
+                        capsule_mid(w0[c], w1[c], mm);
+                        if (cull_far(point_box_dist2(mm, co.obs_lo2[o], co.obs_hi2[o]), 4.f * T::cap_cull[c])) continue;
+                        const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
+                        if (__builtin_amdgcn_ballot_w64(d2 < 1.001f * T::cap_thr[c] + 1e-12f)) near_env |= 1ull << (o * T::L + c);
+                    }
+                }
+            }
+        }
+        if (!prm.use_pose && near_self == 0ull && near_env == 0ull) {
+            float M[NT], m[D];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) M[k] = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) m[j] = 0.f;
+            full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks);
+            return;
+        }
+    }
+    float R[9], p[3], ax[D][3], og[D][3], M[NT], m[D];
 #pragma unroll
     for (int k = 0; k < NT; ++k) M[k] = 0.f;
 #pragma unroll
@@ -210,6 +297,7 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
     if (prm.use_self) {  // :645-680: rows where -alpha * dist > 0
         const float w = prm.a_self * prm.a_self;
         for (int pi = 0; pi < co.npairs; ++pi) {
+            if (!((near_self >> (pi & 63)) & 1ull)) continue;  // screened out above (specialised robots; else all ones)
             const int a = co.pair_a[pi], b = co.pair_b[pi];
             float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
             lds_capsule(lds, tid, a, a0, a1);
@@ -240,6 +328,7 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
         const float w = prm.a_env * prm.a_env;
         for (int o = 0; o < co.nobs; ++o)
             for (int c = 0; c < co.ncaps; ++c) {
+                if (!((near_env >> ((o * co.ncaps + c) & 63)) & 1ull)) continue;
                 float w0[3], w1[3], cs[3], cb[3];
                 lds_capsule(lds, tid, c, w0, w1);
                 {
@@ -262,11 +351,7 @@ __global__ __launch_bounds__(kBlock) void full_blocks_kernel(const ChainK ch, co
                 }
             }
     }
-    float* o = blocks + row * (NT + D);
-#pragma unroll
-    for (int k = 0; k < NT; ++k) o[k] = M[k];
-#pragma unroll
-    for (int j = 0; j < D; ++j) o[NT + j] = m[j];
+    full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks);
 }
 
 // inverse of a symmetric positive definite D x D matrix (full storage in, full storage out) by Cholesky; pivots floored
@@ -548,6 +633,283 @@ __global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, co
         pr += __shfl_xor(pr, 4, 64);
         if (in && j == 0) x_out[(base + t) * D + i] = xt + pr;  // optimization.py:113: x + delta_x
         dl = __shfl(pr, j * 8 + i, 64);
+    }
+}
+
+// Row-per-lane form for D <= 8: EIGHT trajectories per wavefront, lane 8 g + r holds ROW r of trajectory g's 8 x 8 padded block in
+// registers.  The wavefront-per-trajectory kernel above spends its step in dependent ds_bpermute round trips (two per pivot,
+// ~0.1 us each: 0.7 us per waypoint whatever else happens); here every cross-lane read is a broadcast inside a group of eight
+// consecutive lanes from a compile-time lane, which is two DPP instructions (quad_perm picks lane k & 3 of each quad, a
+// bank-masked row_shr:4 / row_shl:4 copies the right quad over the other) and never touches the LDS pipe.  Gauss-Jordan without
+// pivoting (SPD; pivots floored like everywhere else): per pivot the pivot row is broadcast (16 DPP), and one FMA per entry with
+// the factor f = A_rk / p (f = 1 - 1/p in the pivot's own lane, which turns its row into row / p) updates the whole row.
+// ~300 instructions per waypoint forward, ~45 back, one wavefront for eight trajectories: 1024 trajectories are 128 wavefronts.
+template <int K>
+__device__ __forceinline__ float g8_bcast(float x) {  // value of lane (8 g + K) in every lane of group g
+    float t = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), (K & 3) * 0x55, 0xf, 0xf, true));
+    const int ti = __builtin_bit_cast(int, t);
+    if constexpr (K < 4)  // the source sits in the even quad of its group: odd quads (banks 1, 3) read lane - 4
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x114, 0xf, 0xa, false));
+    else                  // ... in the odd quad: even quads (banks 0, 2) read lane + 4
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x104, 0xf, 0x5, false));
+}
+
+template <int D, int C = 0>
+__device__ __forceinline__ void g8_bcast_all(float x, float (&out)[8]) {
+    if constexpr (C < D) {
+        out[C] = g8_bcast<C>(x);
+        g8_bcast_all<D, C + 1>(x, out);
+    }
+}
+
+template <int D, int K, int C = 0>
+__device__ __forceinline__ void g8_bcast_row(const float (&A)[8], float (&out)[8]) {  // out[c] = A[c] of lane K of the group
+    if constexpr (C < D) {
+        out[C] = g8_bcast<K>(A[C]);
+        g8_bcast_row<D, K, C + 1>(A, out);
+    }
+}
+
+template <int D, int K = 0>
+__device__ __forceinline__ void g8_gauss_jordan(float (&A)[8], int r, float floor_) {
+    if constexpr (K < D) {
+        float pr[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pr[c] = 0.f;
+        // pivot row K, every column
+        g8_bcast_row<D, K>(A, pr);
+        const float pv = __builtin_amdgcn_fmed3f(pr[K], floor_, INFINITY);  // max(pivot, floor) in one instruction
+        const float pinv = __builtin_amdgcn_rcpf(pv);  // 1 ulp; the factorisation's own rounding is of that order per entry
+        const bool own = r == K;
+        const float f = own ? 1.f - pinv : A[K] * pinv;
+#pragma unroll
+        for (int c = 0; c < D; ++c) A[c] = CPPF_FMA(-f, pr[c], A[c]);
+        A[K] = own ? pinv : -f;
+        g8_gauss_jordan<D, K + 1>(A, r, floor_);
+    }
+}
+
+// The elimination runs from BOTH ends of the path at once (a twisted factorisation): with m = T / 2, one wavefront eliminates
+// waypoints 0 .. m-1 upwards ( D'_t = A_t - E G_{t-1} E ), another T-1 .. m+1 downwards ( D''_t = A_t - E G_{t+1} E ); the two
+// chains are the same recurrence in mirrored time and touch disjoint waypoints, so they need no communication.  A second
+// launch joins them at waypoint m,
+//     ( A_m - E G'_{m-1} E - E G''_{m+1} E ) delta_m = b_m - E G'_{m-1} y_{m-1} - E G''_{m+1} z_{m+1}
+// (both wavefronts of a pair compute it, redundantly, instead of exchanging it), and substitutes back outwards in both
+// directions:  delta_t = G_t ( y_t + a^2 .* delta_{t +- 1} ).  Per-step work is unchanged and the chain each wavefront walks is
+// half as long -- the launch is bound by that chain, not by throughput (1024 trajectories are 256 wavefronts on 1024 SIMDs).
+// One wavefront per workgroup; the launch reserves enough (unused) LDS per workgroup that at most ceil(#workgroups / 256) of
+// them fit a compute unit, which spreads a small launch over distinct compute units.
+template <int D>
+struct RowsLane {
+    int r, rr;
+    bool live;  // padded rows / idle groups work on a copy of a valid row and store nothing
+    unsigned offM[D], offb, offG, offy;
+    float a2r, pc[D];
+    size_t ubase;
+};
+
+template <int D>
+__device__ __forceinline__ RowsLane<D> rows_lane(const FullK& prm, uint32_t pris_mask, int wave, int lane) {
+    constexpr int NT = D * (D + 1) / 2, STRIDE = NT + D;
+    RowsLane<D> L;
+    L.r = lane & 7;
+    const int s_raw = wave * 8 + (lane >> 3);
+    L.live = s_raw < prm.S && L.r < D;
+    const int s = s_raw < prm.S ? s_raw : prm.S - 1;
+    L.rr = L.r < D ? L.r : 0;
+    const int T = prm.W;
+    // Addresses = a wavefront-uniform 64-bit part (this wavefront's first trajectory, moved by one waypoint per step) + a
+    // 32-bit lane part fixed for the whole kernel (the host bounds 8 W d^2 floats to 2^31 bytes)
+    L.ubase = (size_t)wave * 8 * (size_t)T;
+    const unsigned lrow = (unsigned)(s - wave * 8) * (unsigned)T;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {  // (min(r,c), max(r,c)) in the packed upper triangle
+        const int ii = L.rr < c ? L.rr : c, jj = L.rr < c ? c : L.rr;
+        L.offM[c] = lrow * STRIDE + (unsigned)(ii * D - (ii * (ii - 1)) / 2 + (jj - ii));
+    }
+    L.offb = lrow * STRIDE + NT + L.rr, L.offG = lrow * (D * D) + L.rr * D, L.offy = lrow * D + L.rr;
+    float a2c[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float a = prm.use_diff ? prm.a_diff * (((pris_mask >> c) & 1u) ? prm.a_diff_pris : 1.f) : 0.f;
+        a2c[c] = a * a;
+    }
+    L.a2r = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) L.a2r = L.r == c ? a2c[c] : L.a2r;
+#pragma unroll
+    for (int c = 0; c < D; ++c) L.pc[c] = L.a2r * a2c[c];  // E G E scales entry (r, c) of G by a_r^2 a_c^2
+    return L;
+}
+
+// A -= E G E (this lane's row) and the return value  (G v)_r  for the vector v held one component per lane
+template <int D>
+__device__ __forceinline__ float rows_couple(const RowsLane<D>& L, const float (&G)[D], float v, float (&A)[8]) {
+    float vb[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vb[c] = 0.f;
+    g8_bcast_all<D>(v, vb);
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        acc = CPPF_FMA(G[c], vb[c], acc);
+        A[c] = CPPF_FMA(-L.pc[c], G[c], A[c]);
+    }
+    return acc;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void full_rows_eliminate_kernel(const FullK prm, const uint32_t pris_mask,
+                                                                 const float* __restrict__ blocks, float* __restrict__ workG,
+                                                                 float* __restrict__ worky) {
+    static_assert(D <= 8, "one row of the 8 x 8 padded block per lane");
+    constexpr int NT = D * (D + 1) / 2, STRIDE = NT + D;
+    const int wave = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int T = prm.W, m = T / 2;
+    const int start = dir ? T - 1 : 0, sgn = dir ? -1 : 1, len = dir ? T - 1 - m : m;  // waypoint of step tau: start + sgn tau
+    if (len <= 0) return;
+    const RowsLane<D> L = rows_lane<D>(prm, pris_mask, wave, threadIdx.x);
+    const float* blk = blocks + L.ubase * STRIDE;
+    float* gw = workG + L.ubase * (D * D);
+    float* yw = worky + L.ubase * D;
+    // Block rows are requested PF steps ahead (a step is ~0.8 us of issue; a launch whose workspaces exceed the L2 sees
+    // 2-3 us of load latency), into a ring of register sets indexed at compile time.
+    constexpr int PF = 4;
+    float G[D], y = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) G[c] = 0.f;
+    float pM[PF][D], pb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const float* nxt = blk + (size_t)(start + sgn * (u < len ? u : len - 1)) * STRIDE;
+#pragma unroll
+        for (int c = 0; c < D; ++c) pM[u][c] = nxt[L.offM[c]];
+        pb[u] = nxt[L.offb];
+    }
+    for (int t0 = 0; t0 < len; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int tau = t0 + u;
+            if (tau < len) {
+                const int t = start + sgn * tau;
+                float A[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) A[c] = c < D ? pM[u][c] : 0.f;
+                const float b = pb[u];
+                {  // step tau + PF into the slot just read (the last PF steps re-read the chain's last waypoint)
+                    const float* nxt = blk + (size_t)(start + sgn * (tau + PF < len ? tau + PF : len - 1)) * STRIDE;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) pM[u][c] = nxt[L.offM[c]];
+                    pb[u] = nxt[L.offb];
+                }
+                float ynew = b;
+                if (tau > 0) ynew = CPPF_FMA(L.a2r, rows_couple<D>(L, G, y, A), b);  // y = b - E (G y_prev),  E = -diag(a^2)
+                g8_gauss_jordan<D>(A, L.r, prm.lm_lambda);
+                y = ynew;
+#pragma unroll
+                for (int c = 0; c < D; ++c) G[c] = A[c];
+                if (L.live) {
+                    float* gt = gw + (size_t)t * (D * D);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) gt[L.offG + c] = G[c];
+                    yw[(size_t)t * D + L.offy] = y;
+                }
+            }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK prm, const uint32_t pris_mask,
+                                                                  const float* __restrict__ x, const float* __restrict__ blocks,
+                                                                  const float* __restrict__ workG,
+                                                                  const float* __restrict__ worky, float* __restrict__ x_out) {
+    constexpr int NT = D * (D + 1) / 2, STRIDE = NT + D;
+    const int wave = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int T = prm.W, m = T / 2;
+    const int start = dir ? T - 1 : 0, sgn = dir ? -1 : 1, len = dir ? T - 1 - m : m;
+    const RowsLane<D> L = rows_lane<D>(prm, pris_mask, wave, threadIdx.x);
+    const float* blk = blocks + L.ubase * STRIDE;
+    const float* gw = workG + L.ubase * (D * D);
+    const float* yw = worky + L.ubase * D;
+    const float* xin = x + L.ubase * D;
+    float* xo = x_out + L.ubase * D;
+    // ---- the chains' operands, PB steps ahead of their use (a step is ~0.15 us), requested before the join's arithmetic
+    constexpr int PB = 16;
+    float qG[PB][D], qy[PB], qx[PB];
+#pragma unroll
+    for (int u = 0; u < PB; ++u) {
+        const int tau = len - 1 - u > 0 ? len - 1 - u : 0;
+        const int tp = len > 0 ? start + sgn * tau : m;
+        const float* gt = gw + (size_t)tp * (D * D);
+#pragma unroll
+        for (int c = 0; c < D; ++c) qG[u][c] = gt[L.offG + c];
+        qy[u] = yw[(size_t)tp * D + L.offy];
+        qx[u] = xin[(size_t)tp * D + L.offy];
+    }
+    // ---- the join at waypoint m
+    float dl;
+    {
+        const float* bm = blk + (size_t)m * STRIDE;
+        float A[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) A[c] = c < D ? bm[L.offM[c]] : 0.f;
+        float rhs = bm[L.offb];
+        const float xm = xin[(size_t)m * D + L.offy];
+        if (m > 0) {
+            float Gp[D];
+            const float* gt = gw + (size_t)(m - 1) * (D * D);
+#pragma unroll
+            for (int c = 0; c < D; ++c) Gp[c] = gt[L.offG + c];
+            rhs = CPPF_FMA(L.a2r, rows_couple<D>(L, Gp, yw[(size_t)(m - 1) * D + L.offy], A), rhs);
+        }
+        if (m + 1 < T) {
+            float Gn[D];
+            const float* gt = gw + (size_t)(m + 1) * (D * D);
+#pragma unroll
+            for (int c = 0; c < D; ++c) Gn[c] = gt[L.offG + c];
+            rhs = CPPF_FMA(L.a2r, rows_couple<D>(L, Gn, yw[(size_t)(m + 1) * D + L.offy], A), rhs);
+        }
+        g8_gauss_jordan<D>(A, L.r, prm.lm_lambda);
+        float rb[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) rb[c] = 0.f;
+        g8_bcast_all<D>(rhs, rb);
+        dl = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dl = CPPF_FMA(A[c], rb[c], dl);
+        if (dir == 1 && L.live) xo[(size_t)m * D + L.offy] = xm + dl;  // optimization.py:113: x + delta_x
+    }
+    // ---- back substitution along this wavefront's chain, from the join outwards
+    for (int t0 = len - 1; t0 >= 0; t0 -= PB) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int tau = t0 - u;
+            if (tau >= 0) {
+                const int t = start + sgn * tau;
+                float Gt[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) Gt[c] = qG[u][c];
+                const float yt = qy[u], xt = qx[u];
+                {
+                    const int tp = start + sgn * (tau - PB > 0 ? tau - PB : 0);
+                    const float* gt = gw + (size_t)tp * (D * D);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) qG[u][c] = gt[L.offG + c];
+                    qy[u] = yw[(size_t)tp * D + L.offy];
+                    qx[u] = xin[(size_t)tp * D + L.offy];
+                }
+                float rb[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rb[c] = 0.f;
+                g8_bcast_all<D>(CPPF_FMA(L.a2r, dl, yt), rb);
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc = CPPF_FMA(Gt[c], rb[c], acc);
+                if (L.live) xo[(size_t)t * D + L.offy] = xt + acc;
+                dl = acc;
+            }
+        }
     }
 }
 

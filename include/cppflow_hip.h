@@ -152,8 +152,9 @@ int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
 /* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
 void cppf_debug_force_generic(int on);
 /* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
- * trajectory) when S*W <= n rows (and W <= 512, d <= 8, no pose block), waypoint after waypoint (one wavefront per
- * trajectory) otherwise; default 131072, the measured crossover (process-wide). */
+ * trajectory) when S*W <= n rows (x 0.64 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both
+ * ends of the path (eight trajectories per wavefront) otherwise; n < 0 restores the default 90112, the measured crossover
+ * (process-wide). */
 void cppf_debug_set_pcr_max_rows(int n);
 /* Tuning hooks (process-wide): CPPF_SHAPE_AUTO runs four lanes per row up to n rows (default 16384 = one wavefront of that shape
  * per SIMD, the measured crossover) unless a per-seed summary is requested;
@@ -162,6 +163,10 @@ void cppf_debug_set_pcr_max_rows(int n);
 void cppf_debug_set_quad_max_rows(int n);
 /* Test hook: 0 makes cppf_dp_search issue one launch per waypoint instead of the single resident launch (k <= 256). */
 void cppf_debug_set_dp_persistent(int on);
+/* Test hook: 0 makes cppf_lm_full_step eliminate with one wavefront per trajectory, first waypoint to last (cross-lane reads
+ * through the LDS pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the
+ * path; d <= 8, beyond the parallel-in-time range. */
+void cppf_debug_set_full_rows(int on);
 void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).

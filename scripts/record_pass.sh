@@ -44,6 +44,7 @@ timeout -k 10 300 python scripts/shard_bench.py --shapes quad --mfma 1 --sizes 8
 timeout -k 10 200 python scripts/ksweep.py > "$OUT/ksweep.txt" 2>&1
 echo "== dp_search"
 timeout -k 10 300 python scripts/dp_bench.py > "$OUT/dp_bench.txt" 2>&1
+timeout -k 10 300 python scripts/coupled_bench.py > "$OUT/coupled_bench.txt" 2>&1
 if [ -z "$QUICK" ]; then
     echo "== kbench"
     timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1

@@ -384,8 +384,12 @@ def test_coupled_lm_step_matches_dense_reference_order_oracle(robots, name, vari
     _hip.lib().cppf_debug_set_pcr_max_rows(0)
     try:
         sequential = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
+        # ... and so must the one-wavefront-per-trajectory kernel the row-per-lane one replaced (d <= 8 only)
+        _hip.lib().cppf_debug_set_full_rows(0)
+        per_wave = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
     finally:
-        _hip.lib().cppf_debug_set_pcr_max_rows(131072)
+        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
+        _hip.lib().cppf_debug_set_full_rows(1)
     want, r = H.oracle64(name).lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi, return_residual=True)
     n_fixed = (6 * T if pm.use_pose else 0) + ((T - 1) * rb.ndof if pm.use_differencing else 0) + (8 * rb.ndof if pm.use_virtual_configs else 0)
     if variant != "pose_only":
@@ -410,6 +414,7 @@ def test_coupled_lm_step_matches_dense_reference_order_oracle(robots, name, vari
     else:
         assert np.abs(got - want).max() < 2e-4 + 2e-3 * step, (np.abs(got - want).max(), step)
         assert np.abs(sequential - want).max() < 2e-4 + 2e-3 * step, (np.abs(sequential - want).max(), step)
+        assert np.abs(per_wave - want).max() < 2e-4 + 2e-3 * step, (np.abs(per_wave - want).max(), step)
     rb.set_obstacles([], [])
 
 
@@ -436,9 +441,23 @@ def test_coupled_step_parallel_in_time_equals_sequential_elimination(robots, nam
     try:
         seq = host(rb.lm_full_step(dev(x), dev(target), pm))
     finally:
-        _hip.lib().cppf_debug_set_pcr_max_rows(131072)
+        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
     step = np.abs(seq - x).max()
     assert np.isfinite(pcr).all() and np.abs(pcr - seq).max() < 1e-5 + 1e-3 * step, (np.abs(pcr - seq).max(), step)
+    # eight trajectories per wavefront (the default beyond the parallel-in-time range) vs one wavefront per trajectory, on a
+    # ragged count of trajectories: 11 = one full wavefront of eight + three groups of a second one
+    S11 = 11
+    x11 = H.f32(np.clip(base[None] + 0.01 * rng.randn(S11, T, rb.ndof), ch.lo, ch.hi).reshape(S11 * T, rb.ndof))
+    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    try:
+        rows = host(rb.lm_full_step(dev(x11), dev(target), pm))
+        _hip.lib().cppf_debug_set_full_rows(0)
+        wave = host(rb.lm_full_step(dev(x11), dev(target), pm))
+    finally:
+        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
+        _hip.lib().cppf_debug_set_full_rows(1)
+    step11 = np.abs(wave - x11).max()
+    assert np.isfinite(rows).all() and np.abs(rows - wave).max() < 1e-5 + 1e-3 * step11, (np.abs(rows - wave).max(), step11)
     if T <= 64:
         lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
         want = H.oracle64(name).lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi)
