@@ -1,16 +1,30 @@
 #!/usr/bin/env bash
 # Round-end measurement pass on the MI355X box (run from the repo root through gpurun); everything lands in gpurun_out/rec/.
 # Counter passes are separate rocprofv3 runs with --pmc only (no trace domains), as MI355X_MICROARCH.md prescribes.
-#   bash scripts/record_pass.sh [quick|pmc]    ("quick" skips the test suite and the slow side benches, "pmc" runs the profiler passes only)
+#   bash scripts/record_pass.sh [quick|pmc|side]    ("quick" skips the test suite and the slow side benches, "pmc" runs the profiler passes
+#   only, "side" runs only what "quick" skips: a full pass is "side" + "quick" when one call's time limit is too short for both)
 set -eo pipefail
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out/rec"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 QUICK="${1:-}"
-if [ -z "$QUICK" ]; then
+if [ -z "$QUICK" ] || [ "$QUICK" = "side" ]; then
     echo "== pytest -m gpu"
     timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee "$OUT/pytest_gpu.txt"
+fi
+if [ "$QUICK" = "side" ]; then  # the test suite and the slow side benches only (the other half of a pass split over two calls)
+    echo "== kbench"
+    timeout -k 10 600 python scripts/kbench.py > "$OUT/kbench.txt" 2>&1
+    timeout -k 10 300 python scripts/kbench_small.py > "$OUT/kbench_small.txt" 2>&1
+    echo "== launch model"
+    timeout -k 10 300 python scripts/launch_model.py > "$OUT/launch_model.txt" 2>&1
+    echo "== run-time specialisation"
+    timeout -k 10 300 python scripts/rtc_bench.py > "$OUT/rtc_bench.txt" 2>&1
+    echo "== lone-wavefront issue rates"
+    if [ -x build_var/lone_wave ]; then timeout -k 5 200 ./build_var/lone_wave > "$OUT/lone_wave_micro.txt" 2>&1; fi
+    echo "== done (side)"
+    exit 0
 fi
 if [ "$QUICK" != "pmc" ]; then
 echo "== bench (default: N = 1, C4, + one_stream / random_inputs siblings, + cpu baselines)"
