@@ -364,3 +364,50 @@ def Oracle_fk(ch, q):
     from oracle.oracle import Oracle
 
     return Oracle(ch, f32=False).fk(q)
+
+
+@pytest.mark.parametrize("ndof,seed", [(3, 4), (4, 5), (5, 6), (6, 0), (8, 2)])
+def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
+    """cppf_lm_full_step on chains that match no generated table (every ndof the row-per-lane kernels are instantiated for, a
+    prismatic joint with its own differencing scale, T odd and even, a ragged count of trajectories): the two-ended row-per-lane
+    elimination, the one-wavefront-per-trajectory elimination and parallel cyclic reduction agree with each other and with
+    the oracle's dense restatement of cppflow/optimization.py:95-144."""
+    from cppflow_amd import _hip
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    spec = H.random_chain_spec(ndof, seed)
+    rb = Robot(spec, specialize=False)
+    ch = canonicalize(spec)
+    o64 = Oracle(ch, f32=False)
+    obs = [H.cuboid_obstacle(0.1, 0.1, 0.5, 0.3, 0.3, 0.3)]
+    rb.set_obstacles([c for c, _ in obs], [T_ for _, T_ in obs])
+    lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
+    d = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+    d.update(alpha_differencing_prismatic_scaling=2.0, alpha_self_collision=0.02, alpha_env_collision=0.02)
+    L = _hip.lib()
+    try:
+        for S, T in ((11, 23), (3, 24), (9, 1), (2, 2)):
+            pm = OptimizationParameters(**{**d, "use_virtual_configs": 2 * d["n_virtual_configs"] < T})
+            pm.virtual_configs = torch.tensor([])
+            rng = np.random.RandomState(100 * seed + T)
+            base = np.clip(rng.uniform(ch.lo, ch.hi)[None, :] * 0.6 + np.cumsum(0.03 * rng.randn(T, ndof), axis=0), ch.lo, ch.hi)
+            x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, ndof), ch.lo, ch.hi).reshape(S * T, ndof))
+            target = H.f32(o64.fk(H.f32(base)))
+            got = {}
+            for mode, (pcr, rows) in {"pcr": (1 << 30, 1), "rows": (0, 1), "wave": (0, 0)}.items():
+                L.cppf_debug_set_pcr_max_rows(pcr)
+                L.cppf_debug_set_full_rows(rows)
+                got[mode] = host(rb.lm_full_step(dev(x), dev(target), pm))
+            want = o64.lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi)
+            step = np.abs(want - x).max()
+            for mode, g in got.items():
+                assert np.isfinite(g).all(), (mode, S, T)
+                assert np.abs(g - want).max() < 2e-4 + 2e-3 * step, (mode, S, T, np.abs(g - want).max(), step)
+            assert np.abs(got["rows"] - got["wave"]).max() < 1e-5 + 1e-3 * step, (S, T)
+    finally:
+        L.cppf_debug_set_pcr_max_rows(-1)
+        L.cppf_debug_set_full_rows(1)
+        rb.set_obstacles([], [])
