@@ -311,6 +311,9 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
                     "fill the chip with two launches in flight)")  # fmt: skip
+    ap.add_argument("--graphs", choices=["auto", "on", "off"], default="auto",
+                    help="replay each stream's run of consecutive steps as one captured hipGraph instead of one host call per step "
+                         "(auto: on for shards of <= 65536 rows, where a step is shorter than the host's launch call)")
     ap.add_argument("--shape", choices=["auto", "row", "quad"], default="auto", help="kernel shape (cppf_lm_params.shape)")
     ap.add_argument("--solver", choices=["f32", "f64"], default="f32",
                     help="precision of the damped solve (cppf_lm_params.solver): f32 = the reference's dtype (the headline); f64 = "
@@ -453,7 +456,7 @@ class Runner:
     shard, making an auxiliary stream wait on events of four launch streams cost 22.5 us per step against 7.2 us without the
     waits (the kernels stopped overlapping), while buckets on their own streams keep the full overlap, `n_streams` buckets deep."""
 
-    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0):
+    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0, graphs=False):
         from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
 
         self.robot, self.x0, self.target, self.K, self.collide, self.device = robot, x0, target, K, collide, device
@@ -461,8 +464,11 @@ class Runner:
         self.n, self.S, self.W, self.world = n, n // W, W, world
         self.transport = transport if collide else None
         self.n_streams = max(1, n_streams)
-        self.G = G = max(1, G) if self.transport is not None else 1
-        self.NBUF = NBUF = self.n_streams * G if self.transport is not None else max(4, self.n_streams)
+        self.use_graphs = bool(graphs) and collide
+        # bucket mode: a ring of `n_streams` buckets of G consecutive steps, one stream per bucket
+        self.buckets = self.transport is not None or self.use_graphs
+        self.G = G = max(1, G) if self.buckets else 1
+        self.NBUF = NBUF = self.n_streams * G if self.buckets else max(4, self.n_streams)
         prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
         self.prm = prm
         self.x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
@@ -487,6 +493,27 @@ class Runner:
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(device))
         self.step_no = 0
+        self.graphs = None
+        if self.use_graphs:
+            # One hipGraph per bucket = its G launches in stream order, captured on the bucket's own stream (every launch once
+            # eagerly first: nothing lazy may happen inside a capture).  A replay costs the host one call per G steps.
+            for b in range(NBUF):
+                self.plans[b].launch_on(self.streams[b // G])
+            torch.cuda.synchronize()
+            try:
+                graphs = []
+                for bucket in range(self.n_streams):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[bucket], capture_error_mode="thread_local"):
+                        for b in range(bucket * G, (bucket + 1) * G):
+                            self.plans[b].launch_on(self.streams[bucket])
+                    graphs.append(g)
+                torch.cuda.synchronize()
+                self.graphs = graphs
+            except RuntimeError as e:  # capture refused on this box: the eager path does the same work, one host call per step
+                print(f"bench: hipGraph capture failed ({e}); continuing with eager launches", file=sys.stderr)
+                torch.cuda.synchronize()
+                self.graphs = None
 
     def launch(self):
         """one launch on torch's current stream (ring slot 0)"""
@@ -501,13 +528,29 @@ class Runner:
             return self.launch()
         b = self.step_no % self.NBUF
         self.step_no += 1
-        if self.transport is None:
+        if not self.buckets:
             self.plans[b].launch_on(self.streams[b % self.n_streams])
             return
         bucket = b // self.G
         self.plans[b].launch_on(self.streams[bucket])
-        if b % self.G == self.G - 1:  # the bucket is complete: gather its G summaries from every rank and consume them
-            self.exchange(bucket)
+        if b % self.G == self.G - 1 and self.transport is not None:
+            self.exchange(bucket)  # the bucket is complete: gather its G summaries from every rank and consume them
+
+    def run_steps(self, n):
+        """`n` steps; whole buckets go out as one graph replay each when graphs are on"""
+        while n > 0:
+            b = self.step_no % self.NBUF
+            if self.graphs is not None and b % self.G == 0 and n >= self.G:
+                bucket = b // self.G
+                with torch.cuda.stream(self.streams[bucket]):
+                    self.graphs[bucket].replay()
+                self.step_no += self.G
+                n -= self.G
+                if self.transport is not None:
+                    self.exchange(bucket)
+            else:
+                self.step()
+                n -= 1
 
     def exchange(self, bucket):
         G = self.G
@@ -517,9 +560,9 @@ class Runner:
             self.robot.select_valid_seed(self.gathered[bucket], self.constraints, out=self.selected[bucket])
 
     def drain(self):
-        if self.transport is not None and self.step_no % self.G != 0:
-            # a partly filled bucket: its summaries are exchanged too before the clock stops
-            self.exchange((self.step_no % self.NBUF) // self.G)
+        if self.buckets and self.step_no % self.G != 0:
+            if self.transport is not None:  # a partly filled bucket: its summaries are exchanged too before the clock stops
+                self.exchange((self.step_no % self.NBUF) // self.G)
             self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
 
     def timed(self, steps, warmup, prewarm_ms, barrier):
@@ -535,13 +578,11 @@ class Runner:
                 else:
                     self.launch()
             torch.cuda.synchronize()
-        for _ in range(warmup):
-            self.step()
+        self.run_steps(warmup)
         self.drain()
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
+        self.run_steps(steps)
         self.drain()
         barrier()
         return time.perf_counter() - t0
@@ -549,10 +590,10 @@ class Runner:
     def host_enqueue_us(self):
         """diagnostic: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)"""
         torch.cuda.synchronize()
+        nh = 64 if self.graphs is None else 4 * self.G
         th = time.perf_counter()
-        for _ in range(64):
-            self.step()
-        t = (time.perf_counter() - th) / 64
+        self.run_steps(nh)
+        t = (time.perf_counter() - th) / nh
         self.drain()
         torch.cuda.synchronize()
         return 1e6 * t
@@ -723,7 +764,8 @@ def main():
     n_streams = args.streams if args.streams > 0 else (4 if rows_main <= 131072 else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
-    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver)
+    use_graphs = collide and (args.graphs == "on" or (args.graphs == "auto" and rows_main <= 65536))
+    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver, graphs=use_graphs)
     n = run.n
     elapsed = max_over_ranks(run.timed(args.steps, args.warmup, args.prewarm_ms, barrier))
     host_us = run.host_enqueue_us()
@@ -869,6 +911,7 @@ def main():
                 "inputs": inputs_desc,
                 "streams": run.n_streams,
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                "hip_graphs": (f"on: each stream's {run.G} consecutive steps replayed as one captured graph" if run.graphs is not None else "off (one host call per step)"),
                 "kernel_shape": args.shape,
                 "solver": args.solver + (" (the reference's dtype)" if args.solver == "f32" else " (J J^T, factorisation, substitutions, J^T y in double precision)"),
                 "early_out": "off (every row runs all K iterations: the metric counts K iterations per row)",
