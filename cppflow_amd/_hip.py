@@ -167,6 +167,11 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
     ),
+    "cppf_dp_table_floats": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    "cppf_dp_search_tabled": (
+        ctypes.c_int,
+        [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    ),
 }
 
 _lib: Optional[ctypes.CDLL] = None

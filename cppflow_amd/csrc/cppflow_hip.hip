@@ -986,6 +986,9 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
     return check_launch(robot);
 }
 
+// dynamic LDS of dp_backtrace_kernel: the memo table as bytes when it fits (k <= 256, T k <= 60 KB), else 0 = walk it in global memory
+static size_t dp_stage_bytes(int k, int T) { return (k <= 256 && (size_t)k * T <= 60 * 1024) ? (size_t)k * T : 0; }
+
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
                    void* stream) {
@@ -1012,7 +1015,8 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
                                                  work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
                                                  work_memoT));
         }
-        hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
+        hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
+                       dp_stage_bytes(k, T) != 0, best_idx,
                            best_path);
         return check_launch(robot);
     }
@@ -1034,7 +1038,50 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
         }
 #undef CPPF_DP_LAUNCH
     }
-    hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), 0, st, q, work_costsT, work_memoT, k, T, d, best_idx,
+    hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
+                       dp_stage_bytes(k, T) != 0, best_idx,
+                       best_path);
+    return check_launch(robot);
+}
+
+int cppf_dp_table_floats(int k, int T, size_t* n_floats) {
+    if (!n_floats || k < 1 || T < 1) return fail(CPPF_ERR_INVALID, "cppf_dp_table_floats: k, T must be >= 1, n_floats non-NULL");
+    const size_t kp = (size_t)((k + 63) / 64 * 64);
+    *n_floats = (size_t)(T > 1 ? T - 1 : 0) * (size_t)k * kp + 8 * kp;  // + 8 rows the chain may read past the last slab
+    return CPPF_OK;
+}
+
+int cppf_dp_search_tabled(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
+                          float* work_qT, float* work_costsT, int32_t* work_memoT, float* work_table, float* best_path,
+                          int32_t* best_idx, void* stream) {
+    CPPF_ENTER(robot);
+    CPPF_REQUIRE(k >= 1 && k <= 256 && T >= 1, "cppf_dp_search_tabled: 1 <= k <= 256, T >= 1 (cppf_dp_search has no limit on k)");
+    CPPF_REQUIRE(q && ext_cost && work_qT && work_costsT && work_memoT && best_path && best_idx, "NULL pointer");
+    CPPF_REQUIRE(T == 1 || work_table, "work_table is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = robot->desc.ndof, kp = (k + 63) / 64 * 64;
+    const size_t total = (size_t)k * T * d;
+    hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
+                       ext_cost, k, T, d, work_qT, work_costsT);
+    // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
+    CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
+    if (T >= 2) {
+        CPPF_REQUIRE(T - 1 <= 65535, "cppf_dp_search_tabled: T <= 65536");
+        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_table_kernel<D>), dim3((unsigned)((k * kp + 255) / 256), (unsigned)(T - 1)),
+                                             dim3(256), 0, st, work_qT, k, kp, T, robot->chain.pris_mask, prismatic_scaling,
+                                             reinterpret_cast<uint32_t*>(work_table)));
+        const uint32_t* tab = reinterpret_cast<const uint32_t*>(work_table);
+        switch (kp) {
+            case 64: hipLaunchKernelGGL(dp_chain_kernel<64>, dim3(1), dim3(512), 0, st, tab, ext_cost, k, T, work_costsT); break;
+            case 128: hipLaunchKernelGGL(dp_chain_kernel<128>, dim3(1), dim3(512), 0, st, tab, ext_cost, k, T, work_costsT); break;
+            case 192: hipLaunchKernelGGL(dp_chain_kernel<192>, dim3(1), dim3(512), 0, st, tab, ext_cost, k, T, work_costsT); break;
+            default: hipLaunchKernelGGL(dp_chain_kernel<256>, dim3(1), dim3(512), 0, st, tab, ext_cost, k, T, work_costsT); break;
+        }
+        hipLaunchKernelGGL(dp_memo_kernel, dim3((unsigned)((k + 63) / 64), (unsigned)(T - 1)), dim3(256), 0, st, tab, ext_cost,
+                           work_costsT, k, kp, T, work_memoT);
+    }
+    hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
+                       dp_stage_bytes(k, T) != 0, best_idx,
                        best_path);
     return check_launch(robot);
 }

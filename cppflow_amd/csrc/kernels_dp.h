@@ -288,6 +288,203 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
     }
 }
 
+// ---- the recurrence on ONE compute unit, from a precomputed transition table (k <= 256) -------------------------------------------
+// The resident kernels above pay one inter-workgroup hand-off per waypoint (~2-3 us with k cost words polled by every
+// workgroup) for ~0.1 us of arithmetic.  The only part of a step that depends on the previous one is
+//     c_t[b] = min_a max( m_t[a][b], c_{t-1}[a] ) + e_t[b]        (k^2 max / min pairs),
+// and m_t -- the wrapped, scaled maximum joint change from candidate a at t-1 to candidate b at t, 95 % of the arithmetic --
+// depends on nothing.  So: (1) dp_table_kernel fills m for all T-1 steps with the whole chip (the tensor the reference
+// materialises too, search.py:100-125; [t][a][b] here, b fastest, rows padded to 64 floats); (2) dp_chain_kernel runs the
+// chain in ONE workgroup of 8 wavefronts -- no hand-off, one __syncthreads per waypoint: lane <-> destination b, the sources
+// split over the wavefronts, c_{t-1} held one value per lane and broadcast with v_readlane (an SGPR operand of v_max), the
+// table rows streamed through registers one waypoint ahead (each register is reloaded for step t + 1 right after step t used it);
+// (3) dp_memo_kernel recovers the argmins off the chain: memo_t[b] = the first a whose max(m, c) + e equals c_t[b] -- the same
+// value the strict '<' scan of the per-waypoint kernel keeps, because fp32 addition is monotone ( min_a (f_a + e) = (min_a f_a)
+// + e bit for bit ) and the comparison is on the sums.  Costs, argmins and path stay bit-exact with the oracle.
+// The chain compares ORDER KEYS, not floats: key(x) = bits(x) ^ (x < 0 ? 0xFFFFFFFF : 0x80000000) is monotone in x over all
+// non-NaN floats (dp_key above), so max / min of keys are max / min of the values, exactly, on the integer pipe (one
+// instruction each, no NaN canonicalisation of loaded operands).  The table stores key(m) (m >= 0: bits | 0x80000000).
+__device__ __forceinline__ uint32_t dp_okey(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float dp_okey_value(uint32_t key) {
+    return __uint_as_float(key ^ ((key >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+constexpr uint32_t kDpKeyInf = 0xFF800000u;  // key(+inf)
+
+template <int D>
+__global__ __launch_bounds__(256) void dp_table_kernel(const float* __restrict__ qT, int k, int kp, int T, uint32_t pris_mask,
+                                                       float pscale, uint32_t* __restrict__ table) {
+    // grid: x over the k kp entries of one step, y = step - 1
+    const unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= (unsigned)(k * kp)) return;
+    const int t = (int)blockIdx.y + 1;
+    const int a = (int)(r / (unsigned)kp), b = (int)(r % (unsigned)kp);
+    const size_t idx = (size_t)(t - 1) * k * kp + r;
+    float m = INFINITY;  // row padding: a destination that does not exist
+    if (b < k) {
+        const float* qa = qT + ((size_t)(t - 1) * k + a) * D;
+        const float* qb = qT + ((size_t)t * k + b) * D;
+        m = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float dq = qb[j] - qa[j];
+            if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
+            m = fmaxf(m, fabsf(wrap_pi(dq)));
+        }
+    }
+    table[idx] = dp_okey(m);
+}
+
+// eight sources of the chain: c_{t-1}[a] comes out of lane I0 + i of cv as a scalar operand and meets the lane's four
+// destinations; then the eight table rows of the next step go into the registers just used (16 bytes per lane: one
+// instruction fetches a whole row)
+struct DpU4 {
+    uint32_t x, y, z, w;
+};
+template <int I0, int N, int KP>
+__device__ __forceinline__ void dp_chain_chunk(uint4 (&m)[N], uint32_t cv, DpU4& best, const uint32_t* next, int lane, bool reload) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, I0 + i);
+        best.x = min(best.x, max(m[I0 + i].x, c));
+        best.y = min(best.y, max(m[I0 + i].y, c));
+        best.z = min(best.z, max(m[I0 + i].z, c));
+        best.w = min(best.w, max(m[I0 + i].w, c));
+    }
+    if (reload) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)  // rows past the group's range (up to 7) are read too -- the next group's, or the 8 rows of
+                                     // padding behind the table: their cost lane is the largest key, they never win
+            m[I0 + i] = *reinterpret_cast<const uint4*>(next + (size_t)(I0 + i) * KP + 4 * (unsigned)lane);
+    }
+}
+
+template <int I0, int N, int KP>
+__device__ __forceinline__ void dp_chain_chunks(uint4 (&m)[N], uint32_t cv, int na, DpU4& best, const uint32_t* next, int lane,
+                                                bool reload) {
+    if constexpr (I0 < N) {
+        if (I0 < na) {  // wavefront-uniform
+            dp_chain_chunk<I0, N, KP>(m, cv, best, next, lane, reload);
+            dp_chain_chunks<I0 + 8, N, KP>(m, cv, na, best, next, lane, reload);
+        }
+    }
+}
+
+// 8 wavefronts = 8 groups of <= NA sources; lane <-> destinations 4 lane .. 4 lane + 3 (lanes beyond the row idle).  SETS register
+// sets hold the table rows of SETS consecutive steps: step t computes on set t % SETS and refills it, chunk by chunk, with the
+// rows of step t + SETS -- a load has SETS steps to arrive (one step is shorter than the memory latency: with one set the
+// chain ran at one latency per waypoint).  k <= 192: two sets of 24 rows; k <= 256: one set of 32 (the register file's limit).
+template <int KP, int NA, int SETS>  // KP = row stride of the table = k rounded up to 64: compile-time, so that the row offsets are literals
+__device__ __forceinline__ void dp_chain_body(const uint32_t* __restrict__ table, const float* __restrict__ ext, int k, int T,
+                                              float* __restrict__ costsT, uint32_t (&part)[2][8][256]) {
+    const int tid = threadIdx.x, lane = tid & 63, grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per = (k + 7) / 8;
+    const int a0 = min(grp * per, k - 1);
+    const int na = max(0, min(per, k - grp * per));  // a short last group / empty groups when k < 8
+    const bool active = 4 * lane < KP;
+    uint4 m[SETS][NA];
+#pragma unroll
+    for (int u = 0; u < SETS; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) m[u][i] = make_uint4(kDpKeyInf, kDpKeyInf, kDpKeyInf, kDpKeyInf);
+        if (na > 0 && active) {  // the table rows of steps 1 .. SETS (set u serves steps u, u + SETS, ...; step t -> set t % SETS)
+            const int t = u == 0 ? SETS : u;  // the first step that uses set u
+            const uint32_t* row = table + ((size_t)min(t - 1, max(T - 2, 0)) * k + a0) * KP;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (i < ((na + 7) & ~7)) m[u][i] = *reinterpret_cast<const uint4*>(row + (size_t)i * KP + 4 * (unsigned)lane);
+        }
+    }
+    // the external cost of THIS wavefront's sources at the previous waypoint, one waypoint ahead (ext is [k][T])
+    const int s0 = min(a0 + lane, k - 1);
+    float e0 = 0.f;
+    for (int t0 = 1; t0 < T; t0 += SETS) {
+#pragma unroll
+        for (int u = 0; u < SETS; ++u) {
+            const int t = t0 + u;
+            if (t < T) {
+                constexpr int kSet0 = 1 % SETS;  // set of step t0 (t0 = 1 mod SETS)
+                const int set = (kSet0 + u) % SETS;
+                // ---- c_{t-1} for this wavefront's sources, one per lane
+                float c0;
+                if (t == 1) {
+                    c0 = costsT[s0];  // costs[:, 0] as dp_transpose_kernel left them
+                } else {
+                    const uint32_t (*p)[256] = part[(t - 1) & 1];
+                    uint32_t k0 = p[0][s0];
+#pragma unroll
+                    for (int g = 1; g < 8; ++g) k0 = min(k0, p[g][s0]);
+                    c0 = dp_okey_value(k0) + e0;  // search.py:157-158: min_a max(...) + ext (see the header)
+                    if (lane < na) costsT[(size_t)(t - 1) * k + a0 + lane] = c0;  // the cost row of step t - 1 (memo kernel, back-trace)
+                }
+                const uint32_t cv = lane < na ? dp_okey(c0) : 0xFFFFFFFFu;  // sources beyond this group's range never win
+                e0 = ext[(size_t)s0 * T + t];                               // needed at step t + 1
+                // ---- k^2 / 8 max / min pairs per wavefront; step t + SETS's table rows go into the registers just used
+                const uint32_t* next = table + ((size_t)min(t + SETS - 1, T - 2) * k + a0) * KP;
+                DpU4 best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (active) {
+                    dp_chain_chunks<0, NA, KP>(m[set], cv, na, best, next, lane, t + SETS < T);
+                    *reinterpret_cast<uint4*>(&part[t & 1][grp][4 * lane]) = make_uint4(best.x, best.y, best.z, best.w);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // the last cost row
+    if (T >= 2 && lane < na) {
+        const uint32_t (*p)[256] = part[(T - 1) & 1];
+        uint32_t k0 = p[0][s0];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) k0 = min(k0, p[g][s0]);
+        costsT[(size_t)(T - 1) * k + a0 + lane] = dp_okey_value(k0) + e0;
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(512) void dp_chain_kernel(const uint32_t* __restrict__ table, const float* __restrict__ ext, int k,
+                                                       int T, float* __restrict__ costsT) {
+    __shared__ uint32_t part[2][8][256];  // [parity of t][source group][destination]: partial minima (keys) over the group's sources
+    if constexpr (KP <= 64)
+        dp_chain_body<KP, 8, 3>(table, ext, k, T, costsT, part);
+    else if constexpr (KP <= 128)
+        dp_chain_body<KP, 16, 3>(table, ext, k, T, costsT, part);
+    else if constexpr (KP <= 192)
+        dp_chain_body<KP, 24, 2>(table, ext, k, T, costsT, part);
+    else
+        dp_chain_body<KP, 32, 1>(table, ext, k, T, costsT, part);
+}
+
+// memo_t[b] = first a with max(m_t[a][b], c_{t-1}[a]) + e_t[b] == c_t[b]   (0 when c_t[b] is not below +inf: nothing was ever
+// 'less than' the initial +inf of the scan, search.py:157-159 keeps index 0 then)
+__global__ __launch_bounds__(256) void dp_memo_kernel(const uint32_t* __restrict__ table, const float* __restrict__ ext,
+                                                      const float* __restrict__ costsT, int k, int kp, int T,
+                                                      int32_t* __restrict__ memoT) {
+    // grid: x over chunks of 64 destinations, y = step - 1; the four wavefronts of a workgroup scan a quarter of the sources each
+    __shared__ int first[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = (int)blockIdx.y + 1, b = (int)blockIdx.x * 64 + lane;
+    const int bb = min(b, k - 1);
+    const float target = costsT[(size_t)t * k + bb], e = ext[(size_t)bb * T + t];
+    const uint32_t* col = table + (size_t)(t - 1) * k * kp + bb;
+    const float* cp = costsT + (size_t)(t - 1) * k;
+    const int per = (k + 3) / 4, a_lo = w * per, a_hi = min(k, a_lo + per);
+    int arg = 0x7fffffff;
+    if (target < INFINITY) {
+        for (int a = a_lo; a < a_hi; ++a) {
+            const float v = dp_okey_value(max(col[(size_t)a * kp], dp_okey(cp[a]))) + e;
+            if (arg == 0x7fffffff && v == target) arg = a;
+        }
+    }
+    first[w][lane] = arg;
+    __syncthreads();
+    if (w == 0 && b < k) {
+        int r = min(min(first[0][lane], first[1][lane]), min(first[2][lane], first[3][lane]));
+        memoT[(size_t)t * k + b] = r == 0x7fffffff ? 0 : r;
+    }
+}
+
 // _get_mjacs (cppflow/search.py:100-125): mjacs[i, j, t] = max over joints of |wrap(scale_j (q[i, t+1, j] - q[j_, t, j]))| -- the
 // [k, k, T-1] tensor the reference's dp_search materialises (1 GB at k = 1024).  cppf_dp_search never builds it; this
 // kernel exists for callers that want the tensor itself.  One lane per (i, j_, t), t fastest (coalesced writes).
@@ -314,11 +511,19 @@ __global__ __launch_bounds__(256) void mjacs_kernel(const float* __restrict__ q,
 }
 
 // argmin over the final costs (first minimal index), walk the memo table back, gather the path
+// The walk is T dependent reads of the memo table.  From global memory that is T memory latencies (63 us at T = 256); with
+// `stage` the table is first copied into LDS as bytes (k <= 256, T k <= 64 KB: the launch passes T k bytes of dynamic LDS) and
+// walked there (one LDS latency per step).
 __global__ __launch_bounds__(256) void dp_backtrace_kernel(const float* __restrict__ q, const float* __restrict__ costsT,
-                                                           const int32_t* __restrict__ memoT, int k, int T, int d,
+                                                           const int32_t* __restrict__ memoT, int k, int T, int d, int stage,
                                                            int32_t* __restrict__ best_idx, float* __restrict__ best_path) {
+    extern __shared__ uint8_t memo8[];
     __shared__ float red_v[4];
     __shared__ int red_a[4];
+    if (stage) {
+        const int n = T * k;
+        for (int i = threadIdx.x; i < n; i += 256) memo8[i] = (uint8_t)memoT[i];
+    }
     const float* last = costsT + (size_t)(T - 1) * k;
     float v = INFINITY;
     int a = 0;
@@ -350,9 +555,16 @@ __global__ __launch_bounds__(256) void dp_backtrace_kernel(const float* __restri
                 a = red_a[w];
             }
         int i = a;
-        for (int t = T - 1; t >= 0; --t) {  // search.py:161-173
-            best_idx[t] = i;
-            i = memoT[(size_t)t * k + i];
+        if (stage) {
+            for (int t = T - 1; t >= 0; --t) {  // search.py:161-173
+                best_idx[t] = i;
+                i = memo8[t * k + i];
+            }
+        } else {
+            for (int t = T - 1; t >= 0; --t) {
+                best_idx[t] = i;
+                i = memoT[(size_t)t * k + i];
+            }
         }
     }
     __syncthreads();

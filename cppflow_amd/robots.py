@@ -557,8 +557,13 @@ class Robot:
         )
         return x_out
 
-    def dp_search(self, q: torch.Tensor, ext_cost: torch.Tensor, prismatic_joint_scaling: float = 5.0):
-        """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191."""
+    def dp_search(self, q: torch.Tensor, ext_cost: torch.Tensor, prismatic_joint_scaling: float = 5.0, method: str = "auto",
+                  return_memo: bool = False):
+        """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191.
+        `method`: "table" (k <= 256: transition table + the recurrence on one compute unit, cppf_dp_search_tabled), "resident"
+        (cppf_dp_search: resident workgroups handing the cost row on, or one launch per waypoint beyond k = 256), "auto" = table
+        up to k = 192 (where it is the faster one).  Bit-identical results."""
+        assert method in ("auto", "table", "resident"), method
         q = _require_device_tensor(q, "q")
         ext_cost = _require_device_tensor(ext_cost, "q_costs_external")
         assert q.dim() == 3 and q.shape[2] == self.ndof, tuple(q.shape)
@@ -570,12 +575,29 @@ class Robot:
         memoT = torch.empty((T, k), dtype=torch.int32, device=dev)
         best_path = torch.empty((T, d), dtype=torch.float32, device=dev)
         best_idx = torch.empty(T, dtype=torch.int32, device=dev)
-        _hip.check(
-            _hip.lib().cppf_dp_search(
-                self._handle(dev), q.data_ptr(), ext_cost.data_ptr(), k, T, float(prismatic_joint_scaling), qT.data_ptr(),
-                costsT.data_ptr(), memoT.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(), _stream_ptr(dev),
-            )  # fmt: skip
-        )
+        n_table = ctypes.c_size_t(0)
+        _hip.check(_hip.lib().cppf_dp_table_floats(k, T, ctypes.byref(n_table)))
+        # measured (scripts/dp_bench.py): the table form wins up to k = 192 (two register sets of table rows in flight); at
+        # k = 256 one compute unit's ~100 GB/s of table streaming is slower than the hand-offs of the resident form
+        tabled = method == "table" or (method == "auto" and k <= 192 and 2 <= T <= 65536 and n_table.value * 4 <= (1 << 30))
+        if tabled:
+            table = torch.empty(max(n_table.value, 1), dtype=torch.float32, device=dev)
+            _hip.check(
+                _hip.lib().cppf_dp_search_tabled(
+                    self._handle(dev), q.data_ptr(), ext_cost.data_ptr(), k, T, float(prismatic_joint_scaling), qT.data_ptr(),
+                    costsT.data_ptr(), memoT.data_ptr(), table.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(),
+                    _stream_ptr(dev),
+                )  # fmt: skip
+            )
+        else:
+            _hip.check(
+                _hip.lib().cppf_dp_search(
+                    self._handle(dev), q.data_ptr(), ext_cost.data_ptr(), k, T, float(prismatic_joint_scaling), qT.data_ptr(),
+                    costsT.data_ptr(), memoT.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(), _stream_ptr(dev),
+                )  # fmt: skip
+            )
+        if return_memo:
+            return best_path, best_idx, costsT, memoT
         return best_path, best_idx, costsT
 
     def plan_metrics(self, x: torch.Tensor, target: torch.Tensor, self_mask: Optional[torch.Tensor] = None,

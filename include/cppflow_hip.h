@@ -314,6 +314,18 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
                    void* stream);
 
+/* The same dynamic programme for k <= 256 from a precomputed transition table (the mjacs tensor of search.py:100-125, which
+ * the reference materialises as well): the table is filled by the whole chip, the recurrence then runs on ONE compute unit
+ * (no hand-off between workgroups: one workgroup barrier per waypoint, the table streamed through registers two steps ahead)
+ * and the argmins are recovered in a third, parallel launch.  Same outputs, bit for bit, as cppf_dp_search.  Measured at
+ * T = 256: 642 vs 717 us at the reference's k = 175, 458 vs 735 us at k = 128, 325 vs 419 us at k = 64; slower at k = 256
+ * (one compute unit streams ~100 GB/s).  Extra workspace: work_table, cppf_dp_table_floats(k, T) = ((T-1) * k + 8) *
+ * roundup(k, 64) floats (34 MB at k = 175, T = 256).  T <= 65536. */
+int cppf_dp_table_floats(int k, int T, size_t* n_floats);
+int cppf_dp_search_tabled(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
+                          float* work_qT, float* work_costsT, int32_t* work_memoT, float* work_table, float* best_path,
+                          int32_t* best_idx, void* stream);
+
 /* ---- seed sharding across the GPUs of one node: RCCL behind the C ABI ---------------------------------------
  * The reference is one process on one device (no collective anywhere in its tree); the MI355X build shards the candidate seeds
  * of cppflow/planners.py:231-251 over the GPUs and needs ONE collective: an all-gather of each rank's packed per-row / per-seed

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dp_search latency (developer tool): the resident single-launch form against one launch per waypoint, HIP events, medians."""
+"""dp_search latency (developer tool): the table form (cppf_dp_search_tabled), the resident single-launch form and one launch per
+waypoint (cppf_dp_search), HIP events, medians."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,4 +28,19 @@ for name in ("panda", "fetch", "chain12"):
                 a.record(); call(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
             out.append(np.median(ts))
         _hip.lib().cppf_debug_set_dp_persistent(1)
-        print(f"{name:8s} dp_search k={k:5d} T={T:4d}   single launch {out[0]:8.1f} us   per-waypoint launches {out[1]:8.1f} us")
+        tabled = float("nan")
+        if k <= 256:
+            import ctypes
+            nt = ctypes.c_size_t(0)
+            _hip.check(_hip.lib().cppf_dp_table_floats(k, T, ctypes.byref(nt)))
+            tab = torch.empty(nt.value, device=dev)
+            def call_t():
+                _hip.check(_hip.lib().cppf_dp_search_tabled(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), tab.data_ptr(), bp.data_ptr(), bi.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            for _ in range(5): call_t()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(15):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); call_t(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
+            tabled = np.median(ts)
+        print(f"{name:8s} dp_search k={k:5d} T={T:4d}   table + one compute unit {tabled:8.1f} us   resident single launch {out[0]:8.1f} us   per-waypoint launches {out[1]:8.1f} us", flush=True)

@@ -277,10 +277,12 @@ def test_quad_shape_refuses_what_it_cannot_produce(robots):
                                       shape=_hip.SHAPE_QUAD, **LM)  # fmt: skip
 
 
-@pytest.mark.parametrize("name,k,T", [("panda", 175, 256), ("fetch", 256, 64), ("panda", 96, 40), ("fetch", 97, 33), ("chain12", 5, 9), ("panda", 1, 4)])
+@pytest.mark.parametrize("name,k,T", [("panda", 175, 256), ("fetch", 256, 64), ("panda", 96, 40), ("fetch", 97, 33), ("chain12", 5, 9), ("panda", 1, 4),
+                                      ("panda", 64, 7), ("fetch", 65, 2), ("panda", 129, 19), ("panda", 200, 1)])
 def test_dp_search_single_launch_equals_per_waypoint_launches_and_oracle(robots, name, k, T):
-    """cppf_dp_search's resident single-launch form (cost words that are their own flags) against the one-launch-per-waypoint
-    form and the fp32 oracle restatement of cppflow/search.py:128-191: cost table, argmins and path bit for bit."""
+    """cppf_dp_search's resident single-launch form (cost words that are their own flags) and cppf_dp_search_tabled (transition
+    table + the recurrence on one compute unit + parallel argmin recovery) against the one-launch-per-waypoint form and the fp32
+    oracle restatement of cppflow/search.py:128-191: cost table, argmins (the whole memo table) and path bit for bit."""
     from cppflow_amd import _hip
 
     rb = robots[name]
@@ -294,12 +296,20 @@ def test_dp_search_single_launch_equals_per_waypoint_launches_and_oracle(robots,
         for mode in (1, 0):
             _hip.lib().cppf_debug_set_dp_persistent(mode)
             for rep in range(3):  # repeated calls reuse nothing: every call re-arms its own cost table
-                path, idx, costsT = rb.dp_search(dev(q), dev(ext))
-            got[mode] = (host(path), idx.cpu().numpy(), host(costsT))
+                path, idx, costsT, memoT = rb.dp_search(dev(q), dev(ext), method="resident", return_memo=True)
+            got[mode] = (host(path), idx.cpu().numpy(), host(costsT), memoT.cpu().numpy())
     finally:
         _hip.lib().cppf_debug_set_dp_persistent(1)
+    for rep in range(2):
+        path, idx, costsT, memoT = rb.dp_search(dev(q), dev(ext), method="table", return_memo=True)
+    got["table"] = (host(path), idx.cpu().numpy(), host(costsT), memoT.cpu().numpy())
     for a, b in zip(got[1], got[0]):
         assert np.array_equal(a, b)
+    for i, (a, b) in enumerate(zip(got["table"], got[0])):
+        assert np.array_equal(a, b), ("table vs per-waypoint launches", i)
+    # what a caller gets without asking: the table form in its range
+    auto = rb.dp_search(dev(q), dev(ext))
+    assert np.array_equal(host(auto[2]), got[0][2]) and np.array_equal(auto[1].cpu().numpy(), got[0][1])
     want_idx, want_costs = H.oracle32(name).dp_search(q, ext)
     assert np.array_equal(got[1][2].T, want_costs) and np.array_equal(got[1][1], want_idx)
     assert np.array_equal(got[1][0], q[want_idx, np.arange(T)])
