@@ -213,8 +213,10 @@ __device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, con
 // COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
 // out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
 // F64: the damped solve in double precision (lm_dual_solve_f64).
+// The masks-only fp32 launch of the arms up to 8 joints is held to 128 VGPRs (4 wavefronts per SIMD resident = all of a
+// 262 144-row launch at once instead of 3 + a second round; costs 8 spilled registers outside the LM loop).
 template <class RB, int COLL, bool F64 = false>
-__global__ __launch_bounds__(kBlock, CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+__global__ __launch_bounds__(kBlock, (COLL == 1 && !F64 && RB::D <= 8) ? 4 : CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
     extern __shared__ float lds[];
