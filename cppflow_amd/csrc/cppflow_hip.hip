@@ -183,6 +183,7 @@ int find_static_robot(const cppf_robot_desc& d) {
 int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
+int g_occ4_min_rows = 131072;  // fused masks-only fp32 launch: the 128-VGPR instantiation from this many rows up (see kernels_fused.h)
 bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
                                // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
 bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 256, the measured range in which it wins), else one launch per waypoint
@@ -666,6 +667,9 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     if (f64)                                                                                                               \
         hipLaunchKernelGGL((lm_fused_kernel<RB, 1, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain,          \
                            robot->coll, prm, x_in, target, *out);                                                          \
+    else if (n >= (size_t)g_occ4_min_rows) /* >= 2 wavefronts per SIMD: the 128-VGPR build (arms up to 8 joints) */          \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, false, (RB::D <= 8)>), dim3(grid_for(n)), dim3(kBlock), lds, st,         \
+                           robot->chain, robot->coll, prm, x_in, target, *out);                                            \
     else                                                                                                                   \
         hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll,   \
                            prm, x_in, target, *out)
