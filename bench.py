@@ -464,7 +464,7 @@ class Runner:
         self.n, self.S, self.W, self.world = n, n // W, W, world
         self.transport = transport if collide else None
         self.n_streams = max(1, n_streams)
-        self.use_graphs = bool(graphs) and collide
+        self.use_graphs = bool(graphs)
         # bucket mode: a ring of `n_streams` buckets of G consecutive steps, one stream per bucket
         self.buckets = self.transport is not None or self.use_graphs
         self.G = G = max(1, G) if self.buckets else 1
@@ -480,9 +480,11 @@ class Runner:
             self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=self.summ_all[b],
                                                shape=shape, solver=solver, **prm)
                           for b, (xo, pk) in enumerate(zip(self.x_outs, self.packeds))]  # fmt: skip
-            self.outputs = self.plans[0].outputs
-        else:
-            self.plans, self.outputs = None, None
+        else:  # FK + Jacobian + LM only (BASELINE configs[1]): the result and its pose errors, no collision stage
+            self.errs = [(torch.empty(n, device=device), torch.empty(n, device=device)) for _ in range(NBUF)]
+            self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, errors_out=er, shape=shape, solver=solver, **prm)
+                          for xo, er in zip(self.x_outs, self.errs)]
+        self.outputs = self.plans[0].outputs
         if self.transport is not None:
             self.gathered = [torch.empty((world, G, self.S, 8), dtype=torch.float32, device=device) for _ in range(self.n_streams)]
             self.selected = [torch.empty((G, 4), dtype=torch.int32, device=device) for _ in range(self.n_streams)]
@@ -517,15 +519,9 @@ class Runner:
 
     def launch(self):
         """one launch on torch's current stream (ring slot 0)"""
-        if self.collide:
-            self.plans[0].launch()
-        else:
-            self.robot.lm_pose_steps(self.x0, self.target, n_steps=self.K, clamp=True, x_out=self.x_outs[0], want_errors=True,
-                                     shape=self.shape, solver=self.solver, **self.prm)  # fmt: skip
+        self.plans[0].launch()
 
     def step(self):
-        if not self.collide:
-            return self.launch()
         b = self.step_no % self.NBUF
         self.step_no += 1
         if not self.buckets:
@@ -573,10 +569,7 @@ class Runner:
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
             for i in range(48):
-                if self.collide:
-                    self.plans[i % self.NBUF].launch_on(self.streams[i % self.n_streams])
-                else:
-                    self.launch()
+                self.plans[i % self.NBUF].launch_on(self.streams[i % self.n_streams])
             torch.cuda.synchronize()
         self.run_steps(warmup)
         self.drain()
@@ -764,7 +757,7 @@ def main():
     n_streams = args.streams if args.streams > 0 else (4 if rows_main <= 131072 else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
-    use_graphs = collide and (args.graphs == "on" or (args.graphs == "auto" and rows_main <= 65536))
+    use_graphs = args.graphs == "on" or (args.graphs == "auto" and rows_main <= 65536)
     run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver, graphs=use_graphs)
     n = run.n
     elapsed = max_over_ranks(run.timed(args.steps, args.warmup, args.prewarm_ms, barrier))
@@ -773,9 +766,6 @@ def main():
 
     # sanity on the result of the last step (not timed): most rows converged
     outputs = run.outputs
-    if outputs is None:
-        outputs = robot.lm_pose_steps(x0, target, n_steps=K, clamp=True, x_out=run.x_outs[0], want_errors=True, shape=shape,
-                                      solver=solver, **run.prm)
     conv_frac = float((outputs["pos_err_m"] < 1e-4).float().mean().item())
     selected = None
     if run.selected is not None:

@@ -409,11 +409,14 @@ class Robot:
     def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
                        alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
                        clamp: bool = True, summary_out: Optional[torch.Tensor] = None,
-                       shape: int = _hip.SHAPE_AUTO, solver: int = _hip.SOLVER_F32) -> "LmLaunchPlan":  # fmt: skip
+                       shape: int = _hip.SHAPE_AUTO, solver: int = _hip.SOLVER_F32,
+                       errors_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> "LmLaunchPlan":  # fmt: skip
         """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
-        holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation."""
+        holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation.
+        `packed_out` (15 bytes per row: cost, pose errors, masks) makes it a launch with the collision stage; without it
+        `errors_out` = (pos_err_m [n], rot_err_rad [n]) asks for the pose errors of the result alone."""
         return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                            summary_out, shape, solver)
+                            summary_out, shape, solver, errors_out)
 
     def select_valid_seed(self, seed_summary: torch.Tensor, constraints, self_collisions_ignored: bool = False,
                           env_collisions_ignored: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -668,7 +671,7 @@ def _check_summary_buffer(t: torch.Tensor, S: int, dev) -> None:
 
 class LmLaunchPlan:
     def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                 summary_out=None, shape=_hip.SHAPE_AUTO, solver=_hip.SOLVER_F32):  # fmt: skip
+                 summary_out=None, shape=_hip.SHAPE_AUTO, solver=_hip.SOLVER_F32, errors_out=None):  # fmt: skip
         x = robot._x2d(x)
         x_out = _require_output_tensor(x_out, "x_out")
         target = _require_device_tensor(target, "target_path")
@@ -689,6 +692,13 @@ class LmLaunchPlan:
             for k, v in views.items():
                 setattr(out, k, v.data_ptr())
             self.outputs.update(views)
+        if errors_out is not None:
+            assert packed_out is None, "packed_out already holds the pose errors"
+            pe, re = (_require_output_tensor(t, nm) for t, nm in zip(errors_out, ("pos_err_m", "rot_err_rad")))
+            assert pe.numel() == n and re.numel() == n
+            out.pos_err_m, out.rot_err_rad = pe.data_ptr(), re.data_ptr()
+            self.outputs.update(pos_err_m=pe, rot_err_rad=re)
+            self._keep = self._keep + (pe, re)
         if summary_out is not None:
             _check_summary_buffer(summary_out, n // W, x.device)
             out.seed_summary = summary_out.data_ptr()
@@ -721,7 +731,7 @@ class LmLaunchPlan:
 
     def summary_launcher(self, out: torch.Tensor):
         """A zero-allocation callable that reduces this plan's per-row outputs into `out` [S,8] (`Robot.seed_summary`)."""
-        robot, x, target, x_out, packed = self._keep
+        robot, x, target, x_out, packed = self._keep[:5]
         assert packed is not None, "the plan has no packed per-row outputs"
         n, W = x.shape[0], target.shape[0]
         assert out.shape == (n // W, 8) and out.dtype == torch.float32 and out.is_cuda and out.is_contiguous()
