@@ -438,6 +438,32 @@ class CAbiGather:
         self._hip.lib().cppf_comm_destroy(self.comm)
 
 
+def pick_cabi_or_c10d(dist, rank, world, dev_index, device):
+    """The C-ABI communicator, checked against torch.distributed's own all-gather on a small probe; every rank falls back to
+    the c10d call together if creating it failed or its result differs anywhere (a second RCCL communicator next to c10d's
+    has only been rehearsed on one-GPU boxes)."""
+    ok, cabi, why = 1, None, ""
+    try:
+        cabi = CAbiGather(dist, rank, world, dev_index)
+        probe = torch.full((1, 4, 8), float(rank + 1), dtype=torch.float32, device=device)
+        got = torch.zeros((world, 1, 4, 8), dtype=torch.float32, device=device)
+        cabi.all_gather(got, probe)
+        want = torch.zeros_like(got)
+        dist.all_gather_into_tensor(want.view(world, 4, 8), probe)
+        torch.cuda.synchronize()
+        if not torch.equal(got, want):
+            ok, why = 0, "probe mismatch"
+    except Exception as e:  # noqa: BLE001 -- any failure means: use the other transport
+        ok, why = 0, repr(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return cabi
+    print(f"bench: rank {rank}: C-ABI RCCL transport unavailable ({why or 'failed on another rank'}); using torch.distributed's all-gather",
+          file=sys.stderr)
+    return RcclGather(dist)
+
+
 class NoGather:
     """diagnostic (CPPF_BENCH_TRANSPORT=none): everything of the exchange step except the collective itself"""
 
@@ -699,8 +725,10 @@ def main():
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
             which = os.environ.get("CPPF_BENCH_TRANSPORT", "cabi")
-            transport = {"c10d": lambda: RcclGather(dist), "cabi": lambda: CAbiGather(dist, rank, world, dev_index),
-                         "none": lambda: NoGather()}[which]()  # fmt: skip
+            if which == "cabi":
+                transport = pick_cabi_or_c10d(dist, rank, world, dev_index, device)
+            else:
+                transport = {"c10d": lambda: RcclGather(dist), "none": lambda: NoGather()}[which]()
         assert dist.get_world_size() == world
 
     from cppflow_amd import _hip
