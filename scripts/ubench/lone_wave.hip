@@ -1,6 +1,6 @@
 // lone_wave.hip -- developer microbenchmark (not part of the library): how fast does a wavefront issue dependent VALU work as
 // a function of how many other wavefronts run, and where they sit (same SIMD / same compute unit / elsewhere)?
-//   build: hipcc --offload-arch=gfx950 -O3 -o build_var/lone_wave scripts/micro/lone_wave.hip     run: build_var/lone_wave
+//   build: hipcc --offload-arch=gfx950 -O3 -o build_var/lone_wave scripts/ubench/lone_wave.hip     run: build_var/lone_wave
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
