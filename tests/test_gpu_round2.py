@@ -421,3 +421,41 @@ def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
         L.cppf_debug_set_pcr_max_rows(-1)
         L.cppf_debug_set_full_rows(1)
         rb.set_obstacles([], [])
+
+
+def test_launch_plan_without_collision_stage_matches_the_eager_call_and_replays_in_a_graph(panda):
+    """LmLaunchPlan with errors_out (FK + Jacobian + LM only, BASELINE configs[1]): same x and pose errors as lm_pose_steps,
+    bit for bit, launched eagerly, on an explicit stream, and replayed from a captured hipGraph (what bench.py does for shards)."""
+    rb = panda
+    S, W, K = 16, 64, 5
+    rng = np.random.RandomState(3)
+    ch = H.chain("panda")
+    q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(W, rb.ndof)))
+    target = dev(H.f32(H.oracle64("panda").fk(q_star)))
+    x0 = dev(H.f32(np.clip(q_star[None] + 0.1 * rng.randn(S, W, rb.ndof), ch.lo, ch.hi).reshape(S * W, rb.ndof)))
+    want = rb.lm_pose_steps(x0, target, n_steps=K, want_errors=True, **LM)
+    n = S * W
+    xo = torch.empty_like(x0)
+    pe, re = torch.empty(n, device=x0.device), torch.empty(n, device=x0.device)
+    plan = rb.lm_launch_plan(x0, target, n_steps=K, x_out=xo, errors_out=(pe, re), **LM)
+    plan.launch()
+    torch.cuda.synchronize()
+    for got, key in ((xo, "x"), (pe, "pos_err_m"), (re, "rot_err_rad")):
+        assert torch.equal(got.reshape(-1), want[key].reshape(-1)), key
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    xo.zero_(), pe.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+        plan.launch_on(st)
+        plan.launch_on(st)
+    torch.cuda.synchronize()
+    xo.zero_(), pe.zero_()
+    with torch.cuda.stream(st):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xo.reshape(-1), want["x"].reshape(-1)) and torch.equal(pe, want["pos_err_m"].reshape(-1))
+    with pytest.raises(AssertionError):
+        rb.lm_launch_plan(x0, target, n_steps=K, x_out=xo, errors_out=(pe, re),
+                          packed_out=torch.empty(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=x0.device), **LM)
