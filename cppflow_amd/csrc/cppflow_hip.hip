@@ -460,6 +460,8 @@ void cppf_debug_set_dp_persistent(int on) { g_dp_persistent = on != 0; }
 
 void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
 
+void cppf_debug_set_occ_min_rows(int n) { g_occ4_min_rows = n < 0 ? 131072 : n; }
+
 void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
 int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
@@ -667,8 +669,8 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     if (f64)                                                                                                               \
         hipLaunchKernelGGL((lm_fused_kernel<RB, 1, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain,          \
                            robot->coll, prm, x_in, target, *out);                                                          \
-    else if (n >= (size_t)g_occ4_min_rows) /* >= 2 wavefronts per SIMD: the 128-VGPR build (arms up to 8 joints) */          \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, false, (RB::D <= 8)>), dim3(grid_for(n)), dim3(kBlock), lds, st,         \
+    else if (n >= (size_t)g_occ4_min_rows) /* >= 2 wavefronts per SIMD: the 128-VGPR build (168 beyond 8 joints) */          \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, false, (RB::D <= 8 ? 4 : 3)>), dim3(grid_for(n)), dim3(kBlock), lds, st, \
                            robot->chain, robot->coll, prm, x_in, target, *out);                                            \
     else                                                                                                                   \
         hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll,   \

@@ -213,12 +213,14 @@ __device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, con
 // COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
 // out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
 // F64: the damped solve in double precision (lm_dual_solve_f64).
-// OCC4: the instantiation is held to 128 VGPRs (4 wavefronts per SIMD resident: all of a 262 144-row launch at once instead of
-// 3 + a second round) at the price of ~8 registers spilled to scratch outside the LM loop.  Worth it from 2 wavefronts per SIMD
-// up (C4 41.5 -> 40.6 us per step, C3 25.0 -> 20.9); a launch that uses scratch dispatches more slowly, which costs the small
-// shards in flight on four queues more than the occupancy gives (32 768 rows: 7.0 -> 8.2 us per step), so the host picks by size.
-template <class RB, int COLL, bool F64 = false, bool OCC4 = false>
-__global__ __launch_bounds__(kBlock, OCC4 ? 4 : CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+// OCC = 4: the instantiation is held to 128 VGPRs (4 wavefronts per SIMD resident: all of a 262 144-row launch at once instead
+// of 3 + a second round) at the price of ~8 registers spilled to scratch outside the LM loop.  Same-process A/B
+// (scripts/occ_ab.py, two launches in flight): C4 41.8 -> 41.5 us per step, Fetch 512 x 256 32.6 -> 32.3 -- about 1 %; a launch
+// that uses scratch dispatches more slowly, which costs the small shards in flight on four queues more than the occupancy gives
+// (32 768 rows: 7.0 -> 8.2 us per step), so the host picks by size.
+// OCC = 3 (168 VGPRs) is the same trade for the 12-joint chain's table build (212 VGPRs, 39 spills): C5 621 -> 581 us per step.
+template <class RB, int COLL, bool F64 = false, int OCC = 0>
+__global__ __launch_bounds__(kBlock, OCC ? OCC : CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
     extern __shared__ float lds[];

@@ -167,6 +167,10 @@ void cppf_debug_set_dp_persistent(int on);
  * through the LDS pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the
  * path; d <= 8, beyond the parallel-in-time range. */
 void cppf_debug_set_full_rows(int on);
+/* Tuning hook: cppf_lm_pose_steps launches with masks (no minimum distances, fp32 solve) use the instantiation held to 128
+ * VGPRs (168 beyond 8 joints; a few registers spilled outside the LM loop, one more wavefront per SIMD resident) from n rows
+ * up; n < 0 restores the default 131072, a huge n switches it off (process-wide). */
+void cppf_debug_set_occ_min_rows(int n);
 void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
