@@ -55,6 +55,7 @@ done
 echo "== shard_bench (isolated latency by kernel shape)"
 timeout -k 10 300 python scripts/shard_bench.py --shapes row,quad --sizes 8,32,64,128,256,512,1024 > "$OUT/shard_bench.txt" 2>&1
 timeout -k 10 300 python scripts/shard_bench.py --shapes quad --mfma 1 --sizes 8,32,64 > "$OUT/shard_bench_mfma.txt" 2>&1
+{ for m in 0 1; do echo "== chain12 quad, mfma=$m"; timeout -k 10 200 python scripts/shard_bench.py --robot chain12 --shapes quad --mfma $m --sizes 8,32,64 2>&1 | tail -4; done; echo "== chain12 row"; timeout -k 10 200 python scripts/shard_bench.py --robot chain12 --shapes row --sizes 8,32,64 2>&1 | tail -4; } > "$OUT/mfma_chain12.txt" 2>&1
 timeout -k 10 200 python scripts/ksweep.py > "$OUT/ksweep.txt" 2>&1
 echo "== dp_search"
 timeout -k 10 300 python scripts/dp_bench.py > "$OUT/dp_bench.txt" 2>&1
