@@ -406,12 +406,14 @@ def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
             base = np.clip(rng.uniform(ch.lo, ch.hi)[None, :] * 0.6 + np.cumsum(0.03 * rng.randn(T, ndof), axis=0), ch.lo, ch.hi)
             x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, ndof), ch.lo, ch.hi).reshape(S * T, ndof))
             target = H.f32(o64.fk(H.f32(base)))
+            # explicit virtual configurations (the alternating loop passes the previous x, optimization.py:253) where they apply
+            xv = H.f32(x + 0.01 * rng.randn(*x.shape)) if pm.use_virtual_configs else None
             got = {}
             for mode, (pcr, rows) in {"pcr": (1 << 30, 1), "rows": (0, 1), "wave": (0, 0)}.items():
                 L.cppf_debug_set_pcr_max_rows(pcr)
                 L.cppf_debug_set_full_rows(rows)
-                got[mode] = host(rb.lm_full_step(dev(x), dev(target), pm))
-            want = o64.lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi)
+                got[mode] = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=dev(xv) if xv is not None else None))
+            want = o64.lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi)
             step = np.abs(want - x).max()
             for mode, g in got.items():
                 assert np.isfinite(g).all(), (mode, S, T)
