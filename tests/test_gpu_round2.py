@@ -461,3 +461,43 @@ def test_launch_plan_without_collision_stage_matches_the_eager_call_and_replays_
     with pytest.raises(AssertionError):
         rb.lm_launch_plan(x0, target, n_steps=K, x_out=xo, errors_out=(pe, re),
                           packed_out=torch.empty(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=x0.device), **LM)
+
+
+def test_coupled_step_two_ended_elimination_over_a_sweep_of_shapes(robots):
+    """The two-ended row-per-lane elimination against the one-wavefront-per-trajectory elimination for every small count of
+    trajectories (partly filled wavefronts) and path length (T = 1: the join alone; T = 2, 3: one chain empty; odd / even splits;
+    shorter than the prefetch rings; just past them)."""
+    from cppflow_amd import _hip
+
+    rb, ch = robots["panda"], H.chain("panda")
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T_ for _, T_ in obs])
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+
+    L = _hip.lib()
+    worst = 0.0
+    try:
+        L.cppf_debug_set_pcr_max_rows(0)
+        for T in (1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 33, 40):
+            d = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+            d["use_virtual_configs"] = 2 * d["n_virtual_configs"] < T
+            pm = OptimizationParameters(**d)
+            pm.virtual_configs = torch.tensor([])
+            for S in (1, 7, 8, 9, 17):
+                rng = np.random.RandomState(1000 * T + S)
+                base = np.clip(rng.uniform(ch.lo, ch.hi)[None, :] * 0.5 + np.cumsum(0.03 * rng.randn(T, rb.ndof), axis=0), ch.lo, ch.hi)
+                x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, rb.ndof), ch.lo, ch.hi).reshape(S * T, rb.ndof))
+                target = dev(H.f32(H.oracle64("panda").fk(H.f32(base))))
+                L.cppf_debug_set_full_rows(1)
+                rows = host(rb.lm_full_step(dev(x), target, pm))
+                L.cppf_debug_set_full_rows(0)
+                wave = host(rb.lm_full_step(dev(x), target, pm))
+                step = np.abs(wave - x).max()
+                err = np.abs(rows - wave).max()
+                worst = max(worst, err / (1e-5 + 1e-3 * step))
+                assert np.isfinite(rows).all() and err < 1e-5 + 1e-3 * step, (S, T, err, step)
+    finally:
+        L.cppf_debug_set_pcr_max_rows(-1)
+        L.cppf_debug_set_full_rows(1)
+        rb.set_obstacles([], [])
+    assert worst < 1.0
