@@ -501,3 +501,24 @@ def test_coupled_step_two_ended_elimination_over_a_sweep_of_shapes(robots):
         L.cppf_debug_set_full_rows(1)
         rb.set_obstacles([], [])
     assert worst < 1.0
+
+
+def test_dp_search_table_form_over_a_sweep_of_shapes(robots):
+    """cppf_dp_search_tabled against the per-waypoint launches for every group / chunk boundary of its chain kernel (8 source
+    groups, chunks of 8 rows, 64-destination columns, one to three register sets in flight) and the shortest paths."""
+    from cppflow_amd import _hip
+
+    rb, ch = robots["panda"], H.chain("panda")
+    try:
+        _hip.lib().cppf_debug_set_dp_persistent(0)
+        for k in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 161, 191, 192, 193, 255, 256):
+            for T in (1, 2, 3, 4, 5, 6, 7, 12):
+                rng = np.random.RandomState(31 * k + T)
+                q = H.f32(np.clip(rng.uniform(ch.lo, ch.hi, size=(1, 1, rb.ndof)) * 0.5 + 0.2 * np.cumsum(rng.randn(k, T, rb.ndof) * 0.2, axis=1), ch.lo, ch.hi))
+                ext = ((rng.rand(k, T) < 0.2) * 1000.0 + (rng.rand(k, T) < 0.1) * 100.0).astype(np.float32)
+                a = rb.dp_search(dev(q), dev(ext), method="table", return_memo=True)
+                b = rb.dp_search(dev(q), dev(ext), method="resident", return_memo=True)
+                for i, (u, v) in enumerate(zip(a, b)):
+                    assert torch.equal(u, v), (k, T, i)
+    finally:
+        _hip.lib().cppf_debug_set_dp_persistent(1)
