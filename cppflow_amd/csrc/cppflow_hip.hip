@@ -184,14 +184,17 @@ int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to thi
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
 int g_occ4_min_rows = 131072;  // fused masks-only fp32 launch: the 128-VGPR instantiation from this many rows up (see kernels_fused.h)
+bool g_pcr_lds = true;         // coupled step, parallel-in-time form, W <= 256: the state in LDS instead of the workspace (cppf_debug_set_pcr_lds)
 bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
                                // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
 bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 256, the measured range in which it wins), else one launch per waypoint
 bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
-constexpr int kPcrMaxRowsDefault = 90112;  // 352 trajectories x 256 waypoints
-int g_pcr_max_rows = kPcrMaxRowsDefault;  // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows
-                                          // (measured crossover with the two-ended row-per-lane kernels at d <= 7; x 0.64 at d = 8)
+// coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows -- the measured crossovers with the
+// two-ended row-per-lane kernels at d <= 7 (x 0.64 at d = 8): 832 trajectories x 256 waypoints with the state in LDS (W <= 256),
+// 352 x 256 with the state in the workspace
+constexpr int kPcrMaxRowsLds = 212992, kPcrMaxRowsGlobal = 90112;
+int g_pcr_max_rows = -1;  // < 0: the defaults above
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -452,7 +455,7 @@ int cppf_robot_specialization(const cppf_robot* robot) {
 
 void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
 
-void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n < 0 ? kPcrMaxRowsDefault : n; }
+void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n < 0 ? -1 : n; }
 
 void cppf_debug_set_quad_max_rows(int n) { g_quad_max_rows = n; }
 
@@ -461,6 +464,8 @@ void cppf_debug_set_dp_persistent(int on) { g_dp_persistent = on != 0; }
 void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
 
 void cppf_debug_set_occ_min_rows(int n) { g_occ4_min_rows = n < 0 ? 131072 : n; }
+
+void cppf_debug_set_pcr_lds(int on) { g_pcr_lds = on != 0; }
 
 void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
@@ -910,7 +915,8 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.S = S;
     prm.W = W;
     // which elimination kernel: see the comments at the launches below
-    const size_t pcr_limit = g_pcr_max_rows > 0 ? (size_t)g_pcr_max_rows * (robot->desc.ndof <= 7 ? 100 : 64) / 100 : 0;
+    const size_t pcr_rows = g_pcr_max_rows >= 0 ? (size_t)g_pcr_max_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
+    const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 64) / 100;
     const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
     const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 8 &&
                           W <= (1 << 20);
@@ -930,7 +936,13 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
         switch (robot->desc.ndof) {
 #define CPPF_PCR_CASE(DD)                                                                                              \
     case DD:                                                                                                           \
-        if (W <= 256)                                                                                                  \
+        if (W <= 256 && g_pcr_lds) { /* the state in LDS: 256 x ((d(d+1)/2 + d + d^2) | 1) floats */                     \
+            constexpr size_t kState = 256 * (size_t)((DD * (DD + 1) / 2 + DD + DD * DD) | 1) * sizeof(float);           \
+            CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_solve_pcr_kernel<DD, 256, true>),         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kState));                    \
+            hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 256, true>), dim3((unsigned)S), dim3(256), kState, st,        \
+                               robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, x_out);                  \
+        } else if (W <= 256)                                                                                           \
             hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 256>), dim3((unsigned)S), dim3(256), 0, st, robot->chain, prm, \
                                x_in, virtual_configs, work_blocks, work_G, x_out);                                     \
         else                                                                                                           \

@@ -924,14 +924,31 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
 // parallel.  State lives in the caller's workspace (D_t packed | y_t in work_blocks, L_t dense in work_G) and is exchanged
 // between the lanes of the workgroup through L1 / L2 (workgroup-scope fences of __syncthreads).  Used without the pose block
 // (diagonal blocks = (cnt a^2 + lambda) I + collision terms: well conditioned, the Schur complements stay SPD).
-template <int D, int BS>
+// kLds (T <= 256): the state (D_t | y_t | L_t per waypoint, 84 floats at d = 7) lives in LDS for the whole launch instead of the
+// caller's workspace -- a level's neighbour reads are LDS reads instead of L2 round trips behind a barrier, which was half of a
+// level's time (86 KB of dynamic LDS at d = 7, 110 KB at d = 8: one workgroup per compute unit).
+template <int D, int BS, bool kLds = false>
 __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
                                                             const float* __restrict__ xv, float* blocks, float* workL,
                                                             float* __restrict__ x_out) {
     constexpr int NT = D * (D + 1) / 2, SB = NT + D, DD = D * D;
+    constexpr int STR = (SB + DD) | 1;  // odd stride: lanes t, t + 1, ... of a wavefront hit distinct banks
+    extern __shared__ float pcr_state[];
     const int s = blockIdx.x, t = threadIdx.x, T = prm.W;
     const bool act = t < T;
     const size_t base = (size_t)s * T;
+    auto st_blk = [&](int u) {
+        if constexpr (kLds)
+            return pcr_state + u * STR;
+        else
+            return blocks + (base + u) * SB;
+    };
+    auto st_L = [&](int u) {
+        if constexpr (kLds)
+            return pcr_state + u * STR + SB;
+        else
+            return workL + (base + u) * DD;
+    };
     float a2[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -942,7 +959,8 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
 
     // ---- assemble row t in place: D_t = M_t + (cnt a^2 + [vq] beta^2 + lambda) I,  y_t = m_t + analytic J^T r terms
     if (act) {
-        float* blk = blocks + (base + t) * SB;
+        const float* blk = blocks + (base + t) * SB;  // the row-parallel kernel's M_t | m_t
+        float* dst = st_blk(t);
         const bool has_next = t + 1 < T, has_prev = t > 0;
         const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
         const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
@@ -965,15 +983,21 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
 #pragma unroll
             for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, wrap_pi(xc[j] - xo[j]), b[j]);
         }
-        int k = 0;
+        {
+            int k = 0, kd = 0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            blk[k] += cnt * a2[i] + (vq ? beta2 : 0.f) + prm.lm_lambda;  // diagonal entry (i, i) of the packed upper triangle
-            k += D - i;
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = i; j < D; ++j) {
+                    float v = blk[k];
+                    if (j == i) v += cnt * a2[i] + (vq ? beta2 : 0.f) + prm.lm_lambda;  // diagonal of the packed upper triangle
+                    dst[k++] = v;
+                }
+            (void)kd;
         }
 #pragma unroll
-        for (int j = 0; j < D; ++j) blk[NT + j] = b[j];
-        float* Lt = workL + (base + t) * DD;
+        for (int j = 0; j < D; ++j) dst[NT + j] = b[j];
+        float* Lt = st_L(t);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -1010,7 +1034,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         float nD[D][D], ny[D], nL[D][D];
         if (act) {
             float Dn[D][D], P[D][D];
-            load_sym(blocks + (base + t) * SB, Dn);
+            load_sym(st_blk(t), Dn);
             spd_inverse<D>(Dn, prm.lm_lambda, P);
             int k = 0;
 #pragma unroll
@@ -1020,7 +1044,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         }
         __syncthreads();
         if (act) {
-            const float* own = blocks + (base + t) * SB;
+            const float* own = st_blk(t);
             load_sym(own, nD);
 #pragma unroll
             for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
@@ -1031,14 +1055,15 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
             const int tm = t - st, tp = t + st;
             if (tm >= 0) {
                 float P[D][D], Lt[D][D], Lm[D][D], ym[D];
-                const float* nb = blocks + (base + tm) * SB;
+                const float* nb = st_blk(tm);
+                const float *Ltp = st_L(t), *Lmp = st_L(tm);
                 load_inv(tm, P);
 #pragma unroll
                 for (int i = 0; i < D; ++i)
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        Lt[i][j] = workL[(base + t) * DD + i * D + j];
-                        Lm[i][j] = workL[(base + tm) * DD + i * D + j];
+                        Lt[i][j] = Ltp[i * D + j];
+                        Lm[i][j] = Lmp[i * D + j];
                     }
 #pragma unroll
                 for (int j = 0; j < D; ++j) ym[j] = nb[NT + j];
@@ -1071,12 +1096,13 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
             }
             if (tp < T) {
                 float P[D][D], Lp[D][D], yp[D];
-                const float* nb = blocks + (base + tp) * SB;
+                const float* nb = st_blk(tp);
+                const float* Lpp = st_L(tp);
                 load_inv(tp, P);
 #pragma unroll
                 for (int i = 0; i < D; ++i)
 #pragma unroll
-                    for (int j = 0; j < D; ++j) Lp[i][j] = workL[(base + tp) * DD + i * D + j];
+                    for (int j = 0; j < D; ++j) Lp[i][j] = Lpp[i * D + j];
 #pragma unroll
                 for (int j = 0; j < D; ++j) yp[j] = nb[NT + j];
 #pragma unroll
@@ -1105,7 +1131,8 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         }
         __syncthreads();  // every lane has read its neighbours' old state
         if (act) {
-            float* own = blocks + (base + t) * SB;
+            float* own = st_blk(t);
+            float* Lo = st_L(t);
             int k = 0;
 #pragma unroll
             for (int i = 0; i < D; ++i)
@@ -1116,13 +1143,13 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int j = 0; j < D; ++j) workL[(base + t) * DD + i * D + j] = nL[i][j];
+                for (int j = 0; j < D; ++j) Lo[i * D + j] = nL[i][j];
         }
         __syncthreads();
     }
     if (act) {
         float Dn[D][D], P[D][D], xr[D];
-        const float* own = blocks + (base + t) * SB;
+        const float* own = st_blk(t);
         load_sym(own, Dn);
         spd_inverse<D>(Dn, prm.lm_lambda, P);
         load_x<D>(x, base + t, xr);

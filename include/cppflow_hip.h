@@ -153,8 +153,8 @@ int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
 void cppf_debug_force_generic(int on);
 /* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
  * trajectory) when S*W <= n rows (x 0.64 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both
- * ends of the path (eight trajectories per wavefront) otherwise; n < 0 restores the default 90112, the measured crossover
- * (process-wide). */
+ * ends of the path (eight trajectories per wavefront) otherwise; n < 0 restores the defaults, the measured crossovers:
+ * 212992 rows with the state in LDS (W <= 256), 90112 with it in the workspace (process-wide). */
 void cppf_debug_set_pcr_max_rows(int n);
 /* Tuning hooks (process-wide): CPPF_SHAPE_AUTO runs four lanes per row up to n rows (default 16384 = one wavefront of that shape
  * per SIMD, the measured crossover) unless a per-seed summary is requested;
@@ -171,6 +171,9 @@ void cppf_debug_set_full_rows(int on);
  * VGPRs (168 beyond 8 joints; a few registers spilled outside the LM loop, one more wavefront per SIMD resident) from n rows
  * up; n < 0 restores the default 131072, a huge n switches it off (process-wide). */
 void cppf_debug_set_occ_min_rows(int n);
+/* Test hook: 0 makes the parallel-in-time elimination of cppf_lm_full_step keep its state in the caller's workspace (as it does
+ * for W > 256) instead of LDS (process-wide). */
+void cppf_debug_set_pcr_lds(int on);
 void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).

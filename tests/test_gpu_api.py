@@ -437,6 +437,13 @@ def test_coupled_step_parallel_in_time_equals_sequential_elimination(robots, nam
         pm = _full_params(use_virtual_configs=False)
         pm.virtual_configs = torch.tensor([])
     pcr = host(rb.lm_full_step(dev(x), dev(target), pm))
+    # the same reduction with its state in the caller's workspace instead of LDS (what W > 256 runs): same arithmetic
+    _hip.lib().cppf_debug_set_pcr_lds(0)
+    try:
+        pcr_ws = host(rb.lm_full_step(dev(x), dev(target), pm))
+    finally:
+        _hip.lib().cppf_debug_set_pcr_lds(1)
+    assert np.array_equal(pcr, pcr_ws)
     _hip.lib().cppf_debug_set_pcr_max_rows(0)
     try:
         seq = host(rb.lm_full_step(dev(x), dev(target), pm))
