@@ -73,6 +73,11 @@ fi
 echo "== rocprofv3 kernel trace"
 cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --no-siblings --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
+echo "== rocprofv3 kernel trace of the coupled step and dp_search (per kernel and grid size)"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_coupled" -o kt -- python3 "$ROOT/scripts/coupled_bench.py" --rounds 2 --seeds 1,256,1024 > /dev/null 2> "$OUT/kt_coupled_stderr.txt"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_dp" -o kt -- python3 "$ROOT/scripts/dp_bench.py" > /dev/null 2> "$OUT/kt_dp_stderr.txt"
+{ python3 "$ROOT/scripts/trace_by_grid.py" "$OUT/kt_coupled" full_; python3 "$ROOT/scripts/trace_by_grid.py" "$OUT/kt_dp" dp_ | grep -v dp_step_kernel; } > "$OUT/coupled_dp_kernels.txt" 2>&1
+rm -rf "$OUT/kt_coupled" "$OUT/kt_dp"
 echo "== rocprofv3 pmc FETCH_SIZE"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
 echo "== rocprofv3 pmc WRITE_SIZE"

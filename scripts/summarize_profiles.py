@@ -159,7 +159,7 @@ def main():
     with open(os.path.join(OUT, f"{TAG}_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=2)
     for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_C2.json", "bench_C3.json",
-                "bench_C5.json", "shard_streams.txt", "hwq_sweep.txt", "shard_bench.txt", "shard_bench_mfma.txt", "mfma_chain12.txt", "ksweep.txt", "dp_bench.txt", "coupled_bench.txt", "lone_wave_micro.txt", "kbench.txt",
+                "bench_C5.json", "shard_streams.txt", "hwq_sweep.txt", "shard_bench.txt", "shard_bench_mfma.txt", "mfma_chain12.txt", "ksweep.txt", "dp_bench.txt", "coupled_bench.txt", "coupled_dp_kernels.txt", "lone_wave_micro.txt", "kbench.txt",
                 "kbench_small.txt", "launch_model.txt", "rtc_bench.txt", "pytest_gpu.txt", "valu_issue_rate_calibration.txt"):  # fmt: skip
         if os.path.exists(os.path.join(REC, src)):
             shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{src}"))
