@@ -1065,7 +1065,7 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
 int cppf_dp_table_floats(int k, int T, size_t* n_floats) {
     if (!n_floats || k < 1 || T < 1) return fail(CPPF_ERR_INVALID, "cppf_dp_table_floats: k, T must be >= 1, n_floats non-NULL");
     const size_t kp = (size_t)((k + 63) / 64 * 64);
-    *n_floats = (size_t)(T > 1 ? T - 1 : 0) * (size_t)k * kp + 8 * kp;  // + 8 rows the chain may read past the last slab
+    *n_floats = (size_t)(T > 1 ? T - 1 : 0) * (size_t)k * kp + 32 * kp;  // + 32 rows the chain may read past the last slab
     return CPPF_OK;
 }
 

@@ -786,33 +786,46 @@ __global__ __launch_bounds__(64) void full_rows_eliminate_kernel(const FullK prm
         for (int c = 0; c < D; ++c) pM[u][c] = nxt[L.offM[c]];
         pb[u] = nxt[L.offb];
     }
+    // A block of PF steps is straight-line code (a step past the chain's end recomputes its last waypoint and stores nothing) and
+    // its results are stored together behind it.  Both matter on gfx950: (1) a branch around a step makes the compiler copy
+    // the freshly requested rows into the ring's registers at the end of the SAME step (a wait for loads just issued); (2) loads
+    // and stores share one counter (vmcnt) whose returns are ordered only within each kind, so with a store in flight a
+    // prefetched load can only be waited for by draining the counter -- clustered, the stores cost one drain per block.
     for (int t0 = 0; t0 < len; t0 += PF) {
+        float sG[PF][D], sy[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int tau = t0 + u;
-            if (tau < len) {
-                const int t = start + sgn * tau;
-                float A[8];
+            float A[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) A[c] = c < D ? pM[u][c] : 0.f;
-                const float b = pb[u];
-                {  // step tau + PF into the slot just read (the last PF steps re-read the chain's last waypoint)
-                    const float* nxt = blk + (size_t)(start + sgn * (tau + PF < len ? tau + PF : len - 1)) * STRIDE;
+            for (int c = 0; c < 8; ++c) A[c] = c < D ? pM[u][c] : 0.f;
+            const float b = pb[u];
+            {  // step tau + PF into the slot just read (the last PF steps re-read the chain's last waypoint)
+                const float* nxt = blk + (size_t)(start + sgn * (tau + PF < len ? tau + PF : len - 1)) * STRIDE;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) pM[u][c] = nxt[L.offM[c]];
-                    pb[u] = nxt[L.offb];
-                }
-                float ynew = b;
-                if (tau > 0) ynew = CPPF_FMA(L.a2r, rows_couple<D>(L, G, y, A), b);  // y = b - E (G y_prev),  E = -diag(a^2)
-                g8_gauss_jordan<D>(A, L.r, prm.lm_lambda);
-                y = ynew;
+                for (int c = 0; c < D; ++c) pM[u][c] = nxt[L.offM[c]];
+                pb[u] = nxt[L.offb];
+            }
+            // y = b - E (G y_prev),  E = -diag(a^2); at the chain's first step G = 0, y = 0: A and b pass through exactly
+            const float ynew = CPPF_FMA(L.a2r, rows_couple<D>(L, G, y, A), b);
+            g8_gauss_jordan<D>(A, L.r, prm.lm_lambda);
+            y = ynew;
 #pragma unroll
-                for (int c = 0; c < D; ++c) G[c] = A[c];
-                if (L.live) {
+            for (int c = 0; c < D; ++c) G[c] = A[c];
+#pragma unroll
+            for (int c = 0; c < D; ++c) sG[u][c] = G[c];
+            sy[u] = y;
+        }
+        if (L.live) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int tau = t0 + u;
+                if (tau < len) {
+                    const int t = start + sgn * tau;
                     float* gt = gw + (size_t)t * (D * D);
 #pragma unroll
-                    for (int c = 0; c < D; ++c) gt[L.offG + c] = G[c];
-                    yw[(size_t)t * D + L.offy] = y;
+                    for (int c = 0; c < D; ++c) gt[L.offG + c] = sG[u][c];
+                    yw[(size_t)t * D + L.offy] = sy[u];
                 }
             }
         }
@@ -880,34 +893,43 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
         for (int c = 0; c < D; ++c) dl = CPPF_FMA(A[c], rb[c], dl);
         if (dir == 1 && L.live) xo[(size_t)m * D + L.offy] = xm + dl;  // optimization.py:113: x + delta_x
     }
-    // ---- back substitution along this wavefront's chain, from the join outwards
+    // ---- back substitution along this wavefront's chain, from the join outwards.  The PB results of a block are kept in
+    // registers and stored together after it: gfx950 counts loads and stores on ONE counter (vmcnt) whose returns are ordered
+    // only within each kind, so with a store in flight the compiler can wait for a prefetched load only by draining the counter
+    // (s_waitcnt vmcnt(0)) -- a store per step made every step wait for the loads it had just issued, i.e. one memory latency
+    // per step whatever the prefetch depth.  Clustered, the stores cost one drain per PB steps.
     for (int t0 = len - 1; t0 >= 0; t0 -= PB) {
+        float xs[PB];  // (len = 0: the loop does not run; the prologue above then read waypoint m, harmlessly)
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
+        for (int u = 0; u < PB; ++u) {  // straight-line: a step past the chain's end (tau < 0) works on stale operands, stores nothing
             const int tau = t0 - u;
-            if (tau >= 0) {
-                const int t = start + sgn * tau;
-                float Gt[D];
+            float Gt[D];
 #pragma unroll
-                for (int c = 0; c < D; ++c) Gt[c] = qG[u][c];
-                const float yt = qy[u], xt = qx[u];
-                {
-                    const int tp = start + sgn * (tau - PB > 0 ? tau - PB : 0);
-                    const float* gt = gw + (size_t)tp * (D * D);
+            for (int c = 0; c < D; ++c) Gt[c] = qG[u][c];
+            const float yt = qy[u], xt = qx[u];
+            {
+                const int tp = start + sgn * (tau - PB > 0 ? tau - PB : 0);
+                const float* gt = gw + (size_t)tp * (D * D);
 #pragma unroll
-                    for (int c = 0; c < D; ++c) qG[u][c] = gt[L.offG + c];
-                    qy[u] = yw[(size_t)tp * D + L.offy];
-                    qx[u] = xin[(size_t)tp * D + L.offy];
-                }
-                float rb[8];
+                for (int c = 0; c < D; ++c) qG[u][c] = gt[L.offG + c];
+                qy[u] = yw[(size_t)tp * D + L.offy];
+                qx[u] = xin[(size_t)tp * D + L.offy];
+            }
+            float rb[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) rb[c] = 0.f;
-                g8_bcast_all<D>(CPPF_FMA(L.a2r, dl, yt), rb);
-                float acc = 0.f;
+            for (int c = 0; c < 8; ++c) rb[c] = 0.f;
+            g8_bcast_all<D>(CPPF_FMA(L.a2r, dl, yt), rb);
+            float acc = 0.f;
 #pragma unroll
-                for (int c = 0; c < D; ++c) acc = CPPF_FMA(Gt[c], rb[c], acc);
-                if (L.live) xo[(size_t)t * D + L.offy] = xt + acc;
-                dl = acc;
+            for (int c = 0; c < D; ++c) acc = CPPF_FMA(Gt[c], rb[c], acc);
+            xs[u] = xt + acc;
+            dl = acc;
+        }
+        if (L.live) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int tau = t0 - u;
+                if (tau >= 0) xo[(size_t)(start + sgn * tau) * D + L.offy] = xs[u];
             }
         }
     }

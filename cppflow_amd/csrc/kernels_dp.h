@@ -337,108 +337,124 @@ __global__ __launch_bounds__(256) void dp_table_kernel(const float* __restrict__
     table[idx] = dp_okey(m);
 }
 
-// eight sources of the chain: c_{t-1}[a] comes out of lane I0 + i of cv as a scalar operand and meets the lane's four
-// destinations; then the eight table rows of the next step go into the registers just used (16 bytes per lane: one
-// instruction fetches a whole row)
-struct DpU4 {
-    uint32_t x, y, z, w;
-};
+// eight sources of the chain: c_{t-1}[a] comes out of lane I0 + i of cv as a scalar operand and meets the lane's V = KP / 64
+// destinations (every lane of the wavefront owns V consecutive ones: one V-dword load per lane fetches a whole row, no lane
+// idles); then the eight table rows of the step ahead go into the registers just used
 template <int I0, int N, int KP>
-__device__ __forceinline__ void dp_chain_chunk(uint4 (&m)[N], uint32_t cv, DpU4& best, const uint32_t* next, int lane, bool reload) {
+__device__ __forceinline__ void dp_chain_chunk(uint32_t (&m)[N][KP / 64], uint32_t cv, uint32_t (&best)[KP / 64],
+                                               const uint32_t* next, unsigned col) {
+    constexpr int V = KP / 64;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, I0 + i);
-        best.x = min(best.x, max(m[I0 + i].x, c));
-        best.y = min(best.y, max(m[I0 + i].y, c));
-        best.z = min(best.z, max(m[I0 + i].z, c));
-        best.w = min(best.w, max(m[I0 + i].w, c));
-    }
-    if (reload) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)  // rows past the group's range (up to 7) are read too -- the next group's, or the 8 rows of
-                                     // padding behind the table: their cost lane is the largest key, they never win
-            m[I0 + i] = *reinterpret_cast<const uint4*>(next + (size_t)(I0 + i) * KP + 4 * (unsigned)lane);
+        for (int v = 0; v < V; ++v) best[v] = min(best[v], max(m[I0 + i][v], c));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // rows past the group's range are read too -- the next group's, or the padding behind the
+                                   // table: their cost lane is the largest key, they never win
+        const uint32_t* src = next + (size_t)(I0 + i) * KP + col;
+#pragma unroll
+        for (int v = 0; v < V; ++v) m[I0 + i][v] = src[v];
     }
 }
 
+// every chunk of every step runs, unconditionally: the compiler can count the loads in flight (s_waitcnt vmcnt(N)) only through
+// straight-line code -- a load under a branch makes it wait for (almost) everything, i.e. for the rows just requested
 template <int I0, int N, int KP>
-__device__ __forceinline__ void dp_chain_chunks(uint4 (&m)[N], uint32_t cv, int na, DpU4& best, const uint32_t* next, int lane,
-                                                bool reload) {
+__device__ __forceinline__ void dp_chain_chunks(uint32_t (&m)[N][KP / 64], uint32_t cv, uint32_t (&best)[KP / 64],
+                                                const uint32_t* next, unsigned col) {
     if constexpr (I0 < N) {
-        if (I0 < na) {  // wavefront-uniform
-            dp_chain_chunk<I0, N, KP>(m, cv, best, next, lane, reload);
-            dp_chain_chunks<I0 + 8, N, KP>(m, cv, na, best, next, lane, reload);
-        }
+        dp_chain_chunk<I0, N, KP>(m, cv, best, next, col);
+        dp_chain_chunks<I0 + 8, N, KP>(m, cv, best, next, col);
     }
 }
 
-// 8 wavefronts = 8 groups of <= NA sources; lane <-> destinations 4 lane .. 4 lane + 3 (lanes beyond the row idle).  SETS register
-// sets hold the table rows of SETS consecutive steps: step t computes on set t % SETS and refills it, chunk by chunk, with the
-// rows of step t + SETS -- a load has SETS steps to arrive (one step is shorter than the memory latency: with one set the
-// chain ran at one latency per waypoint).  k <= 192: two sets of 24 rows; k <= 256: one set of 32 (the register file's limit).
+// 8 wavefronts = 8 groups of <= NA sources; lane <-> destinations V lane .. V lane + V - 1.  SETS register sets hold the table
+// rows of SETS consecutive steps: step t computes on set t % SETS and refills it, chunk by chunk, with the rows of step
+// t + SETS -- a load has SETS steps to arrive.
 template <int KP, int NA, int SETS>  // KP = row stride of the table = k rounded up to 64: compile-time, so that the row offsets are literals
 __device__ __forceinline__ void dp_chain_body(const uint32_t* __restrict__ table, const float* __restrict__ ext, int k, int T,
-                                              float* __restrict__ costsT, uint32_t (&part)[2][8][256]) {
+                                              float* __restrict__ costsT, uint32_t (&part)[2][8][256], float (&hist)[32][256]) {
+    constexpr int V = KP / 64;
     const int tid = threadIdx.x, lane = tid & 63, grp = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int per = (k + 7) / 8;
     const int a0 = min(grp * per, k - 1);
     const int na = max(0, min(per, k - grp * per));  // a short last group / empty groups when k < 8
-    const bool active = 4 * lane < KP;
-    uint4 m[SETS][NA];
+    const unsigned col = (unsigned)(V * lane);
+    uint32_t m[SETS][NA][V];
 #pragma unroll
-    for (int u = 0; u < SETS; ++u) {
+    for (int u = 0; u < SETS; ++u) {  // the table rows of steps 1 .. SETS (set u serves steps u, u + SETS, ...; step t -> set t % SETS)
+        const int t = u == 0 ? SETS : u;  // the first step that uses set u
+        const uint32_t* row = table + ((size_t)min(t - 1, max(T - 2, 0)) * k + a0) * KP + col;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) m[u][i] = make_uint4(kDpKeyInf, kDpKeyInf, kDpKeyInf, kDpKeyInf);
-        if (na > 0 && active) {  // the table rows of steps 1 .. SETS (set u serves steps u, u + SETS, ...; step t -> set t % SETS)
-            const int t = u == 0 ? SETS : u;  // the first step that uses set u
-            const uint32_t* row = table + ((size_t)min(t - 1, max(T - 2, 0)) * k + a0) * KP;
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                if (i < ((na + 7) & ~7)) m[u][i] = *reinterpret_cast<const uint4*>(row + (size_t)i * KP + 4 * (unsigned)lane);
-        }
+            for (int v = 0; v < V; ++v) m[u][i][v] = row[(size_t)i * KP + v];
     }
-    // the external cost of THIS wavefront's sources at the previous waypoint, one waypoint ahead (ext is [k][T])
+    // the external cost of THIS wavefront's sources, SETS waypoints ahead of its use like the table rows (ext is [k][T]; a
+    // short chain's step is shorter than the load's latency): er[w % SETS] holds ext[s0][w], slots indexed at compile time
     const int s0 = min(a0 + lane, k - 1);
+    float er[SETS];
+#pragma unroll
+    for (int u = 0; u < SETS; ++u) er[u] = ext[(size_t)s0 * T + min(u == 0 ? SETS : u, T - 1)];  // the first waypoint >= 1 of each slot
+    const float c_first = costsT[s0];  // costs[:, 0] as dp_transpose_kernel left them
     float e0 = 0.f;
-    for (int t0 = 1; t0 < T; t0 += SETS) {
+    // Steps 1 .. T (step T only extracts the last cost row), in groups of SETS that are straight-line code: steps beyond T
+    // in the last group recompute on stale operands and store nothing.  Two gfx950 facts shape the loop (see also
+    // full_rows_eliminate_kernel): a branch around a step or around a load makes the compiler wait for (almost) every load in
+    // flight where it needs one, and loads and stores share ONE counter (vmcnt) whose returns are ordered only within each
+    // kind, so with a store in flight a prefetched load can only be waited for by draining it.  Hence: no global store in a
+    // step -- a cost row goes to an LDS ring and 16 rows at a time are written out, followed by an explicit drain, so that no
+    // store is ever pending where a load is waited for.
+    for (int t0 = 1; t0 <= T; t0 += SETS) {
 #pragma unroll
         for (int u = 0; u < SETS; ++u) {
             const int t = t0 + u;
-            if (t < T) {
-                constexpr int kSet0 = 1 % SETS;  // set of step t0 (t0 = 1 mod SETS)
-                const int set = (kSet0 + u) % SETS;
-                // ---- c_{t-1} for this wavefront's sources, one per lane
-                float c0;
-                if (t == 1) {
-                    c0 = costsT[s0];  // costs[:, 0] as dp_transpose_kernel left them
-                } else {
-                    const uint32_t (*p)[256] = part[(t - 1) & 1];
-                    uint32_t k0 = p[0][s0];
+            constexpr int kSet0 = 1 % SETS;  // set of step t0 (t0 = 1 mod SETS)
+            const int set = (kSet0 + u) % SETS;
+            // ---- c_{t-1} for this wavefront's sources, one per lane
+            float c0;
+            {
+                const uint32_t (*p)[256] = part[(t - 1) & 1];
+                uint32_t k0 = p[0][s0];
 #pragma unroll
-                    for (int g = 1; g < 8; ++g) k0 = min(k0, p[g][s0]);
-                    c0 = dp_okey_value(k0) + e0;  // search.py:157-158: min_a max(...) + ext (see the header)
-                    if (lane < na) costsT[(size_t)(t - 1) * k + a0 + lane] = c0;  // the cost row of step t - 1 (memo kernel, back-trace)
+                for (int g = 1; g < 8; ++g) k0 = min(k0, p[g][s0]);
+                c0 = t == 1 ? c_first : dp_okey_value(k0) + e0;  // search.py:157-158: min_a max(...) + ext (see the header)
+            }
+            if (lane < na && t >= 2 && t <= T) hist[(t - 1) & 31][a0 + lane] = c0;  // the cost row of step t - 1
+            const uint32_t cv = lane < na ? dp_okey(c0) : 0xFFFFFFFFu;  // sources beyond this group's range never win
+            // e_t, needed at step t + 1 (set = t % SETS); the slot is then reloaded with e_{t+SETS}.  The explicit move ends the
+            // old value's life in the slot's register BEFORE the load: left to itself the compiler loads into a scratch
+            // register and copies it into the slot at the loop's end -- a wait for a load just issued.
+            asm volatile("v_mov_b32 %0, %1" : "=v"(e0) : "v"(er[set]));
+            er[set] = ext[(size_t)s0 * T + min(t + SETS, T - 1)];
+            // ---- k^2 / 8 max / min pairs per wavefront; step t + SETS's table rows go into the registers just used
+            const uint32_t* next = table + ((size_t)min(t + SETS - 1, max(T - 2, 0)) * k + a0) * KP;
+            uint32_t best[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) best[v] = 0xFFFFFFFFu;
+            dp_chain_chunks<0, NA, KP>(m[set], cv, best, next, col);
+#pragma unroll
+            for (int v = 0; v < V; ++v) part[t & 1][grp][V * lane + v] = best[v];
+            // A workgroup barrier for the LDS exchange ONLY (__syncthreads() would also drain the global loads in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (((t - 1) & 15) == 15 && t <= T) {  // rows t - 16 .. t - 1 are complete in the ring: two per wavefront go out
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = t - 16 + 2 * grp + q;
+                    if (r >= 1)
+                        for (int jj = lane; jj < k; jj += 64) costsT[(size_t)r * k + jj] = hist[r & 31][jj];
                 }
-                const uint32_t cv = lane < na ? dp_okey(c0) : 0xFFFFFFFFu;  // sources beyond this group's range never win
-                e0 = ext[(size_t)s0 * T + t];                               // needed at step t + 1
-                // ---- k^2 / 8 max / min pairs per wavefront; step t + SETS's table rows go into the registers just used
-                const uint32_t* next = table + ((size_t)min(t + SETS - 1, T - 2) * k + a0) * KP;
-                DpU4 best = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                if (active) {
-                    dp_chain_chunks<0, NA, KP>(m[set], cv, na, best, next, lane, t + SETS < T);
-                    *reinterpret_cast<uint4*>(&part[t & 1][grp][4 * lane]) = make_uint4(best.x, best.y, best.z, best.w);
-                }
-                __syncthreads();
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no store is pending beyond this point
             }
         }
     }
-    // the last cost row
-    if (T >= 2 && lane < na) {
-        const uint32_t (*p)[256] = part[(T - 1) & 1];
-        uint32_t k0 = p[0][s0];
-#pragma unroll
-        for (int g = 1; g < 8; ++g) k0 = min(k0, p[g][s0]);
-        costsT[(size_t)(T - 1) * k + a0 + lane] = dp_okey_value(k0) + e0;
+    // the rows since the last full group of 16 (the barrier of step T has passed: row T - 1 is in the ring)
+    {
+        const int done = T >= 2 ? ((T - 1) / 16) * 16 - 1 : 0;  // last row written by the in-loop flushes (rows 1 .. done), -1 -> none
+        for (int r = max(done + 1, 1) + grp; r <= T - 1; r += 8)
+            for (int jj = lane; jj < k; jj += 64) costsT[(size_t)r * k + jj] = hist[r & 31][jj];
     }
 }
 
@@ -446,14 +462,16 @@ template <int KP>
 __global__ __launch_bounds__(512) void dp_chain_kernel(const uint32_t* __restrict__ table, const float* __restrict__ ext, int k,
                                                        int T, float* __restrict__ costsT) {
     __shared__ uint32_t part[2][8][256];  // [parity of t][source group][destination]: partial minima (keys) over the group's sources
+    __shared__ float hist[32][256];       // the last 32 cost rows (two windows of 16: one fills while the other is written out)
+    // register sets in flight: a step of a long row (k > 128) is as long as the memory latency, one set ahead is enough there
     if constexpr (KP <= 64)
-        dp_chain_body<KP, 8, 3>(table, ext, k, T, costsT, part);
+        dp_chain_body<KP, 8, 3>(table, ext, k, T, costsT, part, hist);
     else if constexpr (KP <= 128)
-        dp_chain_body<KP, 16, 3>(table, ext, k, T, costsT, part);
+        dp_chain_body<KP, 16, 2>(table, ext, k, T, costsT, part, hist);
     else if constexpr (KP <= 192)
-        dp_chain_body<KP, 24, 2>(table, ext, k, T, costsT, part);
+        dp_chain_body<KP, 24, 2>(table, ext, k, T, costsT, part, hist);
     else
-        dp_chain_body<KP, 32, 1>(table, ext, k, T, costsT, part);
+        dp_chain_body<KP, 32, 1>(table, ext, k, T, costsT, part, hist);
 }
 
 // memo_t[b] = first a with max(m_t[a][b], c_{t-1}[a]) + e_t[b] == c_t[b]   (0 when c_t[b] is not below +inf: nothing was ever

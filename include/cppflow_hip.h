@@ -325,8 +325,8 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
  * the reference materialises as well): the table is filled by the whole chip, the recurrence then runs on ONE compute unit
  * (no hand-off between workgroups: one workgroup barrier per waypoint, the table streamed through registers two steps ahead)
  * and the argmins are recovered in a third, parallel launch.  Same outputs, bit for bit, as cppf_dp_search.  Measured at
- * T = 256: 642 vs 717 us at the reference's k = 175, 458 vs 735 us at k = 128, 325 vs 419 us at k = 64; slower at k = 256
- * (one compute unit streams ~100 GB/s).  Extra workspace: work_table, cppf_dp_table_floats(k, T) = ((T-1) * k + 8) *
+ * T = 256: 560 vs 720 us at the reference's k = 175, 378 vs 734 us at k = 128, 168 vs 422 us at k = 64; slower at k = 256
+ * (one compute unit streams ~80-90 GB/s).  Extra workspace: work_table, cppf_dp_table_floats(k, T) = ((T-1) * k + 32) *
  * roundup(k, 64) floats (34 MB at k = 175, T = 256).  T <= 65536. */
 int cppf_dp_table_floats(int k, int T, size_t* n_floats);
 int cppf_dp_search_tabled(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,

@@ -10,3 +10,5 @@ using namespace dev;
 template __global__ void dev::dp_table_kernel<7>(const float*, int, int, int, uint32_t, float, uint32_t*);
 template __global__ void dev::dp_chain_kernel<192>(const uint32_t*, const float*, int, int, float*);
 template __global__ void dev::dp_chain_kernel<64>(const uint32_t*, const float*, int, int, float*);
+template __global__ void dev::dp_chain_kernel<128>(const uint32_t*, const float*, int, int, float*);
+template __global__ void dev::dp_chain_kernel<256>(const uint32_t*, const float*, int, int, float*);
