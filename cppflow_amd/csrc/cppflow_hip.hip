@@ -191,9 +191,9 @@ bool g_dp_persistent = true;    // dp_search: the whole recurrence in one reside
 bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
 bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
 // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows -- the measured crossovers with the
-// two-ended row-per-lane kernels at d <= 7 (x 0.64 at d = 8): 832 trajectories x 256 waypoints with the state in LDS (W <= 256),
-// 352 x 256 with the state in the workspace
-constexpr int kPcrMaxRowsLds = 212992, kPcrMaxRowsGlobal = 90112;
+// two-ended row-per-lane kernels at d <= 7 (x 0.5 at d = 8): 512 trajectories x 256 waypoints with the state in LDS (W <= 256: one
+// workgroup per compute unit, so the time steps up at every multiple of 256 trajectories), 192 x 256 with the state in the workspace
+constexpr int kPcrMaxRowsLds = 131072, kPcrMaxRowsGlobal = 49152;
 int g_pcr_max_rows = -1;  // < 0: the defaults above
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
@@ -916,7 +916,7 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.W = W;
     // which elimination kernel: see the comments at the launches below
     const size_t pcr_rows = g_pcr_max_rows >= 0 ? (size_t)g_pcr_max_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
-    const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 64) / 100;
+    const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 50) / 100;
     const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
     const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 8 &&
                           W <= (1 << 20);

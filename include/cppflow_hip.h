@@ -152,9 +152,9 @@ int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
 /* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
 void cppf_debug_force_generic(int on);
 /* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
- * trajectory) when S*W <= n rows (x 0.64 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both
+ * trajectory) when S*W <= n rows (x 0.5 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both
  * ends of the path (eight trajectories per wavefront) otherwise; n < 0 restores the defaults, the measured crossovers:
- * 212992 rows with the state in LDS (W <= 256), 90112 with it in the workspace (process-wide). */
+ * 131072 rows with the state in LDS (W <= 256), 49152 with it in the workspace (process-wide). */
 void cppf_debug_set_pcr_max_rows(int n);
 /* Tuning hooks (process-wide): CPPF_SHAPE_AUTO runs four lanes per row up to n rows (default 16384 = one wavefront of that shape
  * per SIMD, the measured crossover) unless a per-seed summary is requested;
