@@ -918,8 +918,8 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     const size_t pcr_rows = g_pcr_max_rows >= 0 ? (size_t)g_pcr_max_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
     const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 50) / 100;
     const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
-    const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 8 &&
-                          W <= (1 << 20);
+    const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 12 &&
+                          W <= (1 << 19);
     prm.fold = use_rows;
     hipStream_t st = (hipStream_t)stream;
 #define CPPF_BODY                                                                                                     \
@@ -958,7 +958,8 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     // row-per-lane kernels: 8 trajectories per one-wavefront workgroup and two workgroups (the two ends of the path) per 8
     // trajectories; the LDS reservation caps the workgroups per compute unit at ceil(#workgroups / 256) (160 KB per compute
     // unit), which spreads a small launch over distinct compute units
-    const unsigned rows_wgs = 2u * (unsigned)((S + 7) / 8);
+    const int rows_tpw = robot->desc.ndof <= 8 ? 8 : 4;  // trajectories per wavefront: 8 or 16 lanes each
+    const unsigned rows_wgs = 2u * (unsigned)((S + rows_tpw - 1) / rows_tpw);
     const unsigned rows_per_cu = (rows_wgs + 255) / 256;
     const size_t rows_lds = rows_per_cu == 1 ? 96 * 1024 : rows_per_cu == 2 ? 64 * 1024 : rows_per_cu == 3 ? 48 * 1024 : 0;
     switch (prm.use_pose ? 0 : robot->desc.ndof) {
@@ -981,6 +982,25 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
         break;
         CPPF_WAVE_CASE(3) CPPF_WAVE_CASE(4) CPPF_WAVE_CASE(5) CPPF_WAVE_CASE(6) CPPF_WAVE_CASE(7) CPPF_WAVE_CASE(8)
 #undef CPPF_WAVE_CASE
+#define CPPF_ROWS16_CASE(DD) /* 9 .. 12 joints: sixteen lanes per trajectory (no one-wavefront-per-trajectory form) */          \
+    case DD:                                                                                                            \
+        if (use_rows) {                                                                                                 \
+            if (rows_lds > 64 * 1024) {                                                                                 \
+                CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_rows_eliminate_kernel<DD>),            \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                   \
+                CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_rows_substitute_kernel<DD>),           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                   \
+            }                                                                                                           \
+            hipLaunchKernelGGL((full_rows_eliminate_kernel<DD>), dim3(rows_wgs), dim3(64), rows_lds, st, prm,           \
+                               robot->chain.pris_mask, work_blocks, work_G, work_y);                                    \
+            hipLaunchKernelGGL((full_rows_substitute_kernel<DD>), dim3(rows_wgs), dim3(64), rows_lds, st, prm,          \
+                               robot->chain.pris_mask, x_in, work_blocks, work_G, work_y, x_out);                       \
+        } else                                                                                                          \
+            hipLaunchKernelGGL((full_solve_kernel<DD>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, robot->chain, \
+                               prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out);                         \
+        break;
+        CPPF_ROWS16_CASE(9) CPPF_ROWS16_CASE(10) CPPF_ROWS16_CASE(12)
+#undef CPPF_ROWS16_CASE
         default:
             CPPF_DISPATCH_D(robot->desc.ndof,
                             hipLaunchKernelGGL((full_solve_kernel<D>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,

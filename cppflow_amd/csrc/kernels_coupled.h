@@ -644,38 +644,51 @@ __global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, co
 // pivoting (SPD; pivots floored like everywhere else): per pivot the pivot row is broadcast (16 DPP), and one FMA per entry with
 // the factor f = A_rk / p (f = 1 - 1/p in the pivot's own lane, which turns its row into row / p) updates the whole row.
 // ~300 instructions per waypoint forward, ~45 back, one wavefront for eight trajectories: 1024 trajectories are 128 wavefronts.
-template <int K>
-__device__ __forceinline__ float g8_bcast(float x) {  // value of lane (8 g + K) in every lane of group g
-    float t = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), (K & 3) * 0x55, 0xf, 0xf, true));
-    const int ti = __builtin_bit_cast(int, t);
-    if constexpr (K < 4)  // the source sits in the even quad of its group: odd quads (banks 1, 3) read lane - 4
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x114, 0xf, 0xa, false));
-    else                  // ... in the odd quad: even quads (banks 0, 2) read lane + 4
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, 0x104, 0xf, 0x5, false));
+// d > 8 (up to 16): the same with SIXTEEN lanes per trajectory (one DPP row; four trajectories per wavefront) -- a broadcast is
+// then quad_perm + three bank-masked row shifts (one per other quad of the row): four DPP instructions.
+template <int D>
+inline constexpr int kRowsGW = D <= 8 ? 8 : 16;  // lanes per trajectory = padded block size
+
+template <int GW, int K>
+__device__ __forceinline__ float g_bcast(float x) {  // value of lane (GW g + K) in every lane of group g
+    int t = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), (K & 3) * 0x55, 0xf, 0xf, true);
+    if constexpr (GW == 8) {
+        if constexpr (K < 4)  // the source sits in the even quad of its group: odd quads (banks 1, 3) read lane - 4
+            t = __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xa, false);
+        else                  // ... in the odd quad: even quads (banks 0, 2) read lane + 4
+            t = __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);
+    } else {
+        constexpr int qk = K >> 2;  // the source's quad; every other quad q of the row reads 4 |q - qk| lanes down / up
+        if constexpr (qk != 0) t = __builtin_amdgcn_update_dpp(t, t, 0x100 + 4 * qk, 0xf, 0x1, false);          // row_shl
+        if constexpr (qk != 1) t = __builtin_amdgcn_update_dpp(t, t, qk > 1 ? 0x100 + 4 * (qk - 1) : 0x114, 0xf, 0x2, false);
+        if constexpr (qk != 2) t = __builtin_amdgcn_update_dpp(t, t, qk > 2 ? 0x104 : 0x110 + 4 * (2 - qk), 0xf, 0x4, false);
+        if constexpr (qk != 3) t = __builtin_amdgcn_update_dpp(t, t, 0x110 + 4 * (3 - qk), 0xf, 0x8, false);    // row_shr
+    }
+    return __builtin_bit_cast(float, t);
 }
 
 template <int D, int C = 0>
-__device__ __forceinline__ void g8_bcast_all(float x, float (&out)[8]) {
+__device__ __forceinline__ void g8_bcast_all(float x, float (&out)[kRowsGW<D>]) {
     if constexpr (C < D) {
-        out[C] = g8_bcast<C>(x);
+        out[C] = g_bcast<kRowsGW<D>, C>(x);
         g8_bcast_all<D, C + 1>(x, out);
     }
 }
 
 template <int D, int K, int C = 0>
-__device__ __forceinline__ void g8_bcast_row(const float (&A)[8], float (&out)[8]) {  // out[c] = A[c] of lane K of the group
+__device__ __forceinline__ void g8_bcast_row(const float (&A)[kRowsGW<D>], float (&out)[kRowsGW<D>]) {  // out[c] = A[c] of lane K of the group
     if constexpr (C < D) {
-        out[C] = g8_bcast<K>(A[C]);
+        out[C] = g_bcast<kRowsGW<D>, K>(A[C]);
         g8_bcast_row<D, K, C + 1>(A, out);
     }
 }
 
 template <int D, int K = 0>
-__device__ __forceinline__ void g8_gauss_jordan(float (&A)[8], int r, float floor_) {
+__device__ __forceinline__ void g8_gauss_jordan(float (&A)[kRowsGW<D>], int r, float floor_) {
     if constexpr (K < D) {
-        float pr[8];
+        float pr[kRowsGW<D>];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pr[c] = 0.f;
+        for (int c = 0; c < kRowsGW<D>; ++c) pr[c] = 0.f;
         // pivot row K, every column
         g8_bcast_row<D, K>(A, pr);
         const float pv = __builtin_amdgcn_fmed3f(pr[K], floor_, INFINITY);  // max(pivot, floor) in one instruction
@@ -711,17 +724,18 @@ struct RowsLane {
 template <int D>
 __device__ __forceinline__ RowsLane<D> rows_lane(const FullK& prm, uint32_t pris_mask, int wave, int lane) {
     constexpr int NT = D * (D + 1) / 2, STRIDE = NT + D;
+    constexpr int GW = kRowsGW<D>, TPW = 64 / GW;  // lanes per trajectory, trajectories per wavefront
     RowsLane<D> L;
-    L.r = lane & 7;
-    const int s_raw = wave * 8 + (lane >> 3);
+    L.r = lane & (GW - 1);
+    const int s_raw = wave * TPW + lane / GW;
     L.live = s_raw < prm.S && L.r < D;
     const int s = s_raw < prm.S ? s_raw : prm.S - 1;
     L.rr = L.r < D ? L.r : 0;
     const int T = prm.W;
     // Addresses = a wavefront-uniform 64-bit part (this wavefront's first trajectory, moved by one waypoint per step) + a
     // 32-bit lane part fixed for the whole kernel (the host bounds 8 W d^2 floats to 2^31 bytes)
-    L.ubase = (size_t)wave * 8 * (size_t)T;
-    const unsigned lrow = (unsigned)(s - wave * 8) * (unsigned)T;
+    L.ubase = (size_t)wave * TPW * (size_t)T;
+    const unsigned lrow = (unsigned)(s - wave * TPW) * (unsigned)T;
 #pragma unroll
     for (int c = 0; c < D; ++c) {  // (min(r,c), max(r,c)) in the packed upper triangle
         const int ii = L.rr < c ? L.rr : c, jj = L.rr < c ? c : L.rr;
@@ -744,10 +758,10 @@ __device__ __forceinline__ RowsLane<D> rows_lane(const FullK& prm, uint32_t pris
 
 // A -= E G E (this lane's row) and the return value  (G v)_r  for the vector v held one component per lane
 template <int D>
-__device__ __forceinline__ float rows_couple(const RowsLane<D>& L, const float (&G)[D], float v, float (&A)[8]) {
-    float vb[8];
+__device__ __forceinline__ float rows_couple(const RowsLane<D>& L, const float (&G)[D], float v, float (&A)[kRowsGW<D>]) {
+    float vb[kRowsGW<D>];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) vb[c] = 0.f;
+    for (int c = 0; c < kRowsGW<D>; ++c) vb[c] = 0.f;
     g8_bcast_all<D>(v, vb);
     float acc = 0.f;
 #pragma unroll
@@ -762,7 +776,7 @@ template <int D>
 __global__ __launch_bounds__(64) void full_rows_eliminate_kernel(const FullK prm, const uint32_t pris_mask,
                                                                  const float* __restrict__ blocks, float* __restrict__ workG,
                                                                  float* __restrict__ worky) {
-    static_assert(D <= 8, "one row of the 8 x 8 padded block per lane");
+    static_assert(D <= 16, "one row of the padded block per lane: 8 or 16 lanes per trajectory");
     constexpr int NT = D * (D + 1) / 2, STRIDE = NT + D;
     const int wave = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int T = prm.W, m = T / 2;
@@ -796,9 +810,9 @@ __global__ __launch_bounds__(64) void full_rows_eliminate_kernel(const FullK prm
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int tau = t0 + u;
-            float A[8];
+            float A[kRowsGW<D>];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) A[c] = c < D ? pM[u][c] : 0.f;
+            for (int c = 0; c < kRowsGW<D>; ++c) A[c] = c < D ? pM[u][c] : 0.f;
             const float b = pb[u];
             {  // step tau + PF into the slot just read (the last PF steps re-read the chain's last waypoint)
                 const float* nxt = blk + (size_t)(start + sgn * (tau + PF < len ? tau + PF : len - 1)) * STRIDE;
@@ -864,9 +878,9 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
     float dl;
     {
         const float* bm = blk + (size_t)m * STRIDE;
-        float A[8];
+        float A[kRowsGW<D>];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) A[c] = c < D ? bm[L.offM[c]] : 0.f;
+        for (int c = 0; c < kRowsGW<D>; ++c) A[c] = c < D ? bm[L.offM[c]] : 0.f;
         float rhs = bm[L.offb];
         const float xm = xin[(size_t)m * D + L.offy];
         if (m > 0) {
@@ -884,9 +898,9 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
             rhs = CPPF_FMA(L.a2r, rows_couple<D>(L, Gn, yw[(size_t)(m + 1) * D + L.offy], A), rhs);
         }
         g8_gauss_jordan<D>(A, L.r, prm.lm_lambda);
-        float rb[8];
+        float rb[kRowsGW<D>];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) rb[c] = 0.f;
+        for (int c = 0; c < kRowsGW<D>; ++c) rb[c] = 0.f;
         g8_bcast_all<D>(rhs, rb);
         dl = 0.f;
 #pragma unroll
@@ -915,9 +929,9 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
                 qy[u] = yw[(size_t)tp * D + L.offy];
                 qx[u] = xin[(size_t)tp * D + L.offy];
             }
-            float rb[8];
+            float rb[kRowsGW<D>];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) rb[c] = 0.f;
+            for (int c = 0; c < kRowsGW<D>; ++c) rb[c] = 0.f;
             g8_bcast_all<D>(CPPF_FMA(L.a2r, dl, yt), rb);
             float acc = 0.f;
 #pragma unroll

@@ -19,3 +19,5 @@ template __global__ void dev::full_blocks_kernel<DynRobot<7>>(const ChainK, cons
 template __global__ void dev::full_rows_eliminate_kernel<7>(const FullK, const uint32_t, const float*, float*, float*);
 template __global__ void dev::full_rows_substitute_kernel<7>(const FullK, const uint32_t, const float*, const float*, const float*, const float*, float*);
 template __global__ void dev::full_solve_pcr_kernel<7, 256, true>(const ChainK, const FullK, const float*, const float*, float*, float*, float*);
+template __global__ void dev::full_rows_eliminate_kernel<12>(const FullK, const uint32_t, const float*, float*, float*);
+template __global__ void dev::full_rows_substitute_kernel<12>(const FullK, const uint32_t, const float*, const float*, const float*, const float*, float*);

@@ -376,12 +376,13 @@ def Oracle_fk(ch, q):
     return Oracle(ch, f32=False).fk(q)
 
 
-@pytest.mark.parametrize("ndof,seed", [(3, 4), (4, 5), (5, 6), (6, 0), (8, 2)])
+@pytest.mark.parametrize("ndof,seed", [(3, 4), (4, 5), (5, 6), (6, 0), (8, 2), (9, 7), (10, 8), (12, 3)])
 def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
     """cppf_lm_full_step on chains that match no generated table (every ndof the row-per-lane kernels are instantiated for, a
     prismatic joint with its own differencing scale, T odd and even, a ragged count of trajectories): the two-ended row-per-lane
     elimination, the one-wavefront-per-trajectory elimination and parallel cyclic reduction agree with each other and with
-    the oracle's dense restatement of cppflow/optimization.py:95-144."""
+    the oracle's dense restatement of cppflow/optimization.py:95-144.  Beyond 8 joints the row-per-lane kernels use sixteen lanes
+    per trajectory, the cross-check ("wave") is the one-lane-per-trajectory kernel and there is no parallel-in-time form."""
     from cppflow_amd import _hip
     from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
     from cppflow_amd.robot_model import canonicalize
