@@ -40,6 +40,10 @@ __device__ __forceinline__ float wave_reduce_to_lane63(float v) {
 // or a sum of small integers / multiples of 100, so the order does not matter).  Requires W in {64, 128, 256}: a workgroup
 // then covers whole seeds and a seed is 1, 2 or 4 whole wavefronts.  Joint changes need the NEXT waypoint's final q:
 // lane + 1 through DPP wave_shl:1, the first lane of the next wavefront through LDS.
+// A workgroup barrier for an exchange through LDS ONLY.  __syncthreads() also waits for every global access in flight
+// (s_waitcnt vmcnt(0)) -- here the row's 13 output stores, issued just before: a memory round trip for nothing.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class RB>
 __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t row, bool active, const float (&q)[RB::D],
                                                    const RowSummary& rs, float* __restrict__ out) {
@@ -54,7 +58,7 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
 #pragma unroll
             for (int j = 0; j < D; ++j) s_q[wave][j] = q[j];
         }
-        __syncthreads();
+        lds_barrier();
     }
     const bool seed_ends_here = ((wave + 1) & (wps - 1)) == 0;  // this wavefront holds the seed's last waypoints
     const bool has_next = active && !(lane == 63 && seed_ends_here);
@@ -90,7 +94,7 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_red[wave][k] = v[k];
     }
-    __syncthreads();
+    lds_barrier();
     if (active && lane == 63 && seed_ends_here) {
         for (int i = 1; i < wps; ++i) {
 #pragma unroll
