@@ -124,6 +124,7 @@ SIGNATURES = {
     "cppf_debug_set_full_rows": (None, [ctypes.c_int]),
     "cppf_debug_set_occ_min_rows": (None, [ctypes.c_int]),
     "cppf_debug_set_pcr_lds": (None, [ctypes.c_int]),
+    "cppf_debug_set_rows_pose": (None, [ctypes.c_int]),
     "cppf_debug_set_quad_mfma": (None, [ctypes.c_int]),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),

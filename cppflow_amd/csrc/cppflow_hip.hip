@@ -184,6 +184,7 @@ int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to thi
                                 // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
 int g_occ4_min_rows = 131072;  // fused masks-only fp32 launch: the 128-VGPR instantiation from this many rows up (see kernels_fused.h)
+bool g_rows_pose = false;      // coupled step WITH the pose block through the row-per-lane kernels too (cppf_debug_set_rows_pose)
 bool g_pcr_lds = true;         // coupled step, parallel-in-time form, W <= 256: the state in LDS instead of the workspace (cppf_debug_set_pcr_lds)
 bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
                                // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
@@ -466,6 +467,8 @@ void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
 void cppf_debug_set_occ_min_rows(int n) { g_occ4_min_rows = n < 0 ? 131072 : n; }
 
 void cppf_debug_set_pcr_lds(int on) { g_pcr_lds = on != 0; }
+
+void cppf_debug_set_rows_pose(int on) { g_rows_pose = on != 0; }
 
 void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
 
@@ -918,8 +921,8 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     const size_t pcr_rows = g_pcr_max_rows >= 0 ? (size_t)g_pcr_max_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
     const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 50) / 100;
     const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
-    const bool use_rows = !use_pcr && !prm.use_pose && g_full_rows && robot->desc.ndof >= 3 && robot->desc.ndof <= 12 &&
-                          W <= (1 << 19);
+    const bool use_rows = !use_pcr && (!prm.use_pose || g_rows_pose) && g_full_rows && robot->desc.ndof >= 3 &&
+                          robot->desc.ndof <= 12 && W <= (1 << 19);
     prm.fold = use_rows;
     hipStream_t st = (hipStream_t)stream;
 #define CPPF_BODY                                                                                                     \
@@ -962,7 +965,7 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     const unsigned rows_wgs = 2u * (unsigned)((S + rows_tpw - 1) / rows_tpw);
     const unsigned rows_per_cu = (rows_wgs + 255) / 256;
     const size_t rows_lds = rows_per_cu == 1 ? 96 * 1024 : rows_per_cu == 2 ? 64 * 1024 : rows_per_cu == 3 ? 48 * 1024 : 0;
-    switch (prm.use_pose ? 0 : robot->desc.ndof) {
+    switch ((prm.use_pose && !use_rows) ? 0 : robot->desc.ndof) {
 #define CPPF_WAVE_CASE(DD)                                                                                              \
     case DD:                                                                                                            \
         if (use_rows) {                                                                                                 \

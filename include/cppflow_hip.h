@@ -174,6 +174,9 @@ void cppf_debug_set_occ_min_rows(int n);
 /* Test hook: 0 makes the parallel-in-time elimination of cppf_lm_full_step keep its state in the caller's workspace (as it does
  * for W > 256) instead of LDS (process-wide). */
 void cppf_debug_set_pcr_lds(int on);
+/* Tuning hook: non-zero sends cppf_lm_full_step WITH the pose block (rank-deficient d x d blocks) through the row-per-lane
+ * Gauss-Jordan kernels as well instead of the one-lane-per-trajectory Cholesky kernel (process-wide). */
+void cppf_debug_set_rows_pose(int on);
 void cppf_debug_set_quad_mfma(int on);
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
