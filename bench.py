@@ -839,6 +839,35 @@ def main():
         return {"value": rows * K * steps / el, "ms_per_step": 1e3 * el / steps, "kernel_ms": km, "streams": streams,
                 "rows_per_gpu": int(rows // world)}  # fmt: skip
 
+    def measure_neighbour_stages(robot, run, W, d, device):
+        """The two stages on either side of the hot path, on this workload's own result, untimed and
+        outside `value`: the coupled differencing step (cppf_lm_full_step, ALT_LOSS_V2_1_DIFF) for all seeds and for one, and
+        dp_search over the reference's k = 175 candidates.  HIP events, median of 5 rounds of 5 calls."""
+        from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF
+
+        def timed_us(fn):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(5):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) / 5 * 1e3)
+            return float(np.median(ts))
+
+        x = run.x_outs[0]
+        out = {"coupled_step_us": timed_us(lambda: robot.lm_full_step(x, target, ALT_LOSS_V2_1_DIFF)), "coupled_step_trajectories": run.S,
+               "coupled_step_one_trajectory_us": timed_us(lambda: robot.lm_full_step(x[:W], target, ALT_LOSS_V2_1_DIFF))}
+        kk = min(175, run.S)
+        q3 = x.view(run.S, W, d)[:kk].contiguous()
+        cost = run.outputs["ext_cost"].view(run.S, W)[:kk].contiguous()
+        out.update(dp_search_us=timed_us(lambda: robot.dp_search(q3, cost)), dp_search_candidates=kk, waypoints=W)
+        return out
+
     siblings = {}
     if not args.no_siblings:
         sib_steps = min(args.steps, 1000)
@@ -854,6 +883,8 @@ def main():
             siblings["one_stream"] = measure_sibling(S_main, scaling, args.inputs, 1, sib_steps)
             if args.inputs == "problem":
                 siblings["random_inputs"] = measure_sibling(S_main, scaling, "random", n_streams, sib_steps)
+            if collide and d <= 12 and W >= 2:
+                siblings["neighbour_stages"] = measure_neighbour_stages(robot, run, W, d, device)
 
     if rank == 0:
         iters = float(n) * K * args.steps * world
