@@ -1108,7 +1108,7 @@ int cppf_dp_search_tabled(const cppf_robot* robot, const float* q, const float* 
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
     if (T >= 2) {
         CPPF_REQUIRE(T - 1 <= 65535, "cppf_dp_search_tabled: T <= 65536");
-        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_table_kernel<D>), dim3((unsigned)((k * kp + 255) / 256), (unsigned)(T - 1)),
+        CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_table_kernel<D>), dim3((unsigned)((kp + 255) / 256), (unsigned)((k + 7) / 8), (unsigned)(T - 1)),
                                              dim3(256), 0, st, work_qT, k, kp, T, robot->chain.pris_mask, prismatic_scaling,
                                              reinterpret_cast<uint32_t*>(work_table)));
         const uint32_t* tab = reinterpret_cast<const uint32_t*>(work_table);

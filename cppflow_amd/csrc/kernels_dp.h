@@ -316,25 +316,31 @@ constexpr uint32_t kDpKeyInf = 0xFF800000u;  // key(+inf)
 template <int D>
 __global__ __launch_bounds__(256) void dp_table_kernel(const float* __restrict__ qT, int k, int kp, int T, uint32_t pris_mask,
                                                        float pscale, uint32_t* __restrict__ table) {
-    // grid: x over the k kp entries of one step, y = step - 1
-    const unsigned r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= (unsigned)(k * kp)) return;
-    const int t = (int)blockIdx.y + 1;
-    const int a = (int)(r / (unsigned)kp), b = (int)(r % (unsigned)kp);
-    const size_t idx = (size_t)(t - 1) * k * kp + r;
-    float m = INFINITY;  // row padding: a destination that does not exist
-    if (b < k) {
-        const float* qa = qT + ((size_t)(t - 1) * k + a) * D;
-        const float* qb = qT + ((size_t)t * k + b) * D;
-        m = 0.f;
+    // grid: x over chunks of 256 destinations, y over chunks of 8 sources, z = step - 1.  A thread keeps its destination's
+    // configuration in registers for the 8 sources of its chunk, whose configurations are wavefront-uniform (scalar loads).
+    const int b = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (b >= kp) return;
+    const int t = (int)blockIdx.z + 1, a0 = (int)blockIdx.y * 8;
+    float qb[D];
+    {
+        const float* src = qT + ((size_t)t * k + min(b, k - 1)) * D;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            float dq = qb[j] - qa[j];
-            if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-            m = fmaxf(m, fabsf(wrap_pi(dq)));
-        }
+        for (int j = 0; j < D; ++j) qb[j] = src[j];
     }
-    table[idx] = dp_okey(m);
+    for (int a = a0; a < min(a0 + 8, k); ++a) {
+        float m = INFINITY;  // row padding: a destination that does not exist
+        if (b < k) {
+            const float* qa = qT + ((size_t)(t - 1) * k + a) * D;
+            m = 0.f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float dq = qb[j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
+                m = fmaxf(m, fabsf(wrap_pi(dq)));
+            }
+        }
+        table[((size_t)(t - 1) * k + a) * kp + b] = dp_okey(m);
+    }
 }
 
 // eight sources of the chain: c_{t-1}[a] comes out of lane I0 + i of cv as a scalar operand and meets the lane's V = KP / 64
