@@ -926,8 +926,12 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.fold = use_rows;
     hipStream_t st = (hipStream_t)stream;
 #define CPPF_BODY                                                                                                     \
-    hipLaunchKernelGGL((full_blocks_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, robot->chain, \
-                       robot->coll, prm, x_in, target, virtual_configs, work_blocks)
+    if (n >= 131072)                                                                                                  \
+        hipLaunchKernelGGL((full_blocks_kernel<RB, (RB::D <= 8)>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, \
+                           robot->chain, robot->coll, prm, x_in, target, virtual_configs, work_blocks);              \
+    else                                                                                                              \
+        hipLaunchKernelGGL((full_blocks_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, robot->chain, \
+                           robot->coll, prm, x_in, target, virtual_configs, work_blocks)
     CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     // Trajectories are eliminated one per wavefront (8 x 8 lane tile) up to 8 joints, one per lane beyond.  With the pose

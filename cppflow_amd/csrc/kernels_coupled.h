@@ -178,8 +178,12 @@ __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm,
 // writes its blocks straight away; the others run the general pass below over the flagged tests only (joint axes, closest
 // points, gradients: ~3x the registers).  The general pass decides penetration exactly as before, so the screening changes no
 // result -- it only has to be a superset, which the 1e-3 widening of the thresholds makes it.
-template <class RB>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RB::D <= 8 ? 4 : 1, RB::D <= 8 ? 4 : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
+// OCC4: held to 128 VGPRs (the rare gradient path spills ~23 registers to scratch) so that all four wavefronts per SIMD of a
+// 262 144-row launch are resident.  Small launches use the unconstrained build: a lone wavefront pays a memory round trip per
+// scratch access (one trajectory x 256 waypoints: 68 -> 66.6 us Panda, 95.7 -> 91.3 Fetch) and a scratch-using launch
+// dispatches more slowly.
+template <class RB, bool OCC4 = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4 : 1, OCC4 ? 4 : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ target,
                                                              const float* __restrict__ xv, float* __restrict__ blocks) {
