@@ -185,6 +185,7 @@ int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to thi
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
 int g_occ4_min_rows = 131072;  // fused masks-only fp32 launch: the 128-VGPR instantiation from this many rows up (see kernels_fused.h)
 bool g_rows_pose = false;      // coupled step WITH the pose block through the row-per-lane kernels too (cppf_debug_set_rows_pose)
+bool g_pcr_split = true;       // ... and two half-workgroups per waypoint (cppf_debug_set_pcr_lds(2) / (1) toggles it)
 bool g_pcr_lds = true;         // coupled step, parallel-in-time form, W <= 256: the state in LDS instead of the workspace (cppf_debug_set_pcr_lds)
 bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
                                // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
@@ -466,7 +467,7 @@ void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
 
 void cppf_debug_set_occ_min_rows(int n) { g_occ4_min_rows = n < 0 ? 131072 : n; }
 
-void cppf_debug_set_pcr_lds(int on) { g_pcr_lds = on != 0; }
+void cppf_debug_set_pcr_lds(int on) { g_pcr_lds = on != 0, g_pcr_split = on != 1; }
 
 void cppf_debug_set_rows_pose(int on) { g_rows_pose = on != 0; }
 
@@ -947,6 +948,12 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
             constexpr size_t kState = 256 * (size_t)((DD * (DD + 1) / 2 + DD + DD * DD) | 1) * sizeof(float);           \
             CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_solve_pcr_kernel<DD, 256, true>),         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kState));                    \
+            if (g_pcr_split && DD <= 7) { /* measured: -6 % at d = 7, +9 % at d = 8 (register pressure) */              \
+                CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_solve_pcr_kernel<DD, 512, true, true>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kState));                \
+                hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 512, true, true>), dim3((unsigned)S), dim3(512), kState, st, \
+                                   robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, x_out);              \
+            } else                                                                                                     \
             hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 256, true>), dim3((unsigned)S), dim3(256), kState, st,        \
                                robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, x_out);                  \
         } else if (W <= 256)                                                                                           \

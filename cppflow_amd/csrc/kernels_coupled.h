@@ -967,14 +967,22 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
 // kLds (T <= 256): the state (D_t | y_t | L_t per waypoint, 84 floats at d = 7) lives in LDS for the whole launch instead of the
 // caller's workspace -- a level's neighbour reads are LDS reads instead of L2 round trips behind a barrier, which was half of a
 // level's time (86 KB of dynamic LDS at d = 7, 110 KB at d = 8: one workgroup per compute unit).
-template <int D, int BS, bool kLds = false>
+// kSplit (with kLds, BS = 512, T <= 256): TWO wavefront-uniform halves of the workgroup per waypoint -- lanes 0..255 do the
+// inverse and the t - s side of a level, lanes 256..511 the t + s side into a zero accumulator, which is added to the state in
+// a second write phase (two more barriers per level; the critical path of a level drops from inverse + both sides to inverse +
+// the longer side).  Same-process A/B (scripts/pcr_ab.py): one trajectory 66.1 -> 61.6 us, 512 trajectories 121 -> 114 us at
+// d = 7; slower at d = 8 (96 -> 105 us at 256 trajectories: register pressure), where the host keeps one lane per waypoint.
+template <int D, int BS, bool kLds = false, bool kSplit = false>
 __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
                                                             const float* __restrict__ xv, float* blocks, float* workL,
                                                             float* __restrict__ x_out) {
     constexpr int NT = D * (D + 1) / 2, SB = NT + D, DD = D * D;
     constexpr int STR = (SB + DD) | 1;  // odd stride: lanes t, t + 1, ... of a wavefront hit distinct banks
     extern __shared__ float pcr_state[];
-    const int s = blockIdx.x, t = threadIdx.x, T = prm.W;
+    static_assert(!kSplit || (kLds && BS == 512), "the split form keeps its state in LDS and runs 512 lanes");
+    constexpr int TW = kSplit ? BS / 2 : BS;  // waypoints per workgroup
+    const int s = blockIdx.x, t = kSplit ? (int)(threadIdx.x & (TW - 1)) : (int)threadIdx.x, T = prm.W;
+    const int h = kSplit ? (int)(threadIdx.x / TW) : 0;  // wavefront-uniform
     const bool act = t < T;
     const size_t base = (size_t)s * T;
     auto st_blk = [&](int u) {
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
     const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
 
     // ---- assemble row t in place: D_t = M_t + (cnt a^2 + [vq] beta^2 + lambda) I,  y_t = m_t + analytic J^T r terms
-    if (act) {
+    if (act && h == 0) {
         const float* blk = blocks + (base + t) * SB;  // the row-parallel kernel's M_t | m_t
         float* dst = st_blk(t);
         const bool has_next = t + 1 < T, has_prev = t > 0;
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
     };
 
     // D_t^-1 is needed by both neighbours of t: every lane inverts its own block once per level and shares it through LDS
-    __shared__ float s_P[BS][NT + 1];  // +1: odd row stride, no bank conflicts on the strided neighbour reads
+    __shared__ float s_P[TW][NT + 1];  // +1: odd row stride, no bank conflicts on the strided neighbour reads
     auto load_inv = [&](int u, float (&M)[D][D]) {
         int k = 0;
 #pragma unroll
@@ -1072,7 +1080,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
     };
     for (int st = 1; st < T; st <<= 1) {
         float nD[D][D], ny[D], nL[D][D];
-        if (act) {
+        if (act && h == 0) {
             float Dn[D][D], P[D][D];
             load_sym(st_blk(t), Dn);
             spd_inverse<D>(Dn, prm.lm_lambda, P);
@@ -1085,14 +1093,24 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         __syncthreads();
         if (act) {
             const float* own = st_blk(t);
-            load_sym(own, nD);
+            if (h == 0) {
+                load_sym(own, nD);
 #pragma unroll
-            for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
+                for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
+            } else {  // the t + s side accumulates from zero
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) nD[i][j] = 0.f;
+#pragma unroll
+                for (int j = 0; j < D; ++j) ny[j] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
                 for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
-            const int tm = t - st, tp = t + st;
+            const bool do_m = !kSplit || h == 0, do_p = !kSplit || h == 1;
+            const int tm = do_m ? t - st : -1, tp = do_p ? t + st : T;
             if (st == 1) {
                 // First level: every coupling block is still the diagonal E = -diag(a^2) the assembly wrote (0 above waypoint
                 // 0), so each matrix product below collapses to a row / column scaling.  The results are bit-identical to the
@@ -1214,7 +1232,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
             }  // st > 1
         }
         __syncthreads();  // every lane has read its neighbours' old state
-        if (act) {
+        if (act && h == 0) {
             float* own = st_blk(t);
             float* Lo = st_L(t);
             int k = 0;
@@ -1230,8 +1248,21 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
                 for (int j = 0; j < D; ++j) Lo[i * D + j] = nL[i][j];
         }
         __syncthreads();
+        if constexpr (kSplit) {
+            if (act && h == 1) {  // add the t + s side
+                float* own = st_blk(t);
+                int k = 0;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = i; j < D; ++j) own[k++] += 0.5f * (nD[i][j] + nD[j][i]);
+#pragma unroll
+                for (int j = 0; j < D; ++j) own[NT + j] += ny[j];
+            }
+            __syncthreads();
+        }
     }
-    if (act) {
+    if (act && h == 0) {
         float Dn[D][D], P[D][D], xr[D];
         const float* own = st_blk(t);
         load_sym(own, Dn);

@@ -172,7 +172,8 @@ void cppf_debug_set_full_rows(int on);
  * up; n < 0 restores the default 131072, a huge n switches it off (process-wide). */
 void cppf_debug_set_occ_min_rows(int n);
 /* Test hook: 0 makes the parallel-in-time elimination of cppf_lm_full_step keep its state in the caller's workspace (as it does
- * for W > 256) instead of LDS (process-wide). */
+ * for W > 256) instead of LDS; 1 = LDS, one lane per waypoint; any other value (the default) = LDS, two half-workgroups per
+ * waypoint (process-wide). */
 void cppf_debug_set_pcr_lds(int on);
 /* Tuning hook: non-zero sends cppf_lm_full_step WITH the pose block (rank-deficient d x d blocks) through the row-per-lane
  * Gauss-Jordan kernels as well instead of the one-lane-per-trajectory Cholesky kernel (process-wide). */

@@ -21,3 +21,4 @@ template __global__ void dev::full_rows_substitute_kernel<7>(const FullK, const 
 template __global__ void dev::full_solve_pcr_kernel<7, 256, true>(const ChainK, const FullK, const float*, const float*, float*, float*, float*);
 template __global__ void dev::full_rows_eliminate_kernel<12>(const FullK, const uint32_t, const float*, float*, float*);
 template __global__ void dev::full_rows_substitute_kernel<12>(const FullK, const uint32_t, const float*, const float*, const float*, const float*, float*);
+template __global__ void dev::full_solve_pcr_kernel<7, 512, true, true>(const ChainK, const FullK, const float*, const float*, float*, float*, float*);

@@ -437,13 +437,18 @@ def test_coupled_step_parallel_in_time_equals_sequential_elimination(robots, nam
         pm = _full_params(use_virtual_configs=False)
         pm.virtual_configs = torch.tensor([])
     pcr = host(rb.lm_full_step(dev(x), dev(target), pm))
-    # the same reduction with its state in the caller's workspace instead of LDS (what W > 256 runs): same arithmetic
-    _hip.lib().cppf_debug_set_pcr_lds(0)
+    # the same reduction with its state in the caller's workspace instead of LDS (what W > 256 runs) and in LDS with one lane
+    # per waypoint: the same arithmetic, bit for bit; the default (two half-workgroups per waypoint, the t + s side accumulated
+    # separately) differs from them by rounding only
     try:
+        _hip.lib().cppf_debug_set_pcr_lds(0)
         pcr_ws = host(rb.lm_full_step(dev(x), dev(target), pm))
-    finally:
         _hip.lib().cppf_debug_set_pcr_lds(1)
-    assert np.array_equal(pcr, pcr_ws)
+        pcr_one = host(rb.lm_full_step(dev(x), dev(target), pm))
+    finally:
+        _hip.lib().cppf_debug_set_pcr_lds(2)
+    assert np.array_equal(pcr_one, pcr_ws)
+    assert np.abs(pcr - pcr_ws).max() < 1e-6 + 1e-4 * np.abs(pcr_ws - x).max()
     _hip.lib().cppf_debug_set_pcr_max_rows(0)
     try:
         seq = host(rb.lm_full_step(dev(x), dev(target), pm))
