@@ -780,7 +780,8 @@ def main():
         return float(t.item())
 
     rows_main = S_main * W
-    G = args.gather_every if args.gather_every > 0 else (32 if rows_main <= 65536 else 8)
+    # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket
+    G = args.gather_every if args.gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
     # a shard of <= 2 wavefronts per SIMD: two launches in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
     n_streams = args.streams if args.streams > 0 else (4 if rows_main <= 131072 else 2)
 
