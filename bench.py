@@ -306,8 +306,7 @@ def parse_args(argv=None):
                     help="untimed launches before the W warm-up steps, to reach sustained clocks (0 disables)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective); "
-                    "0 = 8, or 32 for shards of <= 65 536 rows, whose step is shorter than an eighth of the ~60 us of host time one "
-                    "collective call costs")  # fmt: skip
+                    "0 = 8, 32 for shards of <= 65 536 rows, 64 for <= 32 768: a collective's latency is paid once per G steps")  # fmt: skip
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
                     "fill the chip with two launches in flight)")  # fmt: skip
