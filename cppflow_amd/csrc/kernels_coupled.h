@@ -1,4 +1,4 @@
-// kernels_coupled.h -- the coupled LM step: waypoint-local blocks, distance Jacobians, the three eliminations of the block-tridiagonal system.
+// kernels_coupled.h -- the coupled LM step: waypoint-local blocks, distance Jacobians, the eliminations of the block-tridiagonal system.
 // Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
 #pragma once
 
@@ -13,6 +13,12 @@
 //   full_solve_kernel   (one lane per seed): adds the analytic differencing / virtual-config / lambda terms and runs the
 //                        block-tridiagonal elimination D'_t = A_tt - E G_{t-1} E,  G_t = D'_t^-1  (E = -diag(a^2)) forward and
 //                        back -- O(T d^3) per trajectory, any number of trajectories at once (the reference: one, :128).
+//                        Used when the pose block is on (rank-deficient blocks: Cholesky with floored pivots).
+//   full_rows_eliminate_kernel + full_rows_substitute_kernel  (8 or 16 lanes per trajectory, one block row per lane, DPP
+//                        Gauss-Jordan, both ends of the path at once): the default beyond ~512 trajectories x 256 waypoints.
+//   full_solve_pcr_kernel (one workgroup per trajectory, parallel cyclic reduction over the waypoints, state in LDS for
+//                        W <= 256): the default up to there -- the reference's cadence is ONE trajectory.
+//   full_solve_wave_kernel (one wavefront per trajectory, round 1's form): kept as a cross-check behind a test hook.
 
 struct FullK {
     float lm_lambda, a_pos, a_rot, a_diff, a_diff_pris, a_vq, a_self, a_env;
