@@ -105,15 +105,29 @@ float sqrt_threshold(float r) {
     return y;
 }
 
-// broad-phase thresholds (see cull_far): (reach + 1 cm)^2 (1 + 1e-4), rounded up to fp32
-double cap_half_length(const cppf_robot_desc& d, int c) {
-    double s = 0.0;
+// A capsule as the kernels use it: centre c = 0.5 (p0 + p1), half-axis h = 0.5 (p1 - p0), a = |h|^2, 1 / a -- double arithmetic
+// on the fp32 end points of the description, each rounded to fp32 once (a over the ROUNDED h, summed (h0 h0 + h1 h1) + h2 h2).
+// The same lines are in cppflow_amd/gen_robots.py (capsule_centred) and oracle/lmik_oracle.c (orc_robot_create).
+struct CapsuleCentred {
+    float c[3], h[3], a, ia;
+    double half_length;  // sqrt of the unrounded a
+};
+CapsuleCentred capsule_centred(const cppf_robot_desc& d, int cap) {
+    CapsuleCentred r;
     for (int k = 0; k < 3; ++k) {
-        const double v = (double)d.cap_p1[c][k] - (double)d.cap_p0[c][k];
-        s += v * v;
+        r.c[k] = (float)(0.5 * ((double)d.cap_p0[cap][k] + (double)d.cap_p1[cap][k]));
+        r.h[k] = (float)(0.5 * ((double)d.cap_p1[cap][k] - (double)d.cap_p0[cap][k]));
     }
-    return 0.5 * std::sqrt(s);
+    const double h0 = r.h[0], h1 = r.h[1], h2 = r.h[2];
+    const double a = (h0 * h0 + h1 * h1) + h2 * h2;
+    r.a = (float)a;
+    r.ia = (float)(1.0 / a);
+    r.half_length = std::sqrt(a);
+    return r;
 }
+
+// broad-phase thresholds (see cull_far): (reach + 1 cm)^2 (1 + 1e-4), rounded up to fp32
+double cap_half_length(const cppf_robot_desc& d, int c) { return capsule_centred(d, c).half_length; }
 
 float cull_threshold(double reach) {
     const double y = (reach + 0.01) * (reach + 0.01) * (1.0 + 1e-4);
@@ -329,14 +343,17 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     co.ncaps = desc->n_capsules;
     co.npairs = desc->n_pairs;
     for (int c = 0; c < co.ncaps; ++c) {
+        const CapsuleCentred cc = capsule_centred(*desc, c);
         for (int k = 0; k < 3; ++k) {
-            co.cap_p0[c][k] = desc->cap_p0[c][k];
-            co.cap_p1[c][k] = desc->cap_p1[c][k];
+            co.cap_c[c][k] = cc.c[k];
+            co.cap_h[c][k] = cc.h[k];
         }
+        co.cap_a[c] = cc.a;
+        co.cap_ia[c] = cc.ia;
         co.cap_r[c] = desc->cap_r[c];
         co.cap_link[c] = (int8_t)desc->cap_link[c];
         co.cap_thr[c] = sqrt_threshold(desc->cap_r[c]);
-        co.cap_cull4[c] = 4.f * cull_threshold(cap_half_length(*desc, c) + (double)desc->cap_r[c]);
+        co.cap_cull[c] = cull_threshold(cap_half_length(*desc, c) + (double)desc->cap_r[c]);
     }
     // cap_begin[l+1] = first capsule whose link >= l
     for (int l = -1; l <= d; ++l) {
@@ -350,7 +367,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
         co.pair_b[p] = (uint8_t)desc->pairs[p][1];
         co.pair_thr[p] = sqrt_threshold(desc->cap_r[desc->pairs[p][0]] + desc->cap_r[desc->pairs[p][1]]);
         const int a = desc->pairs[p][0], b = desc->pairs[p][1];
-        co.pair_cull4[p] = 4.f * cull_threshold(cap_half_length(*desc, a) + cap_half_length(*desc, b) + (double)desc->cap_r[a] +
+        co.pair_cull[p] = cull_threshold(cap_half_length(*desc, a) + cap_half_length(*desc, b) + (double)desc->cap_r[a] +
                                          (double)desc->cap_r[b]);
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
@@ -361,11 +378,11 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     if (device != kNoDevice) {
         std::vector<uint4> host(CPPF_MAX_PAIRS + CPPF_MAX_CAPSULES, uint4{0, 0, 0, 0});
         for (int p = 0; p < co.npairs; ++p) {
-            QuadPairRec r{co.pair_a[p], co.pair_b[p], co.pair_thr[p], co.pair_cull4[p]};
+            QuadPairRec r{co.pair_a[p], co.pair_b[p], co.pair_thr[p], co.pair_cull[p]};
             std::memcpy(&host[p], &r, sizeof r);
         }
         for (int c = 0; c < co.ncaps; ++c) {
-            QuadCapRec r{co.cap_thr[c], co.cap_cull4[c], co.cap_r[c], 0.f};
+            QuadCapRec r{co.cap_thr[c], co.cap_cull[c], co.cap_a[c], co.cap_ia[c]};
             std::memcpy(&host[CPPF_MAX_PAIRS + c], &r, sizeof r);
         }
         DeviceGuard guard(device);
@@ -486,8 +503,6 @@ int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const
             CPPF_REQUIRE(cuboids[o * 6 + k] <= cuboids[o * 6 + 3 + k], "cuboid min corner > max corner");
             robot->coll.obs_lo[o][k] = R[9 + k] + cuboids[o * 6 + k];
             robot->coll.obs_hi[o][k] = R[9 + k] + cuboids[o * 6 + 3 + k];
-            robot->coll.obs_lo2[o][k] = 2.f * robot->coll.obs_lo[o][k];
-            robot->coll.obs_hi2[o][k] = 2.f * robot->coll.obs_hi[o][k];
         }
     }
     robot->coll.nobs = n_obs;

@@ -3,8 +3,9 @@
 #pragma once
 
 // ---- collision stage --------------------------------------------------------------------------------------------------------
-// Capsule end points are wave-private scratch indexed by a wave-uniform but run-time capsule id, which registers cannot
-// do without spilling; they go to LDS as [capsule*6 + k][lane] so that a wave's 64 lanes hit 64 consecutive banks.
+// A capsule in the world is (centre c, half-axis h).  In the generic kernels those are wave-private scratch indexed by a
+// wave-uniform but run-time capsule id, which registers cannot do without spilling; they go to LDS as [capsule*6 + k][lane]
+// (k = 0..2 the centre, 3..5 the half-axis) so that a wave's 64 lanes hit 64 consecutive banks.
 struct CollOut {
     float min_self, min_env;
     int self_hit, env_hit;
@@ -13,8 +14,8 @@ struct CollOut {
 // ---- broad phase (mask-only launches) -----------------------------------------------------------------------------------------
 // A capsule's segment lies in the ball of radius h (half its length, a constant of the rigid link) about its mid point m,
 // so  dist(seg_a, seg_b) >= |m_a - m_b| - h_a - h_b  and  dist(seg_c, box) >= dist(m_c, box) - h_c.  A pair is skipped when
-// EVERY active lane of the wavefront has   |m_a - m_b|^2 > (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4)   (tabulated, rounded up;
-// evaluated on doubled mid points against 4 x the threshold, which is the same comparison bit for bit).
+// EVERY active lane of the wavefront has   |m_a - m_b|^2 > (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4)   (tabulated, rounded up).
+// The mid point IS the capsule's centre, and m_a - m_b is the first thing the exact test needs as well.
 // The exact functions return the squared distance between two points ON the segments / box (whatever parameters the
 // fp32 arithmetic lands on), which is >= the true squared distance up to the ~1e-6 relative rounding of the final
 // difference and dot product; with the 1 cm margin the skipped test could only have said "no hit", so the masks are
@@ -43,8 +44,8 @@ __device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co
     for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
-            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_c[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_h[c][k];
         }
     }
 #pragma unroll
@@ -52,27 +53,27 @@ __device__ __forceinline__ void fk_capsules_to_lds(const RB& rb, const CollK& co
         fk_fixed_joint(rb, j, R, p);
         fk_joint(R, p, rb.pris(j), q[j]);
         for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
-            float w0[3], w1[3];
-            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
-            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+            float wc[3], wh[3];
+            xform_point(R, p, co.cap_c[c][0], co.cap_c[c][1], co.cap_c[c][2], wc);
+            xform_dir(R, co.cap_h[c][0], co.cap_h[c][1], co.cap_h[c][2], wh);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                lds[(c * 6 + k) * kBlock + tid] = w0[k];
-                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+                lds[(c * 6 + k) * kBlock + tid] = wc[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = wh[k];
             }
         }
     }
 }
 
-// Robot-specialised variant: capsule ids, link ids and the pair list are compile-time, so the end points live in VGPRs
+// Robot-specialised variant: capsule ids, link ids and the pair list are compile-time, so centres and half-axes live in VGPRs
 // (static indices after unrolling) and no LDS is touched.  Same canonical operation order as the LDS variant.  Two phases so
 // that a caller can retire everything else it holds (target pose, q, the frame) between them: the pair / cuboid tests then
-// run with the capsule end points as the only long-lived registers, which keeps the fused kernel at <= 128 VGPRs, i.e. all
+// run with the capsules as the only long-lived registers, which keeps the fused kernel at <= 128 VGPRs, i.e. all
 // four wavefronts per SIMD of a 262 144-row launch resident at once (no half-empty second round).
 template <class RB>
 __device__ __forceinline__ void capsule_fk_static(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
-                                                  float (&w0)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
-                                                  float (&w1)[(RB::Table::L > 0 ? RB::Table::L : 1)][3]) {
+                                                  float (&wc)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                  float (&wh)[(RB::Table::L > 0 ? RB::Table::L : 1)][3]) {
     using T = typename RB::Table;
     frame_identity(R, p);
 #pragma unroll
@@ -80,8 +81,8 @@ __device__ __forceinline__ void capsule_fk_static(const RB& rb, const float (&q)
         if (T::cap_link[c] < 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                w0[c][k] = T::cap_p0[c][k];
-                w1[c][k] = T::cap_p1[c][k];
+                wc[c][k] = T::cap_c[c][k];
+                wh[c][k] = T::cap_h[c][k];
             }
         }
     }
@@ -92,30 +93,32 @@ __device__ __forceinline__ void capsule_fk_static(const RB& rb, const float (&q)
 #pragma unroll
         for (int c = 0; c < T::L; ++c) {
             if (T::cap_link[c] == j) {
-                xform_point(R, p, T::cap_p0[c][0], T::cap_p0[c][1], T::cap_p0[c][2], w0[c]);
-                xform_point(R, p, T::cap_p1[c][0], T::cap_p1[c][1], T::cap_p1[c][2], w1[c]);
+                xform_point(R, p, T::cap_c[c][0], T::cap_c[c][1], T::cap_c[c][2], wc[c]);
+                xform_dir(R, T::cap_h[c][0], T::cap_h[c][1], T::cap_h[c][2], wh[c]);
             }
         }
     }
 }
 
-// twice the capsule's mid point: the broad phase works on doubled coordinates (|s_a - s_b|^2 against 4 x the tabulated
-// threshold, the cuboid corners doubled by the host) -- exactly the same comparison as on the mid points themselves (scaling
-// by powers of two is exact), without the three multiplies per capsule
-__device__ __forceinline__ void capsule_mid(const float (&a0)[3], const float (&a1)[3], float (&m)[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) m[k] = a0[k] + a1[k];
+// Which of the cuboids can a capsule reach at all?  Bit o set: SOME lane of the wavefront is within the broad-phase reach of
+// cuboid o (wave-uniform).  Evaluated per capsule BEFORE anything of the exact test: the three reciprocals of the half-axis
+// the exact test needs do not depend on the cuboid, and a compiler that sees them inside a loop over cuboids hoists them in
+// front of it -- i.e. computes them for every capsule of every row whether or not a single test survives the broad phase.
+__device__ __forceinline__ uint32_t cuboids_in_reach(const CollK& co, const float (&c)[3], float cull2) {
+    uint32_t near = 0u;
+    for (int o = 0; o < co.nobs; ++o)
+        if (!cull_far(point_box_dist2(c, co.obs_lo[o], co.obs_hi[o]), cull2)) near |= 1u << o;
+    return near;
 }
 
 template <class RB, bool WANT_MIN>
 __device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
-                                                        const float (&w0)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
-                                                        const float (&w1)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                        const float (&wc)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
+                                                        const float (&wh)[(RB::Table::L > 0 ? RB::Table::L : 1)][3],
                                                         bool do_self, bool do_env) {
     using T = typename RB::Table;
     // Broad phase of the mask-only launches (see cull_far): one bounding-sphere test per pair / per (capsule, cuboid) on
-    // the capsule mid points (recomputed per test: 6 adds are cheaper than 27 more live registers); the exact distance is
-    // evaluated only when some lane of the wavefront is within reach.
+    // the capsule centres; the exact distance is evaluated only when some lane of the wavefront is within reach.
     CollOut r;
     r.min_self = INFINITY;
     r.self_hit = 0;
@@ -124,12 +127,9 @@ __device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
         for (int pi = 0; pi < T::P; ++pi) {
             const int a = T::pair_a[pi], b = T::pair_b[pi];
             if constexpr (!WANT_MIN) {
-                float ma[3], mb[3];
-                capsule_mid(w0[a], w1[a], ma);
-                capsule_mid(w0[b], w1[b], mb);
-                if (cull_far(mid_dist2(ma, mb), 4.f * T::pair_cull[pi])) continue;
+                if (cull_far(mid_dist2(wc[a], wc[b]), T::pair_cull[pi])) continue;
             }
-            const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
+            const float d2 = seg_seg_dist2(wc[a], wh[a], wc[b], wh[b], T::cap_a[a], T::cap_ia[a], T::cap_a[b], T::cap_ia[b]);
             if constexpr (WANT_MIN) {
                 const float v = __builtin_sqrtf(d2) - (T::cap_r[a] + T::cap_r[b]);
                 r.min_self = v < r.min_self ? v : r.min_self;
@@ -139,40 +139,39 @@ __device__ __forceinline__ CollOut collide_tests_static(const CollK& co,
         }
     }
     if constexpr (WANT_MIN) r.self_hit = r.min_self < 0.f;
+    // env: min over capsules per cuboid, "< 0", OR over cuboids (collision_detection.py:39-43) == any (capsule, cuboid) < 0,
+    // and the minimum over all of them -- so the loops may nest capsule-outer
     r.min_env = INFINITY;
     r.env_hit = 0;
     if (do_env) {
-        for (int o = 0; o < co.nobs; ++o) {
-            float me = INFINITY;
 #pragma unroll
-            for (int c = 0; c < T::L; ++c) {
-                if constexpr (!WANT_MIN) {
-                    float m[3];
-                    capsule_mid(w0[c], w1[c], m);
-                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), 4.f * T::cap_cull[c])) continue;
-                }
-                const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
+        for (int c = 0; c < T::L; ++c) {
+            uint32_t near = ~0u;
+            if constexpr (!WANT_MIN) {
+                near = cuboids_in_reach(co, wc[c], T::cap_cull[c]);
+                if (near == 0u) continue;
+            }
+            for (int o = 0; o < co.nobs; ++o) {
+                if (!((near >> o) & 1u)) continue;
+                const float d2 = seg_box_dist2(wc[c], wh[c], co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
                     const float v = __builtin_sqrtf(d2) - T::cap_r[c];
-                    me = v < me ? v : me;
+                    r.min_env = v < r.min_env ? v : r.min_env;
                 } else {
                     r.env_hit |= d2 < T::cap_thr[c];
                 }
             }
-            if constexpr (WANT_MIN) {
-                r.env_hit |= (me < 0.f);
-                r.min_env = me < r.min_env ? me : r.min_env;
-            }
         }
+        if constexpr (WANT_MIN) r.env_hit = r.min_env < 0.f;
     }
     return r;
 }
 
-__device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int tid, int c, float (&w0)[3], float (&w1)[3]) {
+__device__ __forceinline__ void lds_capsule(const float* __restrict__ lds, int tid, int c, float (&wc)[3], float (&wh)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        w0[k] = lds[(c * 6 + k) * kBlock + tid];
-        w1[k] = lds[(c * 6 + 3 + k) * kBlock + tid];
+        wc[k] = lds[(c * 6 + k) * kBlock + tid];
+        wh[k] = lds[(c * 6 + 3 + k) * kBlock + tid];
     }
 }
 
@@ -188,16 +187,13 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
     if (do_self) {
         for (int pi = 0; pi < co.npairs; ++pi) {
             const int a = co.pair_a[pi], b = co.pair_b[pi];
-            float a0[3], a1[3], b0[3], b1[3];
-            lds_capsule(lds, tid, a, a0, a1);
-            lds_capsule(lds, tid, b, b0, b1);
+            float ca[3], ha[3], cb[3], hb[3];
+            lds_capsule(lds, tid, a, ca, ha);
+            lds_capsule(lds, tid, b, cb, hb);
             if constexpr (!WANT_MIN) {
-                float ma[3], mb[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) ma[k] = a0[k] + a1[k], mb[k] = b0[k] + b1[k];  // doubled mid points
-                if (cull_far(mid_dist2(ma, mb), co.pair_cull4[pi])) continue;
+                if (cull_far(mid_dist2(ca, cb), co.pair_cull[pi])) continue;
             }
-            const float d2 = seg_seg_dist2(a0, a1, b0, b1);
+            const float d2 = seg_seg_dist2(ca, ha, cb, hb, co.cap_a[a], co.cap_ia[a], co.cap_a[b], co.cap_ia[b]);
             if constexpr (WANT_MIN) {
                 const float v = __builtin_sqrtf(d2) - (co.cap_r[a] + co.cap_r[b]);
                 r.min_self = v < r.min_self ? v : r.min_self;
@@ -210,30 +206,26 @@ __device__ __forceinline__ CollOut collide_from_lds(const CollK& co, const float
     r.min_env = INFINITY;
     r.env_hit = 0;
     if (do_env) {
-        for (int o = 0; o < co.nobs; ++o) {
-            float me = INFINITY;
-            for (int c = 0; c < co.ncaps; ++c) {
-                float w0[3], w1[3];
-                lds_capsule(lds, tid, c, w0, w1);
-                if constexpr (!WANT_MIN) {
-                    float m[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) m[k] = w0[k] + w1[k];  // doubled mid point
-                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), co.cap_cull4[c])) continue;
-                }
-                const float d2 = seg_box_dist2(w0, w1, co.obs_lo[o], co.obs_hi[o]);
+        for (int c = 0; c < co.ncaps; ++c) {
+            float wc[3], wh[3];
+            lds_capsule(lds, tid, c, wc, wh);
+            uint32_t near = ~0u;
+            if constexpr (!WANT_MIN) {
+                near = cuboids_in_reach(co, wc, co.cap_cull[c]);
+                if (near == 0u) continue;
+            }
+            for (int o = 0; o < co.nobs; ++o) {
+                if (!((near >> o) & 1u)) continue;
+                const float d2 = seg_box_dist2(wc, wh, co.obs_lo[o], co.obs_hi[o]);
                 if constexpr (WANT_MIN) {
                     const float v = __builtin_sqrtf(d2) - co.cap_r[c];
-                    me = v < me ? v : me;
+                    r.min_env = v < r.min_env ? v : r.min_env;
                 } else {
                     r.env_hit |= d2 < co.cap_thr[c];
                 }
             }
-            if constexpr (WANT_MIN) {
-                r.env_hit |= (me < 0.f);  // collision_detection.py:39-43
-                r.min_env = me < r.min_env ? me : r.min_env;
-            }
         }
+        if constexpr (WANT_MIN) r.env_hit = r.min_env < 0.f;  // collision_detection.py:39-43 (an OR over cuboids of min < 0)
     }
     return r;
 }
@@ -244,9 +236,9 @@ __device__ __forceinline__ CollOut collide_row(const RB& rb, const CollK& co, co
                                                float (&R)[9], float (&p)[3], bool do_self, bool do_env) {
     if constexpr (RB::kStatic) {
         constexpr int L = RB::Table::L > 0 ? RB::Table::L : 1;
-        float w0[L][3], w1[L][3];
-        capsule_fk_static<RB>(rb, q, R, p, w0, w1);
-        return collide_tests_static<RB, WANT_MIN>(co, w0, w1, do_self, do_env);
+        float wc[L][3], wh[L][3];
+        capsule_fk_static<RB>(rb, q, R, p, wc, wh);
+        return collide_tests_static<RB, WANT_MIN>(co, wc, wh, do_self, do_env);
     } else {
         fk_capsules_to_lds<RB>(rb, co, q, lds, tid, R, p);
         return collide_from_lds<WANT_MIN>(co, lds, tid, do_self, do_env);

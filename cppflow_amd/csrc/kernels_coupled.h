@@ -85,8 +85,8 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
     for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
-            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_c[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_h[c][k];
         }
     }
 #pragma unroll
@@ -99,13 +99,13 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
         }
         fk_joint(R, p, rb.pris(j), q[j]);
         for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
-            float w0[3], w1[3];
-            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
-            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+            float wc[3], wh[3];
+            xform_point(R, p, co.cap_c[c][0], co.cap_c[c][1], co.cap_c[c][2], wc);
+            xform_dir(R, co.cap_h[c][0], co.cap_h[c][1], co.cap_h[c][2], wh);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                lds[(c * 6 + k) * kBlock + tid] = w0[k];
-                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+                lds[(c * 6 + k) * kBlock + tid] = wc[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = wh[k];
             }
         }
     }
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
         for (int j = 0; j < D; ++j) g[j] = 0.f;
         if constexpr (ENV) {
             const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
-            float w0[3], w1[3], cs[3], cb[3];
-            lds_capsule(lds, tid, e, w0, w1);
-            sd = seg_box_closest(w0, w1, lo, hi, cs, cb);
+            float wc[3], wh[3], cs[3], cb[3];
+            lds_capsule(lds, tid, e, wc, wh);
+            sd = seg_box_closest(wc, wh, lo, hi, cs, cb);
             radius = co.cap_r[e];
             if (sd > 0.f) {
 #pragma unroll
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
             point_grad<RB>(rb, co.cap_link[e], nrm, cs, ax, og, 1.f, g);
         } else {
             const int a = co.pair_a[e], b = co.pair_b[e];
-            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
-            lds_capsule(lds, tid, a, a0, a1);
-            lds_capsule(lds, tid, b, b0, b1);
-            sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            float ca[3], ha[3], cb2[3], hb[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, ca, ha);
+            lds_capsule(lds, tid, b, cb2, hb);
+            sd = seg_seg_closest(ca, ha, cb2, hb, co.cap_a[a], co.cap_ia[a], co.cap_a[b], co.cap_ia[b], c1, c2);
             radius = co.cap_r[a] + co.cap_r[b];
             if (sd > 0.f) {
 #pragma unroll
@@ -212,28 +212,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
         const bool env_bits = prm.use_env && co.nobs * T::L <= 64;
         if (env_bits || !prm.use_env) near_env = 0ull;
         if (prm.use_self || env_bits) {
-            float R[9], p[3], w0[L][3], w1[L][3];
-            capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+            float R[9], p[3], wc[L][3], wh[L][3];
+            capsule_fk_static<RB>(rb, q, R, p, wc, wh);
             if (prm.use_self) {
 #pragma unroll
                 for (int pi = 0; pi < T::P; ++pi) {
                     const int a = T::pair_a[pi], b = T::pair_b[pi];
-                    float ma[3], mb[3];
-                    capsule_mid(w0[a], w1[a], ma);
-                    capsule_mid(w0[b], w1[b], mb);
-                    if (cull_far(mid_dist2(ma, mb), 4.f * T::pair_cull[pi])) continue;
-                    const float d2 = seg_seg_dist2(w0[a], w1[a], w0[b], w1[b]);
+                    if (cull_far(mid_dist2(wc[a], wc[b]), T::pair_cull[pi])) continue;
+                    const float d2 = seg_seg_dist2(wc[a], wh[a], wc[b], wh[b], T::cap_a[a], T::cap_ia[a], T::cap_a[b], T::cap_ia[b]);
                     if (__builtin_amdgcn_ballot_w64(d2 < 1.001f * T::pair_thr[pi] + 1e-12f)) near_self |= 1ull << pi;
                 }
             }
             if (env_bits) {
-                for (int o = 0; o < co.nobs; ++o) {
 #pragma unroll
-                    for (int c = 0; c < T::L; ++c) {
-                        float mm[3];
-                        capsule_mid(w0[c], w1[c], mm);
-                        if (cull_far(point_box_dist2(mm, co.obs_lo2[o], co.obs_hi2[o]), 4.f * T::cap_cull[c])) continue;
-                        const float d2 = seg_box_dist2(w0[c], w1[c], co.obs_lo[o], co.obs_hi[o]);
+                for (int c = 0; c < T::L; ++c) {
+                    const uint32_t reach = cuboids_in_reach(co, wc[c], T::cap_cull[c]);
+                    if (reach == 0u) continue;
+                    for (int o = 0; o < co.nobs; ++o) {
+                        if (!((reach >> o) & 1u)) continue;
+                        const float d2 = seg_box_dist2(wc[c], wh[c], co.obs_lo[o], co.obs_hi[o]);
                         if (__builtin_amdgcn_ballot_w64(d2 < 1.001f * T::cap_thr[c] + 1e-12f)) near_env |= 1ull << (o * T::L + c);
                     }
                 }
@@ -260,8 +257,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
     for (int c = co.cap_begin[0]; c < co.cap_begin[1]; ++c) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            lds[(c * 6 + k) * kBlock + tid] = co.cap_p0[c][k];
-            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_p1[c][k];
+            lds[(c * 6 + k) * kBlock + tid] = co.cap_c[c][k];
+            lds[(c * 6 + 3 + k) * kBlock + tid] = co.cap_h[c][k];
         }
     }
 #pragma unroll
@@ -274,13 +271,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
         }
         fk_joint(R, p, rb.pris(j), q[j]);
         for (int c = co.cap_begin[j + 1]; c < co.cap_begin[j + 2]; ++c) {
-            float w0[3], w1[3];
-            xform_point(R, p, co.cap_p0[c][0], co.cap_p0[c][1], co.cap_p0[c][2], w0);
-            xform_point(R, p, co.cap_p1[c][0], co.cap_p1[c][1], co.cap_p1[c][2], w1);
+            float wc[3], wh[3];
+            xform_point(R, p, co.cap_c[c][0], co.cap_c[c][1], co.cap_c[c][2], wc);
+            xform_dir(R, co.cap_h[c][0], co.cap_h[c][1], co.cap_h[c][2], wh);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                lds[(c * 6 + k) * kBlock + tid] = w0[k];
-                lds[(c * 6 + 3 + k) * kBlock + tid] = w1[k];
+                lds[(c * 6 + k) * kBlock + tid] = wc[k];
+                lds[(c * 6 + 3 + k) * kBlock + tid] = wh[k];
             }
         }
     }
@@ -309,16 +306,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
         for (int pi = 0; pi < co.npairs; ++pi) {
             if (!((near_self >> (pi & 63)) & 1ull)) continue;  // screened out above (specialised robots; else all ones)
             const int a = co.pair_a[pi], b = co.pair_b[pi];
-            float a0[3], a1[3], b0[3], b1[3], c1[3], c2[3];
-            lds_capsule(lds, tid, a, a0, a1);
-            lds_capsule(lds, tid, b, b0, b1);
-            {  // broad phase (cull_far): only pairs that penetrate contribute rows, and a far pair cannot penetrate
-                float ma[3], mb[3];
-                capsule_mid(a0, a1, ma);
-                capsule_mid(b0, b1, mb);
-                if (cull_far(mid_dist2(ma, mb), co.pair_cull4[pi])) continue;
-            }
-            const float sd = seg_seg_closest(a0, a1, b0, b1, c1, c2);
+            float ca[3], ha[3], cb2[3], hb[3], c1[3], c2[3];
+            lds_capsule(lds, tid, a, ca, ha);
+            lds_capsule(lds, tid, b, cb2, hb);
+            // broad phase (cull_far): only pairs that penetrate contribute rows, and a far pair cannot penetrate
+            if (cull_far(mid_dist2(ca, cb2), co.pair_cull[pi])) continue;
+            const float sd = seg_seg_closest(ca, ha, cb2, hb, co.cap_a[a], co.cap_ia[a], co.cap_a[b], co.cap_ia[b], c1, c2);
             const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
             if (dist < 0.f) {
                 float nrm[3] = {0.f, 0.f, 0.f}, g[D];
@@ -339,14 +332,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
         for (int o = 0; o < co.nobs; ++o)
             for (int c = 0; c < co.ncaps; ++c) {
                 if (!((near_env >> ((o * co.ncaps + c) & 63)) & 1ull)) continue;
-                float w0[3], w1[3], cs[3], cb[3];
-                lds_capsule(lds, tid, c, w0, w1);
-                {
-                    float m[3];
-                    capsule_mid(w0, w1, m);
-                    if (cull_far(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]), co.cap_cull4[c])) continue;
-                }
-                const float sd = seg_box_closest(w0, w1, co.obs_lo[o], co.obs_hi[o], cs, cb);
+                float wc[3], wh[3], cs[3], cb[3];
+                lds_capsule(lds, tid, c, wc, wh);
+                if (cull_far(point_box_dist2(wc, co.obs_lo[o], co.obs_hi[o]), co.cap_cull[c])) continue;
+                const float sd = seg_box_closest(wc, wh, co.obs_lo[o], co.obs_hi[o], cs, cb);
                 const float dist = sd - co.cap_r[c];
                 if (dist < 0.f) {
                     float nrm[3] = {0.f, 0.f, 0.f}, g[D];

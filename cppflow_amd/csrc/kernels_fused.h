@@ -184,13 +184,13 @@ __device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, con
         };
         if constexpr (RB::kStatic) {
             constexpr int L = RB::Table::L > 0 ? RB::Table::L : 1;
-            float w0[L][3], w1[L][3];
+            float wc[L][3], wh[L][3];
             {
                 float R[9], p[3];
-                capsule_fk_static<RB>(rb, q, R, p, w0, w1);
+                capsule_fk_static<RB>(rb, q, R, p, wc, wh);
                 metrics(R, p);
             }
-            c = collide_tests_static<RB, COLL == 2>(co, w0, w1, do_self, do_env);
+            c = collide_tests_static<RB, COLL == 2>(co, wc, wh, do_self, do_env);
         } else {
             {
                 float R[9], p[3];
@@ -307,17 +307,18 @@ __global__ __launch_bounds__(kBlock) void distances_kernel(const ChainK ch, cons
     if constexpr (ENV) {
         const float lo[3] = {blo0, blo1, blo2}, hi[3] = {bhi0, bhi1, bhi2};
         for (int c = 0; c < co.ncaps; ++c) {
-            float w0[3], w1[3];
-            lds_capsule(lds, tid, c, w0, w1);
-            dists[row * co.ncaps + c] = seg_box_dist(w0, w1, lo, hi) - co.cap_r[c];
+            float wc[3], wh[3];
+            lds_capsule(lds, tid, c, wc, wh);
+            dists[row * co.ncaps + c] = seg_box_dist(wc, wh, lo, hi) - co.cap_r[c];
         }
     } else {
         for (int pi = 0; pi < co.npairs; ++pi) {
             const int a = co.pair_a[pi], b = co.pair_b[pi];
-            float a0[3], a1[3], b0[3], b1[3];
-            lds_capsule(lds, tid, a, a0, a1);
-            lds_capsule(lds, tid, b, b0, b1);
-            dists[row * co.npairs + pi] = seg_seg_dist(a0, a1, b0, b1) - (co.cap_r[a] + co.cap_r[b]);
+            float ca[3], ha[3], cb[3], hb[3];
+            lds_capsule(lds, tid, a, ca, ha);
+            lds_capsule(lds, tid, b, cb, hb);
+            dists[row * co.npairs + pi] =
+                seg_seg_dist(ca, ha, cb, hb, co.cap_a[a], co.cap_ia[a], co.cap_a[b], co.cap_ia[b]) - (co.cap_r[a] + co.cap_r[b]);
         }
     }
 }

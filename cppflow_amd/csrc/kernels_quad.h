@@ -36,10 +36,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // per capsule
 struct QuadPairRec {
     int32_t a, b;
-    float thr, cull4;
+    float thr, cull;
 };
 struct QuadCapRec {
-    float thr, cull4, r, pad;
+    float thr, cull, a, ia;  // sqrt threshold of r, broad-phase threshold, |h|^2, 1 / |h|^2
 };
 
 template <int CTRL>
@@ -383,11 +383,12 @@ __global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, con
         if constexpr (COLL != 0) {
             if (kk < 3) {
                 for (int c = co.cap_begin[link + 1]; c < co.cap_begin[link + 2]; ++c) {
-                    // xform_point's order, row i:  R[i][2] c2 + (R[i][1] c1 + (R[i][0] c0 + p[i]))
-                    const float w0 = CPPF_FMA(f.r[2], co.cap_p0[c][2], CPPF_FMA(f.r[1], co.cap_p0[c][1], CPPF_FMA(f.r[0], co.cap_p0[c][0], f.p)));
-                    const float w1 = CPPF_FMA(f.r[2], co.cap_p1[c][2], CPPF_FMA(f.r[1], co.cap_p1[c][1], CPPF_FMA(f.r[0], co.cap_p1[c][0], f.p)));
-                    mine[c * 8 + kk] = w0;
-                    mine[c * 8 + 4 + kk] = w1;
+                    // xform_point's / xform_dir's order, row i:  R[i][2] c2 + (R[i][1] c1 + (R[i][0] c0 + p[i]))  and
+                    // R[i][2] h2 + (R[i][1] h1 + R[i][0] h0)
+                    const float wc = CPPF_FMA(f.r[2], co.cap_c[c][2], CPPF_FMA(f.r[1], co.cap_c[c][1], CPPF_FMA(f.r[0], co.cap_c[c][0], f.p)));
+                    const float wh = CPPF_FMA(f.r[2], co.cap_h[c][2], CPPF_FMA(f.r[1], co.cap_h[c][1], f.r[0] * co.cap_h[c][0]));
+                    mine[c * 8 + kk] = wc;
+                    mine[c * 8 + 4 + kk] = wh;
                 }
             }
         }
@@ -427,9 +428,9 @@ __global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, con
     }
     if constexpr (COLL != 0) {
         __syncthreads();  // tables and every quad's end points are in LDS
-        auto cap = [&](int c, float (&w0)[3], float (&w1)[3]) {
+        auto cap = [&](int c, float (&wc)[3], float (&wh)[3]) {  // centre, half-axis
             const float4 a = *reinterpret_cast<const float4*>(mine + c * 8), b = *reinterpret_cast<const float4*>(mine + c * 8 + 4);
-            w0[0] = a.x, w0[1] = a.y, w0[2] = a.z, w1[0] = b.x, w1[1] = b.y, w1[2] = b.z;
+            wc[0] = a.x, wc[1] = a.y, wc[2] = a.z, wh[0] = b.x, wh[1] = b.y, wh[2] = b.z;
         };
         int self_hit = 0, env_hit = 0;
         const bool do_self = out.self_mask || out.ext_cost, do_env = out.env_mask || out.ext_cost;
@@ -437,13 +438,14 @@ __global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, con
             for (int p0 = 0; p0 < npairs; p0 += 4) {
                 const int pi = p0 + kk;
                 const QuadPairRec pr = s_pairs[pi < npairs ? pi : npairs - 1];
-                float a0[3], a1[3], b0[3], b1[3], ma[3], mb[3];
-                cap(pr.a, a0, a1);
-                cap(pr.b, b0, b1);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) ma[t] = a0[t] + a1[t], mb[t] = b0[t] + b1[t];  // doubled mid points
-                const bool near = pi < npairs && !(mid_dist2(ma, mb) > pr.cull4);
-                if (near) self_hit |= seg_seg_dist2(a0, a1, b0, b1) < pr.thr;
+                float ca[3], ha[3], cb[3], hb[3];
+                cap(pr.a, ca, ha);
+                cap(pr.b, cb, hb);
+                const bool near = pi < npairs && !(mid_dist2(ca, cb) > pr.cull);
+                if (near) {
+                    const QuadCapRec ra = s_caps[pr.a], rb2 = s_caps[pr.b];
+                    self_hit |= seg_seg_dist2(ca, ha, cb, hb, ra.a, ra.ia, rb2.a, rb2.ia) < pr.thr;
+                }
             }
         }
         if (do_env) {
@@ -452,12 +454,10 @@ __global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, con
                     const int c = c0 + kk;
                     const int cc = c < ncaps ? c : ncaps - 1;
                     const QuadCapRec cr = s_caps[cc];
-                    float w0[3], w1[3], m[3];
-                    cap(cc, w0, w1);
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) m[t] = w0[t] + w1[t];
-                    const bool near = c < ncaps && !(point_box_dist2(m, co.obs_lo2[o], co.obs_hi2[o]) > cr.cull4);
-                    if (near) env_hit |= seg_box_dist2(w0, w1, co.obs_lo[o], co.obs_hi[o]) < cr.thr;
+                    float wc[3], wh[3];
+                    cap(cc, wc, wh);
+                    const bool near = c < ncaps && !(point_box_dist2(wc, co.obs_lo[o], co.obs_hi[o]) > cr.cull);
+                    if (near) env_hit |= seg_box_dist2(wc, wh, co.obs_lo[o], co.obs_hi[o]) < cr.thr;
                 }
             }
         }

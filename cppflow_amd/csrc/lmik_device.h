@@ -36,21 +36,21 @@ struct ChainK {
 };
 
 struct CollK {
-    float cap_p0[CPPF_MAX_CAPSULES][3];
-    float cap_p1[CPPF_MAX_CAPSULES][3];
+    float cap_c[CPPF_MAX_CAPSULES][3];    // link-frame centre  fp32(0.5 (p0 + p1))  and half-axis  fp32(0.5 (p1 - p0))  of each capsule
+    float cap_h[CPPF_MAX_CAPSULES][3];    // (host: double arithmetic on the fp32 end points of the description, rounded once)
+    float cap_a[CPPF_MAX_CAPSULES];       // |h|^2 and 1 / |h|^2 (double arithmetic on the fp32 h, rounded once): a rigid link's
+    float cap_ia[CPPF_MAX_CAPSULES];      // constants -- the segment-segment test never divides by a capsule's length
     float cap_r[CPPF_MAX_CAPSULES];
     int32_t cap_begin[CPPF_MAX_DOF + 2];  // capsules of link l (-1..d-1) are [cap_begin[l+1], cap_begin[l+2])
     int8_t cap_link[CPPF_MAX_CAPSULES];   // moving link of each capsule (-1 = base)
     float pair_thr[CPPF_MAX_PAIRS];       // smallest y with sqrt_rn(y) >= r_a + r_b:  sqrt(d2) - (r_a+r_b) < 0  <=>  d2 < y
     float cap_thr[CPPF_MAX_CAPSULES];     // the same for r alone (capsule vs cuboid)
-    float pair_cull4[CPPF_MAX_PAIRS];     // broad phase: 4 (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4), h = half length (x4: doubled mid points)
-    float cap_cull4[CPPF_MAX_CAPSULES];   // broad phase: 4 (h + r + 1 cm)^2 (1 + 1e-4)
+    float pair_cull[CPPF_MAX_PAIRS];      // broad phase: (h_a + h_b + r_a + r_b + 1 cm)^2 (1 + 1e-4), h = half length
+    float cap_cull[CPPF_MAX_CAPSULES];    // broad phase: (h + r + 1 cm)^2 (1 + 1e-4)
     uint8_t pair_a[CPPF_MAX_PAIRS];
     uint8_t pair_b[CPPF_MAX_PAIRS];
     float obs_lo[CPPF_MAX_OBSTACLES][3];  // world-frame box corners
     float obs_hi[CPPF_MAX_OBSTACLES][3];
-    float obs_lo2[CPPF_MAX_OBSTACLES][3];  // 2 x the corners (broad phase on doubled mid points)
-    float obs_hi2[CPPF_MAX_OBSTACLES][3];
     float jl_lo[CPPF_MAX_DOF];  // padded limits of search.py:46-51
     float jl_hi[CPPF_MAX_DOF];
     int32_t ncaps, npairs, nobs, has_jl;
@@ -254,105 +254,124 @@ __device__ __forceinline__ void quat_to_mat(float w, float x, float y, float z, 
     R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
-// ---- distances (canonical order) ------------------------------------------------------------------------------------------
-// closest distance between two non-degenerate segments (Ericson, Real-Time Collision Detection 5.1.9); also returns the
-// closest points c1 (on P1Q1) and c2 (on P2Q2)
-__device__ __forceinline__ float seg_seg_closest2(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
-                                                  const float (&Q2)[3], float (&c1)[3], float (&c2)[3]) {
-    float d1[3], d2[3], rr[3];
+// ---- reciprocal ------------------------------------------------------------------------------------------------------------
+// RN(1/x), the correctly rounded reciprocal, in 3 VALU instructions instead of the 10 of hipcc's IEEE division: v_rcp_f32 (1 ulp)
+// and ONE Newton step.  That this IS the correctly rounded result for every x with 2^-126 <= |x| < 2^126 -- all 2^32 bit patterns
+// were compared on the MI355X itself (scripts/ubench/rcp_exhaustive.hip; profiles/r3_rcp_exhaustive.txt; the test
+// tests/test_gpu_round3.py::test_fast_reciprocal_is_correctly_rounded repeats it) -- is what lets the CPU oracle spell the same
+// value as a plain `1 / x`.  Below 2^-100 (zero, denormals: v_rcp_f32 does not handle them) the result is DEFINED as 0, which is
+// what every caller wants from a vanishing denominator; beyond 2^126 (nothing geometric) the two sides may differ.
+__device__ __forceinline__ float rcp_newton(float x) {
+    const float y0 = __builtin_amdgcn_rcpf(x);
+    return CPPF_FMA(CPPF_FMA(-x, y0, 1.0f), y0, y0);
+}
+__device__ __forceinline__ float rcp_rn(float x) { return fabsf(x) >= 0x1p-100f ? rcp_newton(x) : 0.f; }
+// for denominators that must be positive: 0 for x < 2^-100 (negative and NaN included)
+__device__ __forceinline__ float rcp_rn_pos(float x) { return x >= 0x1p-100f ? rcp_newton(x) : 0.f; }
+
+__device__ __forceinline__ float clamp11(float v) { return __builtin_amdgcn_fmed3f(v, -1.f, 1.f); }
+
+// world half-axis of a capsule: R * h (no translation); canonical order shared with the oracle
+__device__ __forceinline__ void xform_dir(const float (&R)[9], float h0, float h1, float h2, float (&w)[3]) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        d1[i] = Q1[i] - P1[i];
-        d2[i] = Q2[i] - P2[i];
-        rr[i] = P1[i] - P2[i];
-    }
-    const float a = dot3(d1[0], d1[1], d1[2], d1[0], d1[1], d1[2]);
-    const float e = dot3(d2[0], d2[1], d2[2], d2[0], d2[1], d2[2]);
-    const float f = dot3(d2[0], d2[1], d2[2], rr[0], rr[1], rr[2]);
-    const float c = dot3(d1[0], d1[1], d1[2], rr[0], rr[1], rr[2]);
-    const float b = dot3(d1[0], d1[1], d1[2], d2[0], d2[1], d2[2]);
-    const float denom = CPPF_FMA(a, e, -(b * b));
-    const float inv_a = 1.f / a, inv_e = 1.f / e;  // one IEEE division per capsule: shared by every pair it is in
-    float s = denom > 0.f ? clamp01(CPPF_FMA(b, f, -(c * e)) / denom) : 0.f;
-    float t = CPPF_FMA(b, s, f) * inv_e;
-    // branch-free form of { t < 0: t = 0, s = clamp(-c/a) ; t > 1: t = 1, s = clamp((b-c)/a) } -- lanes of a wave
+    for (int i = 0; i < 3; ++i) w[i] = cfma(R[3 * i + 2], h2, cfma(R[3 * i + 1], h1, cmul(R[3 * i], h0)));
+}
+
+// ---- distances (canonical order) ------------------------------------------------------------------------------------------
+// A capsule's segment is { c + u h : u in [-1, 1] } (centre c, half-axis h; |h|^2 = a and 1 / a are constants of the rigid link).
+// Closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9, re-parametrised to [-1, 1]): minimise
+// | r + s h1 - t h2 |^2, r = c1 - c2.  One reciprocal (of the Gram determinant) per test, no division by a length.
+// Returns the squared distance; c1 / c2 = the closest points (dead code where the caller ignores them).
+__device__ __forceinline__ float seg_seg_closest2(const float (&C1)[3], const float (&H1)[3], const float (&C2)[3],
+                                                  const float (&H2)[3], float a, float ia, float e, float ie,
+                                                  float (&c1)[3], float (&c2)[3]) {
+    float rr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rr[i] = C1[i] - C2[i];
+    const float b = dot3(H1[0], H1[1], H1[2], H2[0], H2[1], H2[2]);
+    const float c = dot3(H1[0], H1[1], H1[2], rr[0], rr[1], rr[2]);
+    const float f = dot3(H2[0], H2[1], H2[2], rr[0], rr[1], rr[2]);
+    const float denom = CPPF_FMA(-b, b, a * e);
+    float s = clamp11(CPPF_FMA(b, f, -(c * e)) * rcp_rn_pos(denom));  // parallel segments (denom < 2^-100): s = 0, the centre
+    float t = CPPF_FMA(b, s, f) * ie;
+    // branch-free form of { t < -1: t = -1, s = clamp((-b - c) / a) ; t > 1: t = 1, s = clamp((b - c) / a) } -- lanes of a wave
     // disagree on these cases all the time, so both candidates are always computed and selected
-    const float s_lo = clamp01(-c * inv_a), s_hi = clamp01((b - c) * inv_a);
-    s = t < 0.f ? s_lo : (t > 1.f ? s_hi : s);
-    t = clamp01(t);
+    const float s_lo = clamp11(-(b + c) * ia), s_hi = clamp11((b - c) * ia);
+    s = t < -1.f ? s_lo : (t > 1.f ? s_hi : s);
+    t = clamp11(t);
     float df[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        c1[i] = CPPF_FMA(d1[i], s, P1[i]);
-        c2[i] = CPPF_FMA(d2[i], t, P2[i]);
-        df[i] = c1[i] - c2[i];
+        df[i] = CPPF_FMA(-t, H2[i], CPPF_FMA(s, H1[i], rr[i]));
+        c1[i] = CPPF_FMA(s, H1[i], C1[i]);
+        c2[i] = CPPF_FMA(t, H2[i], C2[i]);
     }
     return dot3(df[0], df[1], df[2], df[0], df[1], df[2]);
 }
 
 // squared distance (what the mask-only kernels compare against the sqrt thresholds) and the distance itself
-__device__ __forceinline__ float seg_seg_dist2(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
-                                               const float (&Q2)[3]) {
+__device__ __forceinline__ float seg_seg_dist2(const float (&C1)[3], const float (&H1)[3], const float (&C2)[3],
+                                               const float (&H2)[3], float a, float ia, float e, float ie) {
     float c1[3], c2[3];
-    return seg_seg_closest2(P1, Q1, P2, Q2, c1, c2);
+    return seg_seg_closest2(C1, H1, C2, H2, a, ia, e, ie, c1, c2);
 }
 
-__device__ __forceinline__ float seg_seg_closest(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
-                                                 const float (&Q2)[3], float (&c1)[3], float (&c2)[3]) {
-    return __builtin_sqrtf(seg_seg_closest2(P1, Q1, P2, Q2, c1, c2));
+__device__ __forceinline__ float seg_seg_closest(const float (&C1)[3], const float (&H1)[3], const float (&C2)[3],
+                                                 const float (&H2)[3], float a, float ia, float e, float ie,
+                                                 float (&c1)[3], float (&c2)[3]) {
+    return __builtin_sqrtf(seg_seg_closest2(C1, H1, C2, H2, a, ia, e, ie, c1, c2));
 }
 
-__device__ __forceinline__ float seg_seg_dist(const float (&P1)[3], const float (&Q1)[3], const float (&P2)[3],
-                                              const float (&Q2)[3]) {
-    return __builtin_sqrtf(seg_seg_dist2(P1, Q1, P2, Q2));
+__device__ __forceinline__ float seg_seg_dist(const float (&C1)[3], const float (&H1)[3], const float (&C2)[3],
+                                              const float (&H2)[3], float a, float ia, float e, float ie) {
+    return __builtin_sqrtf(seg_seg_dist2(C1, H1, C2, H2, a, ia, e, ie));
 }
 
-// exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 when they intersect): root of the nondecreasing,
-// piecewise-linear half-derivative g of dist^2, bracketed among t = 0, 1 and the six (clamped) face-crossing parameters.
-__device__ __forceinline__ float seg_box_closest2(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+// exact distance from the segment { C + u H } to the axis-aligned box [lo, hi] (0 when they intersect): root of the
+// nondecreasing, piecewise-linear half-derivative g of dist^2, bracketed among u = -1, 1 and the six (clamped) face-crossing
+// parameters.
+__device__ __forceinline__ float seg_box_closest2(const float (&C)[3], const float (&H)[3], const float* __restrict__ lo,
                                                   const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
-    // Along the segment x_i(t) = P0_i + t D_i the excess over the slab [lo_i, hi_i] is D_i (t - clamp(t, a_i, b_i)) with
+    // Along the segment x_i(u) = C_i + u H_i the excess over the slab [lo_i, hi_i] is H_i (u - clamp(u, a_i, b_i)) with
     // [a_i, b_i] the parameter interval in which coordinate i is inside the slab, so the half-derivative of dist^2 is
-    //     g(t) = sum_i w_i (t - clamp(t, a_i, b_i)),   w_i = D_i^2
-    // nondecreasing and piecewise linear with break points a_i, b_i.  (D_i = 0: w_i = 0, the term vanishes.)
-    float D[3], w[3], ta[3], tb[3], cand[8], gv[8];
+    //     g(u) = sum_i w_i (u - clamp(u, a_i, b_i)),   w_i = H_i^2
+    // nondecreasing and piecewise linear with break points a_i, b_i.  (H_i = 0: w_i = 0, the term vanishes.)
+    float w[3], ua[3], ub[3], cand[8], gv[8];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        D[i] = P1[i] - P0[i];
-        const float inv = D[i] != 0.f ? 1.f / D[i] : 0.f;
-        const float t0 = (lo[i] - P0[i]) * inv, t1 = (hi[i] - P0[i]) * inv;
-        ta[i] = fminf(t0, t1);
-        tb[i] = fmaxf(t0, t1);
-        w[i] = D[i] * D[i];
-        cand[2 + 2 * i] = clamp01(ta[i]);
-        cand[3 + 2 * i] = clamp01(tb[i]);
+        const float inv = rcp_rn(H[i]);
+        const float u0 = (lo[i] - C[i]) * inv, u1 = (hi[i] - C[i]) * inv;
+        ua[i] = fminf(u0, u1);
+        ub[i] = fmaxf(u0, u1);
+        w[i] = H[i] * H[i];
+        cand[2 + 2 * i] = clamp11(ua[i]);
+        cand[3 + 2 * i] = clamp11(ub[i]);
     }
-    cand[0] = 0.f;
+    cand[0] = -1.f;
     cand[1] = 1.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float t = cand[k];
-        gv[k] = CPPF_FMA(w[2], t - clampf(t, ta[2], tb[2]),
-                         CPPF_FMA(w[1], t - clampf(t, ta[1], tb[1]), w[0] * (t - clampf(t, ta[0], tb[0]))));
+        const float u = cand[k];
+        gv[k] = CPPF_FMA(w[2], u - clampf(u, ua[2], ub[2]),
+                         CPPF_FMA(w[1], u - clampf(u, ua[1], ub[1]), w[0] * (u - clampf(u, ua[0], ub[0]))));
     }
     // g is monotone, so the bracket of its root is two independent max / min reductions over the candidates:
-    //   tl = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0};  tr = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}
-    float tl = 0.f, gl = gv[0], tr = 1.f, gr = gv[1];
+    //   ul = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0};  ur = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}
+    float ul = -1.f, gl = gv[0], ur = 1.f, gr = gv[1];
 #pragma unroll
     for (int k = 2; k < 8; ++k) {
         const bool neg = gv[k] <= 0.f;
-        tl = fmaxf(tl, neg ? cand[k] : 0.f);
+        ul = fmaxf(ul, neg ? cand[k] : -1.f);
         gl = fmaxf(gl, neg ? gv[k] : gv[0]);
-        tr = fminf(tr, neg ? 1.f : cand[k]);
+        ur = fminf(ur, neg ? 1.f : cand[k]);
         gr = fminf(gr, neg ? gv[1] : gv[k]);
     }
-    const float dg = gr - gl;
-    const float t_in = dg > 0.f ? CPPF_FMA(tr - tl, (-gl) / dg, tl) : tl;
-    const float t = gv[0] >= 0.f ? 0.f : (gv[1] <= 0.f ? 1.f : t_in);
+    const float u_in = CPPF_FMA(ur - ul, (-gl) * rcp_rn_pos(gr - gl), ul);  // a flat bracket (gr - gl < 2^-100): its left end
+    const float u = gv[0] >= 0.f ? -1.f : (gv[1] <= 0.f ? 1.f : u_in);
     float ex[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float x = CPPF_FMA(D[i], t, P0[i]);
+        const float x = CPPF_FMA(H[i], u, C[i]);
         cs[i] = x;
         cb[i] = clampf(x, lo[i], hi[i]);
         ex[i] = x - cb[i];
@@ -360,20 +379,20 @@ __device__ __forceinline__ float seg_box_closest2(const float (&P0)[3], const fl
     return dot3(ex[0], ex[1], ex[2], ex[0], ex[1], ex[2]);
 }
 
-__device__ __forceinline__ float seg_box_dist2(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+__device__ __forceinline__ float seg_box_dist2(const float (&C)[3], const float (&H)[3], const float* __restrict__ lo,
                                                const float* __restrict__ hi) {
     float cs[3], cb[3];
-    return seg_box_closest2(P0, P1, lo, hi, cs, cb);
+    return seg_box_closest2(C, H, lo, hi, cs, cb);
 }
 
-__device__ __forceinline__ float seg_box_closest(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+__device__ __forceinline__ float seg_box_closest(const float (&C)[3], const float (&H)[3], const float* __restrict__ lo,
                                                  const float* __restrict__ hi, float (&cs)[3], float (&cb)[3]) {
-    return __builtin_sqrtf(seg_box_closest2(P0, P1, lo, hi, cs, cb));
+    return __builtin_sqrtf(seg_box_closest2(C, H, lo, hi, cs, cb));
 }
 
-__device__ __forceinline__ float seg_box_dist(const float (&P0)[3], const float (&P1)[3], const float* __restrict__ lo,
+__device__ __forceinline__ float seg_box_dist(const float (&C)[3], const float (&H)[3], const float* __restrict__ lo,
                                               const float* __restrict__ hi) {
-    return __builtin_sqrtf(seg_box_dist2(P0, P1, lo, hi));
+    return __builtin_sqrtf(seg_box_dist2(C, H, lo, hi));
 }
 
 // torch.remainder(dq + pi, 2 pi) - pi   (cppflow/evaluation_utils.py:151-153).  For |dq + pi| < 4 pi -- every difference of

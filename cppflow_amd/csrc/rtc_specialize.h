@@ -137,9 +137,14 @@ std::string rtc_table_source(const cppf_robot& rb) {
     };
     vec3s("cap_p0", d.cap_p0);
     vec3s("cap_p1", d.cap_p1);
-    std::vector<float> cap_r(Lm, 0.f), cap_thr(Lm, 0.f), cap_cull(Lm, 0.f), pair_thr(Pm, 0.f), pair_cull(Pm, 0.f);
-    for (int c = 0; c < L; ++c) cap_r[c] = d.cap_r[c], cap_thr[c] = co.cap_thr[c], cap_cull[c] = 0.25f * co.cap_cull4[c];  // /4: exact
-    for (int p = 0; p < P; ++p) pair_thr[p] = co.pair_thr[p], pair_cull[p] = 0.25f * co.pair_cull4[p];
+    vec3s("cap_c", co.cap_c);
+    vec3s("cap_h", co.cap_h);
+    std::vector<float> cap_r(Lm, 0.f), cap_thr(Lm, 0.f), cap_cull(Lm, 0.f), pair_thr(Pm, 0.f), pair_cull(Pm, 0.f), cap_a(Lm, 0.f), cap_ia(Lm, 0.f);
+    for (int c = 0; c < L; ++c)
+        cap_r[c] = d.cap_r[c], cap_thr[c] = co.cap_thr[c], cap_cull[c] = co.cap_cull[c], cap_a[c] = co.cap_a[c], cap_ia[c] = co.cap_ia[c];
+    for (int p = 0; p < P; ++p) pair_thr[p] = co.pair_thr[p], pair_cull[p] = co.pair_cull[p];
+    o << "    static constexpr float cap_a[" << Lm << "] = " << rtc_array(cap_a.begin(), cap_a.end()) << ";\n";
+    o << "    static constexpr float cap_ia[" << Lm << "] = " << rtc_array(cap_ia.begin(), cap_ia.end()) << ";\n";
     o << "    static constexpr float cap_r[" << Lm << "] = " << rtc_array(cap_r.begin(), cap_r.end()) << ";\n";
     o << "    static constexpr float pair_thr[" << Pm << "] = " << rtc_array(pair_thr.begin(), pair_thr.end()) << ";\n";
     o << "    static constexpr float cap_thr[" << Lm << "] = " << rtc_array(cap_thr.begin(), cap_thr.end()) << ";\n";

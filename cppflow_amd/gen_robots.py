@@ -62,6 +62,21 @@ def cull_threshold(reach: float) -> np.float32:
     return f
 
 
+def capsule_centred(cap_p0, cap_p1):
+    """(centre, half-axis, |h|^2, 1 / |h|^2) of every capsule as the kernels use them: double arithmetic on the fp32 end points,
+    each rounded to fp32 once -- c = 0.5 (p0 + p1), h = 0.5 (p1 - p0), a = (h0 h0 + h1 h1) + h2 h2 over the ROUNDED h, 1 / a.
+    The same four lines are in csrc/cppflow_hip.hip (capsule_centred) and oracle/lmik_oracle.c (orc_robot_create)."""
+    p0 = np.asarray(cap_p0, dtype=np.float32).astype(np.float64).reshape(-1, 3)
+    p1 = np.asarray(cap_p1, dtype=np.float32).astype(np.float64).reshape(-1, 3)
+    c = (0.5 * (p0 + p1)).astype(np.float32)
+    h = (0.5 * (p1 - p0)).astype(np.float32)
+    hd = h.astype(np.float64)
+    a = (hd[:, 0] * hd[:, 0] + hd[:, 1] * hd[:, 1]) + hd[:, 2] * hd[:, 2]
+    with np.errstate(divide="ignore"):
+        ia = 1.0 / a
+    return c, h, a.astype(np.float32), ia.astype(np.float32), np.sqrt(a)
+
+
 def emit_robot(name: str, ch: CanonicalChain) -> str:
     d, L, P = ch.ndof, ch.n_capsules, ch.n_pairs
     cname = "".join(p.capitalize() for p in name.split("_"))
@@ -81,12 +96,16 @@ def emit_robot(name: str, ch: CanonicalChain) -> str:
     s.append(f"    static constexpr float cap_p0[{Lm}][3] = {{" + ", ".join(_arr(v) for v in (ch.cap_p0 if L else [[0, 0, 0]])) + "};")
     s.append(f"    static constexpr float cap_p1[{Lm}][3] = {{" + ", ".join(_arr(v) for v in (ch.cap_p1 if L else [[0, 0, 0]])) + "};")
     s.append(f"    static constexpr float cap_r[{Lm}] = {_arr(ch.cap_r if L else [0])};")
+    cc, hh, aa, ia, half = capsule_centred(ch.cap_p0, ch.cap_p1) if L else (np.zeros((1, 3)), np.zeros((1, 3)), [0], [0], [])
+    s.append(f"    static constexpr float cap_c[{Lm}][3] = {{" + ", ".join(_arr(v) for v in cc) + "};  // centre 0.5 (p0 + p1)")
+    s.append(f"    static constexpr float cap_h[{Lm}][3] = {{" + ", ".join(_arr(v) for v in hh) + "};  // half-axis 0.5 (p1 - p0)")
+    s.append(f"    static constexpr float cap_a[{Lm}] = {_arr(aa)};  // |h|^2")
+    s.append(f"    static constexpr float cap_ia[{Lm}] = {_arr(ia)};  // 1 / |h|^2")
     r32 = ch.cap_r.astype(np.float32)
     pair_thr = [sqrt_threshold(np.float32(r32[a] + r32[b])) for a, b in ch.pairs] if P else [0]
     cap_thr = [sqrt_threshold(r) for r in r32] if L else [0]
     s.append(f"    static constexpr float pair_thr[{Pm}] = {_arr(pair_thr)};  // sqrt thresholds of r_a + r_b")
     s.append(f"    static constexpr float cap_thr[{Lm}] = {_arr(cap_thr)};  // sqrt thresholds of r")
-    half = 0.5 * np.linalg.norm(ch.cap_p1.astype(np.float32).astype(np.float64) - ch.cap_p0.astype(np.float32).astype(np.float64), axis=-1) if L else []
     pair_cull = [cull_threshold(half[a] + half[b] + float(r32[a]) + float(r32[b])) for a, b in ch.pairs] if P else [0]
     cap_cull = [cull_threshold(half[c] + float(r32[c])) for c in range(L)] if L else [0]
     s.append(f"    static constexpr float pair_cull[{Pm}] = {_arr(pair_cull)};  // broad phase, pairs")

@@ -86,6 +86,8 @@ typedef struct {
     int ncaps;
     int cap_link[ORC_MAX_CAPS]; /* -1 = base */
     REAL cap_p0[ORC_MAX_CAPS][3], cap_p1[ORC_MAX_CAPS][3], cap_r[ORC_MAX_CAPS];
+    /* the capsule as the distance functions use it: centre, half-axis, |h|^2, 1 / |h|^2 (see orc_robot_create) */
+    REAL cap_c[ORC_MAX_CAPS][3], cap_h[ORC_MAX_CAPS][3], cap_a[ORC_MAX_CAPS], cap_ia[ORC_MAX_CAPS];
     int npairs;
     int pair_a[ORC_MAX_PAIRS], pair_b[ORC_MAX_PAIRS];
 } orc_robot;
@@ -115,6 +117,20 @@ void* orc_robot_create(int ndof, const double* F, const double* Fee, const int* 
             rb->cap_p1[c][k] = (REAL)cap_p1[c * 3 + k];
         }
         rb->cap_r[c] = (REAL)cap_r[c];
+        /* centre c = 0.5 (p0 + p1), half-axis h = 0.5 (p1 - p0), a = |h|^2, 1 / a: double arithmetic on the (fp32-valued) end
+         * points, each rounded to fp32 ONCE, a over the rounded h summed (h0 h0 + h1 h1) + h2 h2 -- the same lines as
+         * cppflow_amd/gen_robots.py (capsule_centred) and csrc/cppflow_hip.hip (capsule_centred), so that all three hold the
+         * same bits; the fp64 build keeps the fp32-valued c and h (it is the ground truth OF THAT capsule) with a, 1 / a unrounded. */
+        float hf[3];
+        for (int k = 0; k < 3; ++k) {
+            const double p0 = (double)(float)cap_p0[c * 3 + k], p1 = (double)(float)cap_p1[c * 3 + k];
+            rb->cap_c[c][k] = (REAL)(float)(0.5 * (p0 + p1));
+            hf[k] = (float)(0.5 * (p1 - p0));
+            rb->cap_h[c][k] = (REAL)hf[k];
+        }
+        const double a = ((double)hf[0] * (double)hf[0] + (double)hf[1] * (double)hf[1]) + (double)hf[2] * (double)hf[2];
+        rb->cap_a[c] = (REAL)a; /* fp32 build: rounded once, the kernels' constants; fp64 build: the exact |h|^2 */
+        rb->cap_ia[c] = (REAL)(1.0 / a);
     }
     rb->npairs = npairs;
     for (int p = 0; p < npairs; ++p) {
@@ -640,87 +656,89 @@ void orc_pose_metrics_exact(const void* h, const double* x, const double* target
 /* collision distances (canonical order)                                                                            */
 
 static inline REAL dot3(const REAL* a, const REAL* b) { return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0])); }
-static inline REAL clamp01(REAL v) { return v < 0 ? (REAL)0 : (v > 1 ? (REAL)1 : v); }
+static inline REAL clamp11(REAL v) { return v < -1 ? (REAL)-1 : (v > 1 ? (REAL)1 : v); }
 
-/* closest distance between segments P1Q1 and P2Q2 (non-degenerate), Ericson "Real-Time Collision Detection" 5.1.9;
- * also returns the closest points c1 (on P1Q1) and c2 (on P2Q2) */
-static REAL seg_seg_closest(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2, REAL* c1, REAL* c2) {
-    REAL d1[3], d2[3], rr[3];
-    for (int i = 0; i < 3; ++i) {
-        d1[i] = Q1[i] - P1[i];
-        d2[i] = Q2[i] - P2[i];
-        rr[i] = P1[i] - P2[i];
-    }
-    const REAL a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, rr), c = dot3(d1, rr), b = dot3(d1, d2);
-    const REAL denom = FMA(a, e, -(b * b));
-    const REAL inv_a = (REAL)1 / a, inv_e = (REAL)1 / e; /* one division per capsule (shared by all its pairs) */
-    REAL s = denom > 0 ? clamp01(FMA(b, f, -(c * e)) / denom) : (REAL)0;
-    REAL t = FMA(b, s, f) * inv_e;
-    if (t < 0) {
-        t = 0;
-        s = clamp01(-c * inv_a);
+/* The correctly rounded reciprocal, DEFINED as 0 below 2^-100 (zero, denormals, and -- for the positive-only form -- negative
+ * denominators): what every caller wants from a vanishing denominator.  The HIP kernels evaluate it as v_rcp_f32 + one
+ * Newton step, which equals RN(1/x) for every fp32 x with 2^-126 <= |x| < 2^126 (all 2^32 bit patterns compared on the GPU:
+ * scripts/ubench/rcp_exhaustive.hip, tests/test_gpu_round3.py) -- so a plain division here is the same bits. */
+static inline REAL rcp_rn(REAL x) { return FABS(x) >= RC(0x1p-100) ? (REAL)1 / x : (REAL)0; }
+static inline REAL rcp_rn_pos(REAL x) { return x >= RC(0x1p-100) ? (REAL)1 / x : (REAL)0; }
+
+/* A capsule's segment is { C + u H : u in [-1, 1] } (centre, half-axis; a = |H|^2 and ia = 1 / a are constants of the rigid
+ * link).  Closest distance between two such segments (non-degenerate), Ericson "Real-Time Collision Detection" 5.1.9
+ * re-parametrised to [-1, 1]: minimise | r + s H1 - t H2 |^2, r = C1 - C2; also returns the closest points c1, c2. */
+static REAL seg_seg_closest(const REAL* C1, const REAL* H1, const REAL* C2, const REAL* H2, REAL a, REAL ia, REAL e,
+                            REAL ie, REAL* c1, REAL* c2) {
+    REAL rr[3];
+    for (int i = 0; i < 3; ++i) rr[i] = C1[i] - C2[i];
+    const REAL b = dot3(H1, H2), c = dot3(H1, rr), f = dot3(H2, rr);
+    const REAL denom = FMA(-b, b, a * e);
+    REAL s = clamp11(FMA(b, f, -(c * e)) * rcp_rn_pos(denom)); /* parallel: s = 0, the centre */
+    REAL t = FMA(b, s, f) * ie;
+    if (t < -1) {
+        t = -1;
+        s = clamp11(-(b + c) * ia);
     } else if (t > 1) {
         t = 1;
-        s = clamp01((b - c) * inv_a);
+        s = clamp11((b - c) * ia);
     }
     REAL df[3];
     for (int i = 0; i < 3; ++i) {
-        c1[i] = FMA(d1[i], s, P1[i]);
-        c2[i] = FMA(d2[i], t, P2[i]);
-        df[i] = c1[i] - c2[i];
+        df[i] = FMA(-t, H2[i], FMA(s, H1[i], rr[i]));
+        c1[i] = FMA(s, H1[i], C1[i]);
+        c2[i] = FMA(t, H2[i], C2[i]);
     }
     return SQRT(dot3(df, df));
 }
 
-static REAL seg_seg_dist(const REAL* P1, const REAL* Q1, const REAL* P2, const REAL* Q2) {
+static REAL seg_seg_dist(const REAL* C1, const REAL* H1, const REAL* C2, const REAL* H2, REAL a, REAL ia, REAL e, REAL ie) {
     REAL c1[3], c2[3];
-    return seg_seg_closest(P1, Q1, P2, Q2, c1, c2);
+    return seg_seg_closest(C1, H1, C2, H2, a, ia, e, ie, c1, c2);
 }
 
 static inline REAL clampr(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static inline REAL maxr(REAL a, REAL b) { return a > b ? a : b; }
 static inline REAL minr(REAL a, REAL b) { return a < b ? a : b; }
 
-/* exact distance from segment P0P1 to the axis-aligned box [lo, hi] (0 if they intersect), with the closest points.
- * Along the segment x_i(t) = P0_i + t D_i the excess over the slab [lo_i, hi_i] is D_i (t - clamp(t, a_i, b_i)), [a_i, b_i]
- * being the parameter interval in which coordinate i is inside the slab; so the half-derivative of dist^2 is
- *     g(t) = sum_i w_i (t - clamp(t, a_i, b_i)),  w_i = D_i^2,
- * nondecreasing and piecewise linear with break points a_i, b_i.  g is evaluated at t = 0, 1 and the six clamped break
+/* exact distance from the segment { C + u H } to the axis-aligned box [lo, hi] (0 if they intersect), with the closest
+ * points.  Along the segment x_i(u) = C_i + u H_i the excess over the slab [lo_i, hi_i] is H_i (u - clamp(u, a_i, b_i)),
+ * [a_i, b_i] being the parameter interval in which coordinate i is inside the slab; so the half-derivative of dist^2 is
+ *     g(u) = sum_i w_i (u - clamp(u, a_i, b_i)),  w_i = H_i^2,
+ * nondecreasing and piecewise linear with break points a_i, b_i.  g is evaluated at u = -1, 1 and the six clamped break
  * points; because g is monotone the bracket of its root is two independent max / min reductions over those candidates
- * (tl = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0}; tr = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}), and the root is
+ * (ul = max{c : g(c) <= 0}, gl = max{g(c) : g(c) <= 0}; ur = min{c : g(c) > 0}, gr = min{g(c) : g(c) > 0}), and the root is
  * interpolated linearly inside the bracket. */
-static REAL seg_box_closest(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi, REAL* cs, REAL* cb) {
-    REAL D[3], w[3], ta[3], tb[3], cand[8], gv[8];
+static REAL seg_box_closest(const REAL* C, const REAL* H, const REAL* lo, const REAL* hi, REAL* cs, REAL* cb) {
+    REAL w[3], ua[3], ub[3], cand[8], gv[8];
     for (int i = 0; i < 3; ++i) {
-        D[i] = P1[i] - P0[i];
-        const REAL inv = D[i] != 0 ? (REAL)1 / D[i] : (REAL)0;
-        const REAL t0 = (lo[i] - P0[i]) * inv, t1 = (hi[i] - P0[i]) * inv;
-        ta[i] = minr(t0, t1);
-        tb[i] = maxr(t0, t1);
-        w[i] = D[i] * D[i];
-        cand[2 + 2 * i] = clamp01(ta[i]);
-        cand[3 + 2 * i] = clamp01(tb[i]);
+        const REAL inv = rcp_rn(H[i]);
+        const REAL u0 = (lo[i] - C[i]) * inv, u1 = (hi[i] - C[i]) * inv;
+        ua[i] = minr(u0, u1);
+        ub[i] = maxr(u0, u1);
+        w[i] = H[i] * H[i];
+        cand[2 + 2 * i] = clamp11(ua[i]);
+        cand[3 + 2 * i] = clamp11(ub[i]);
     }
-    cand[0] = 0;
+    cand[0] = -1;
     cand[1] = 1;
     for (int k = 0; k < 8; ++k) {
-        const REAL t = cand[k];
-        gv[k] = FMA(w[2], t - clampr(t, ta[2], tb[2]), FMA(w[1], t - clampr(t, ta[1], tb[1]), w[0] * (t - clampr(t, ta[0], tb[0]))));
+        const REAL u = cand[k];
+        gv[k] = FMA(w[2], u - clampr(u, ua[2], ub[2]), FMA(w[1], u - clampr(u, ua[1], ub[1]), w[0] * (u - clampr(u, ua[0], ub[0]))));
     }
-    REAL tl = 0, gl = gv[0], tr = 1, gr = gv[1];
+    REAL ul = -1, gl = gv[0], ur = 1, gr = gv[1];
     for (int k = 2; k < 8; ++k) {
         const int neg = gv[k] <= 0;
-        tl = maxr(tl, neg ? cand[k] : (REAL)0);
+        ul = maxr(ul, neg ? cand[k] : (REAL)-1);
         gl = maxr(gl, neg ? gv[k] : gv[0]);
-        tr = minr(tr, neg ? (REAL)1 : cand[k]);
+        ur = minr(ur, neg ? (REAL)1 : cand[k]);
         gr = minr(gr, neg ? gv[1] : gv[k]);
     }
-    const REAL dg = gr - gl;
-    const REAL t_in = dg > 0 ? FMA(tr - tl, (-gl) / dg, tl) : tl;
-    const REAL t = gv[0] >= 0 ? (REAL)0 : (gv[1] <= 0 ? (REAL)1 : t_in);
+    const REAL u_in = FMA(ur - ul, (-gl) * rcp_rn_pos(gr - gl), ul); /* a flat bracket: its left end */
+    const REAL u = gv[0] >= 0 ? (REAL)-1 : (gv[1] <= 0 ? (REAL)1 : u_in);
     REAL ex[3];
     for (int i = 0; i < 3; ++i) {
-        const REAL x = FMA(D[i], t, P0[i]);
+        const REAL x = FMA(H[i], u, C[i]);
         cs[i] = x;
         cb[i] = clampr(x, lo[i], hi[i]);
         ex[i] = x - cb[i];
@@ -728,31 +746,39 @@ static REAL seg_box_closest(const REAL* P0, const REAL* P1, const REAL* lo, cons
     return SQRT(dot3(ex, ex));
 }
 
-static REAL seg_box_dist(const REAL* P0, const REAL* P1, const REAL* lo, const REAL* hi) {
+static REAL seg_box_dist(const REAL* C, const REAL* H, const REAL* lo, const REAL* hi) {
     REAL cs[3], cb[3];
-    return seg_box_closest(P0, P1, lo, hi, cs, cb);
+    return seg_box_closest(C, H, lo, hi, cs, cb);
 }
 
-static void capsule_endpoints(const orc_robot* rb, const REAL* q, REAL (*w0)[3], REAL (*w1)[3]) {
-    frame_t links[ORC_MAX_DOF];
-    fk_chain(rb, q, links, NULL, NULL, NULL);
+/* world centre / half-axis of every capsule from the link frames (canonical order: the centre as a point, R c + p; the
+ * half-axis as a direction, R h) */
+static void capsules_from_links(const orc_robot* rb, const frame_t* links, REAL (*wc)[3], REAL (*wh)[3]) {
     for (int c = 0; c < rb->ncaps; ++c) {
         const int li = rb->cap_link[c];
         if (li < 0) {
             for (int i = 0; i < 3; ++i) {
-                w0[c][i] = rb->cap_p0[c][i];
-                w1[c][i] = rb->cap_p1[c][i];
+                wc[c][i] = rb->cap_c[c][i];
+                wh[c][i] = rb->cap_h[c][i];
             }
         } else {
             const frame_t* f = &links[li];
             for (int i = 0; i < 3; ++i) {
                 const REAL r0 = f->R[3 * i], r1 = f->R[3 * i + 1], r2 = f->R[3 * i + 2];
-                w0[c][i] = FMA(r2, rb->cap_p0[c][2], FMA(r1, rb->cap_p0[c][1], FMA(r0, rb->cap_p0[c][0], f->p[i])));
-                w1[c][i] = FMA(r2, rb->cap_p1[c][2], FMA(r1, rb->cap_p1[c][1], FMA(r0, rb->cap_p1[c][0], f->p[i])));
+                wc[c][i] = FMA(r2, rb->cap_c[c][2], FMA(r1, rb->cap_c[c][1], FMA(r0, rb->cap_c[c][0], f->p[i])));
+                wh[c][i] = FMA(r2, rb->cap_h[c][2], FMA(r1, rb->cap_h[c][1], r0 * rb->cap_h[c][0]));
             }
         }
     }
 }
+
+static void capsule_endpoints(const orc_robot* rb, const REAL* q, REAL (*wc)[3], REAL (*wh)[3]) {
+    frame_t links[ORC_MAX_DOF];
+    fk_chain(rb, q, links, NULL, NULL, NULL);
+    capsules_from_links(rb, links, wc, wh);
+}
+
+#define PAIR_CONSTS(rb, a, b) (rb)->cap_a[a], (rb)->cap_ia[a], (rb)->cap_a[b], (rb)->cap_ia[b]
 
 /* Robot.self_collision_distances: x[n,d] -> dists[n,P] (signed: segment distance - r_a - r_b), SURVEY a11 */
 void orc_self_dists(const void* h, const double* x, int n, double* dists) {
@@ -764,7 +790,7 @@ void orc_self_dists(const void* h, const double* x, int n, double* dists) {
         capsule_endpoints(rb, q, w0, w1);
         for (int p = 0; p < rb->npairs; ++p) {
             const int a = rb->pair_a[p], b = rb->pair_b[p];
-            const REAL dist = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]);
+            const REAL dist = seg_seg_dist(w0[a], w1[a], w0[b], w1[b], PAIR_CONSTS(rb, a, b));
             dists[(size_t)r * rb->npairs + p] = dist - (rb->cap_r[a] + rb->cap_r[b]);
         }
     }
@@ -799,8 +825,8 @@ void orc_capsule_endpoints(const void* h, const double* x, int n, double* out) {
         capsule_endpoints(rb, q, w0, w1);
         for (int c = 0; c < rb->ncaps; ++c)
             for (int i = 0; i < 3; ++i) {
-                out[((size_t)r * rb->ncaps + c) * 6 + i] = w0[c][i];
-                out[((size_t)r * rb->ncaps + c) * 6 + 3 + i] = w1[c][i];
+                out[((size_t)r * rb->ncaps + c) * 6 + i] = w0[c][i] - w1[c][i];     /* centre - half-axis */
+                out[((size_t)r * rb->ncaps + c) * 6 + 3 + i] = w0[c][i] + w1[c][i]; /* centre + half-axis */
             }
     }
 }
@@ -821,7 +847,7 @@ void orc_masks(const void* h, const double* x, int n, int nobs, const double* bo
         REAL ms = INFINITY;
         for (int p = 0; p < rb->npairs; ++p) {
             const int a = rb->pair_a[p], b = rb->pair_b[p];
-            const REAL v = seg_seg_dist(w0[a], w1[a], w0[b], w1[b]) - (rb->cap_r[a] + rb->cap_r[b]);
+            const REAL v = seg_seg_dist(w0[a], w1[a], w0[b], w1[b], PAIR_CONSTS(rb, a, b)) - (rb->cap_r[a] + rb->cap_r[b]);
             if (v < ms) ms = v;
         }
         int env = 0;
@@ -1046,25 +1072,12 @@ static void point_jacobian_col(const orc_robot* rb, int link, int j, const REAL 
     }
 }
 
-/* capsule world end points + joint axes / origins for one configuration */
+/* capsule world centres / half-axes (w0 / w1 below) + joint axes / origins for one configuration */
 static void capsules_and_axes(const orc_robot* rb, const REAL* q, REAL (*w0)[3], REAL (*w1)[3], REAL (*axis)[3],
                               REAL (*origin)[3]) {
     frame_t links[ORC_MAX_DOF];
     fk_chain(rb, q, links, axis, origin, NULL);
-    for (int c = 0; c < rb->ncaps; ++c) {
-        const int li = rb->cap_link[c];
-        for (int i = 0; i < 3; ++i) {
-            if (li < 0) {
-                w0[c][i] = rb->cap_p0[c][i];
-                w1[c][i] = rb->cap_p1[c][i];
-            } else {
-                const frame_t* f = &links[li];
-                const REAL r0 = f->R[3 * i], r1 = f->R[3 * i + 1], r2 = f->R[3 * i + 2];
-                w0[c][i] = FMA(r2, rb->cap_p0[c][2], FMA(r1, rb->cap_p0[c][1], FMA(r0, rb->cap_p0[c][0], f->p[i])));
-                w1[c][i] = FMA(r2, rb->cap_p1[c][2], FMA(r1, rb->cap_p1[c][1], FMA(r0, rb->cap_p1[c][0], f->p[i])));
-            }
-        }
-    }
+    capsules_from_links(rb, links, w0, w1);
 }
 
 /* signed self-collision distances [P] and their gradients [P,d] for one configuration: the derivative of the minimum
@@ -1079,7 +1092,7 @@ static void self_dists_and_grads(const orc_robot* rb, const REAL* q, REAL* dist,
     for (int p = 0; p < rb->npairs; ++p) {
         const int a = rb->pair_a[p], b = rb->pair_b[p];
         REAL c1[3], c2[3];
-        const REAL sd = seg_seg_closest(w0[a], w1[a], w0[b], w1[b], c1, c2);
+        const REAL sd = seg_seg_closest(w0[a], w1[a], w0[b], w1[b], PAIR_CONSTS(rb, a, b), c1, c2);
         dist[p] = sd - (rb->cap_r[a] + rb->cap_r[b]);
         REAL n[3] = {0, 0, 0};
         if (sd > 0)
