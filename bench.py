@@ -98,22 +98,60 @@ def workload_key(robot, S, W, K, collide, inputs="problem"):
     return f"{robot}_S{S}_W{W}_K{K}_coll{int(collide)}" + ("" if inputs == "problem" else f"_{inputs}")
 
 
-def traffic_from_profiles(robot, S, W, K, collide):
+PROFILE_ROUND = "r3"  # the committed record pass these lookups read (scripts/record_pass.sh -> profiles/r3_*)
+
+
+def traffic_from_profiles(robot, S, W, K, collide, build_id):
     """HBM bytes per launch of the fused kernel from the rocprofv3 PMC passes committed under profiles/ (separate
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950).  bench.py cannot profile itself, so the figure is the recorded one for the matching workload, else None."""
-    for fname in ("r2_traffic.json", "r1_traffic.json"):
-        rec = _profile_record(fname, workload_key(robot, S, W, K, collide))
-        if rec:
-            return rec.get("hbm_bytes_per_launch")
+    for gfx950).  bench.py cannot profile itself, so the figure is the recorded one for the matching workload AND library
+    build (the record carries the build id of the library it was taken with), else None."""
+    rec = _profile_record(f"{PROFILE_ROUND}_traffic.json", workload_key(robot, S, W, K, collide))
+    if rec and _profile_record(f"{PROFILE_ROUND}_traffic.json", "_build_id") == build_id:
+        return rec.get("hbm_bytes_per_launch")
     return None
 
 
-def issue_record_from_profiles(robot, S, W, K, collide, inputs):
-    """{"valu_insts_per_launch": SQ_INSTS_VALU of one fused launch (wave-instructions), "flops_per_valu_lane_op": executed
-    flops per VALU lane-operation from the kernel's ISA (FMA = 2, mul / add / sub = 1, everything else 0)} recorded by
-    `rocprofv3 --pmc SQ_INSTS_VALU` for the matching workload (scripts/record_pass.sh -> profiles/r2_issue.json), else None."""
-    return _profile_record("r2_issue.json", workload_key(robot, S, W, K, collide, inputs))
+def issue_record_from_profiles(robot, S, W, K, collide, inputs, build_id):
+    """({"valu_insts_per_launch": SQ_INSTS_VALU of one fused launch (wave-instructions), "flops_per_valu_lane_op": executed
+    flops per VALU lane-operation (FMA = 2, mul / add / sub = 1, everything else 0), ...}, note) recorded by `rocprofv3 --pmc` for
+    the matching workload (scripts/record_pass.sh -> profiles/r3_issue.json).  A record is only used when it was taken with THIS
+    build of the library (`_build_id` in the file == cppf_build_id()): after any kernel change the counts are stale, and a stale
+    instruction count divided by a live kernel time is not a measurement.  Returns (None, why) otherwise."""
+    fname = f"{PROFILE_ROUND}_issue.json"
+    rec = _profile_record(fname, workload_key(robot, S, W, K, collide, inputs))
+    if rec is None:
+        return None, f"no SQ_INSTS_VALU record for this workload in profiles/{fname}"
+    have = _profile_record(fname, "_build_id")
+    if have != build_id:
+        return None, f"profiles/{fname} was recorded with library build {have}, this run loaded {build_id}"
+    return rec, ""
+
+
+def kernel_profile_from_profiles(kernel_substr, build_id):
+    """Average duration (ms) and call count of the dominant kernel in the committed `rocprofv3 --kernel-trace --stats` summary of
+    this same command (profiles/r3_fused_kernel_stats.csv; its first line names the build it was taken with), or (None, why)."""
+    import csv
+
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_fused_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None, f"profiles/{PROFILE_ROUND}_fused_kernel_stats.csv missing"
+    with open(path) as f:
+        first = f.readline()
+        if not first.startswith("# build_id="):
+            return None, "stats file carries no build id"
+        have = first.strip().split("=", 1)[1]
+        rows = list(csv.DictReader(f))
+    if have != build_id:
+        return None, f"stats recorded with library build {have}, this run loaded {build_id}"
+    best = None
+    for r in rows:
+        if kernel_substr in r["Name"] and (best is None or int(r["Calls"]) > int(best["Calls"])):
+            best = r
+    if best is None:
+        return None, f"no row matching {kernel_substr!r}"
+    return {"ms": float(best["AverageNs"]) * 1e-6, "calls": int(best["Calls"]), "min_ms": float(best["MinNs"]) * 1e-6,
+            "max_ms": float(best["MaxNs"]) * 1e-6}, ""
 
 
 def make_inputs(robot, S, W, device, seed):
@@ -302,6 +340,11 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                     help="auto = strong for N > 1 (BASELINE.json configs[3]: the same seeds sharded over the GPUs); the other mode "
                     "is measured in the same run and reported as a sibling key")  # fmt: skip
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps between barrier + synchronize pairs) is measured this many times "
+                    "back to back; value / ms_per_step are the MEDIAN repetition (min and max in config.timed_region)")
+    ap.add_argument("--kernel-reps", type=int, default=400,
+                    help="isolated launches behind roofline.kernel_ms (median of HIP-event pairs after a pre-warm)")
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="untimed launches before the W warm-up steps, to reach sustained clocks (0 disables)")
     ap.add_argument("--gather-every", type=int, default=0,
@@ -314,9 +357,10 @@ def parse_args(argv=None):
                     help="replay each stream's run of consecutive steps as one captured hipGraph instead of one host call per step "
                          "(auto: on for shards of <= 65536 rows, where a step is shorter than the host's launch call)")
     ap.add_argument("--shape", choices=["auto", "row", "quad"], default="auto", help="kernel shape (cppf_lm_params.shape)")
-    ap.add_argument("--solver", choices=["f32", "f64"], default="f32",
-                    help="precision of the damped solve (cppf_lm_params.solver): f32 = the reference's dtype (the headline); f64 = "
-                    "exact to rounding on near-singular rows too")  # fmt: skip
+    ap.add_argument("--solver", choices=["auto", "f32", "f64"], default="auto",
+                    help="precision of the damped solve (cppf_lm_params.solver): auto = the reference's dtype with the conditioning gate "
+                    "(rows whose fp32 solve is estimated to be off by > 1e-5 in task space redo it in double precision; the default and "
+                    "the headline); f32 = no gate; f64 = every row in double precision")  # fmt: skip
     ap.add_argument("--inputs", choices=["problem", "random"], default="problem",
                     help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); "
                     "random: independent random configurations per waypoint (the 8d fall-back, worst case for the broad phase)")  # fmt: skip
@@ -407,29 +451,17 @@ class RcclGather:
 class CAbiGather:
     """RCCL through the library's own C ABI (cppf_comm_init_rank / cppf_allgather_bytes): one ncclAllGather enqueued on the
     auxiliary stream itself -- no second stream, no c10d bookkeeping (3 us of host time and 6 us on the stream against 28 / 33 us
-    for torch.distributed's call on one rank, scripts/gather_latency.py).  The communicator's unique id travels to the other
-    ranks through the torch.distributed group that is up anyway."""
+    for torch.distributed's call on one rank, scripts/gather_latency.py).  Built by `pick_cabi_or_c10d`, which ships the
+    communicator's unique id to the other ranks through the torch.distributed group that is up anyway."""
 
-    def __init__(self, dist, rank, world, device_index):
-        import ctypes
-
+    def __init__(self, comm, world):
         from cppflow_amd import _hip
 
-        self._hip, self._ct = _hip, ctypes
-        lib = _hip.lib()
-        uid = (ctypes.c_char * 128)()
-        if rank == 0:
-            _hip.check(lib.cppf_comm_unique_id(uid))
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0)
-        uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
-        self.comm = ctypes.c_void_p()
-        _hip.check(lib.cppf_comm_init_rank(uid, rank, world, device_index, ctypes.byref(self.comm)))
-        assert lib.cppf_comm_world(self.comm) == world
+        self._hip, self.comm, self.world = _hip, comm, world
 
     def all_gather(self, out, inp):
         nbytes = inp.numel() * inp.element_size()
-        assert out.numel() * out.element_size() == nbytes * self._hip.lib().cppf_comm_world(self.comm)
+        assert out.numel() * out.element_size() == nbytes * self.world
         self._hip.check(self._hip.lib().cppf_allgather_bytes(self.comm, inp.data_ptr(), out.data_ptr(), nbytes,
                                                               torch.cuda.current_stream(inp.device).cuda_stream))
 
@@ -438,29 +470,104 @@ class CAbiGather:
 
 
 def pick_cabi_or_c10d(dist, rank, world, dev_index, device):
-    """The C-ABI communicator, checked against torch.distributed's own all-gather on a small probe; every rank falls back to
-    the c10d call together if creating it failed or its result differs anywhere (a second RCCL communicator next to c10d's
-    has only been rehearsed on one-GPU boxes)."""
-    ok, cabi, why = 1, None, ""
+    """The C-ABI communicator if EVERY rank can bring it up and its all-gather equals torch.distributed's own on a probe, else
+    the c10d call on every rank.  Returns (transport, record).
+
+    Every rank executes the SAME sequence of collectives on the c10d group whatever happens to it locally (a rank
+    that failed early used to jump to the fall-back's all-reduce while the others still sat in the broadcast -- mismatched
+    collectives, a hang until the c10d timeout): local failures become flags, and after each stage all ranks MIN-reduce their
+    flag and leave together.  Stage 0 (no collective): can this rank load RCCL through the library (cppf_comm_available)?  1: rank
+    0 draws the unique id and ALWAYS broadcasts (status, id).  2: all ranks agree to go on, then call cppf_comm_init_rank.  3:
+    agree again, then the probe (both all-gathers on every rank).  4: agree on the comparison.  A successful probe is the
+    validation of this transport on the hardware the run is on."""
+    import ctypes
+
+    from cppflow_amd import _hip
+
+    def all_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    rec = {"requested": "cabi", "stages": []}
+    why, lib = "", None
     try:
-        cabi = CAbiGather(dist, rank, world, dev_index)
+        lib = _hip.lib()
+        ok = lib.cppf_comm_available() == 0
+        if not ok:
+            why = lib.cppf_last_error().decode("utf-8", "replace")
+    except Exception as e:  # noqa: BLE001 -- any local failure becomes a flag
+        ok, why = False, repr(e)
+    box = [None]
+    if rank == 0:
+        uid = (ctypes.c_char * 128)()
+        st = False
+        if ok:
+            try:
+                st = lib.cppf_comm_unique_id(uid) == 0
+            except Exception as e:  # noqa: BLE001
+                why = repr(e)
+        box = [(bool(st), bytes(uid))]
+    dist.broadcast_object_list(box, src=0)
+    ok = ok and bool(box[0][0])
+    go = all_ok(ok)
+    rec["stages"].append({"stage": "load RCCL through the C ABI + unique id from rank 0 (torch.distributed broadcast)", "ok": go})
+    comm = ctypes.c_void_p()
+    if go:
+        try:
+            uid = (ctypes.c_char * 128).from_buffer_copy(box[0][1])
+            ok = lib.cppf_comm_init_rank(uid, rank, world, dev_index, ctypes.byref(comm)) == 0 and lib.cppf_comm_world(comm) == world
+            if not ok:
+                why = lib.cppf_last_error().decode("utf-8", "replace")
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, repr(e)
+        go = all_ok(ok)
+        rec["stages"].append({"stage": "cppf_comm_init_rank on every rank", "ok": go})
+    if go:
+        cabi = CAbiGather(comm, world)
         probe = torch.full((1, 4, 8), float(rank + 1), dtype=torch.float32, device=device)
         got = torch.zeros((world, 1, 4, 8), dtype=torch.float32, device=device)
-        cabi.all_gather(got, probe)
         want = torch.zeros_like(got)
-        dist.all_gather_into_tensor(want.view(world, 4, 8), probe)
+        try:
+            cabi.all_gather(got, probe)
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, repr(e)
+        dist.all_gather_into_tensor(want.view(world, 4, 8), probe)  # (every rank, whatever the C-ABI call did)
         torch.cuda.synchronize()
-        if not torch.equal(got, want):
-            ok, why = 0, "probe mismatch"
-    except Exception as e:  # noqa: BLE001 -- any failure means: use the other transport
-        ok, why = 0, repr(e)
-    flag = torch.tensor([ok], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
-        return cabi
-    print(f"bench: rank {rank}: C-ABI RCCL transport unavailable ({why or 'failed on another rank'}); using torch.distributed's all-gather",
+        ok = ok and bool(torch.equal(got, want))
+        if not ok and not why:
+            why = "probe mismatch"
+        go = all_ok(ok)
+        rec["stages"].append({"stage": "probe: cppf_allgather_bytes == torch.distributed all_gather_into_tensor", "ok": go})
+        if go:
+            rec.update(transport="RCCL through the C ABI (cppf_allgather_bytes on the launch stream)", world_seen=int(lib.cppf_comm_world(comm)),
+                       unique_id_via="cppf_comm_unique_id on rank 0 -> torch.distributed broadcast_object_list")
+            return cabi, rec
+    if comm.value:
+        try:
+            lib.cppf_comm_destroy(comm)
+        except Exception:  # noqa: BLE001
+            pass
+    print(f"bench: rank {rank}: C-ABI RCCL transport not used ({why or 'failed on another rank'}); every rank uses torch.distributed's all-gather",
           file=sys.stderr)
-    return RcclGather(dist)
+    rec.update(transport="nccl (RCCL) through torch.distributed", world_seen=dist.get_world_size(), unique_id_via="torch.distributed (c10d store)",
+               fallback_reason=why or "failed on another rank")
+    return RcclGather(dist), rec
+
+
+def device_census(dist, rank, dev_index):
+    """[(rank, device ordinal, PCI bus id, name)] of every rank, gathered through the process group: lets a reader of the JSON
+    check that N ranks sat on N different GPUs."""
+    p = torch.cuda.get_device_properties(dev_index)
+    bus = None
+    if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    mine = {"rank": rank, "device": dev_index, "pci_bus_id": bus, "uuid": str(getattr(p, "uuid", "")) or None, "name": p.name}
+    if dist is None:
+        return [mine]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return everyone
 
 
 class NoGather:
@@ -586,9 +693,9 @@ class Runner:
                 self.exchange((self.step_no % self.NBUF) // self.G)
             self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
 
-    def timed(self, steps, warmup, prewarm_ms, barrier):
-        """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then exactly `steps`
-        steps between barrier + synchronize pairs.  Returns this rank's elapsed seconds."""
+    def timed(self, steps, warmup, prewarm_ms, barrier, repeats=1):
+        """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then `repeats` times:
+        exactly `steps` steps between barrier + synchronize pairs.  Returns this rank's elapsed seconds of every repetition."""
         # the pre-warm is time-based, so it must not contain collectives (ranks would issue different numbers of them):
         # bare launches round-robin over the ring slots and streams
         t_pre = time.perf_counter()
@@ -598,12 +705,15 @@ class Runner:
             torch.cuda.synchronize()
         self.run_steps(warmup)
         self.drain()
-        barrier()
-        t0 = time.perf_counter()
-        self.run_steps(steps)
-        self.drain()
-        barrier()
-        return time.perf_counter() - t0
+        out = []
+        for _ in range(max(1, repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            self.run_steps(steps)
+            self.drain()
+            barrier()
+            out.append(time.perf_counter() - t0)
+        return out
 
     def host_enqueue_us(self):
         """diagnostic: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)"""
@@ -616,16 +726,25 @@ class Runner:
         torch.cuda.synchronize()
         return 1e6 * t
 
-    def kernel_ms(self, reps):
-        """isolated launch duration: HIP events bracketing single launches on the launch stream (torch's current stream IS
-        the stream the kernel is launched on); no collective inside the bracket"""
+    def kernel_ms(self, reps, prewarm=300):
+        """Isolated launch duration: HIP events bracketing single launches on the launch stream (torch's current stream IS
+        the stream the kernel is launched on), one launch in flight at a time, no collective inside the bracket.  `prewarm`
+        untimed launches first (an idle gap drops the clocks: the first launches after one run 30-40 % long), then the MEDIAN of
+        `reps` pairs -- one host hiccup of a millisecond moves a mean of 50 by 20 us and a median not at all.  Returns a dict."""
+        for _ in range(prewarm):
+            self.launch()
+        torch.cuda.synchronize()
+        for _ in range(prewarm // 4):
+            self.launch()
         kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in kev:
             a.record()
             self.launch()
             b.record()
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in kev]))
+        t = np.array([a.elapsed_time(b) for a, b in kev])
+        return {"median": float(np.median(t)), "mean": float(t.mean()), "min": float(t.min()), "p10": float(np.quantile(t, 0.1)),
+                "p90": float(np.quantile(t, 0.9)), "max": float(t.max()), "n": int(reps)}
 
 
 def dryrun(args, world, rank):
@@ -653,6 +772,14 @@ def dryrun(args, world, rank):
     mine[e - b :] = float("inf")  # filler seeds can never be selected
     allseeds = drop_padding(allgather_seed_summaries(mine), S_pad, shard_counts(S, world))
     valid = [i for i in range(allseeds.shape[0]) if seed_metrics_are_below_threshold(DEFAULT_CONSTRAINTS, allseeds[i, :4])[0]]
+    # the same self-verification as the real run: every rank's selection gathered and compared, and against the single-process
+    # answer (here: seed 0 is the first valid one, all S are valid, and the stand-in cost makes seed 0 the cheapest)
+    mine_sel = [valid[0] if valid else -1, len(valid), int(torch.argmin(allseeds[:, 7]).item()), 0]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine_sel)
+    assert all(e == everyone[0] for e in everyone), everyone
+    census = [None] * world
+    dist.all_gather_object(census, {"rank": rank, "device": None, "pci_bus_id": None, "name": "cpu (dry run)"})
     t = torch.tensor([float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
@@ -664,7 +791,12 @@ def dryrun(args, world, rank):
                           "data": "dryrun (no GPU: launcher and collective choreography only)",
                           "config": {"world_size": dist.get_world_size(), "seeds_total": S, "seeds_per_gpu_padded": S_pad,
                                      "gathered_seed_ids": [int(v) for v in allseeds[:, 7]], "n_valid": len(valid),
-                                     "max_rank": int(t.item())}}), flush=True)  # fmt: skip
+                                     "max_rank": int(t.item())},
+                          "rccl": {"requested": "dryrun", "transport": "gloo (dry run)", "world_seen": dist.get_world_size(),
+                                   "unique_id_via": "torch.distributed (c10d store)", "ranks": census},
+                          "selection_check": {"selected_by_rank": everyone, "identical_on_every_rank": True,
+                                              "single_process_selection": [0, S, 0, 0],
+                                              "equals_single_process": everyone[0] == [0, S, 0, 0]}}), flush=True)  # fmt: skip
         os.dup2(2, 1)
     dist.destroy_process_group()
 
@@ -705,6 +837,7 @@ def main():
     dist = None
     saved_stdout_fd = None
     transport = None
+    rccl_rec = None
     # CPPF_BENCH_FORCE_DIST=1 initialises the RCCL process group even for one rank (rehearses the N > 1 code path)
     force_dist = os.environ.get("CPPF_BENCH_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
@@ -725,9 +858,11 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
             which = os.environ.get("CPPF_BENCH_TRANSPORT", "cabi")
             if which == "cabi":
-                transport = pick_cabi_or_c10d(dist, rank, world, dev_index, device)
+                transport, rccl_rec = pick_cabi_or_c10d(dist, rank, world, dev_index, device)
             else:
                 transport = {"c10d": lambda: RcclGather(dist), "none": lambda: NoGather()}[which]()
+                rccl_rec = {"requested": which, "transport": {"c10d": "nccl (RCCL) through torch.distributed", "none": "none (diagnostic)"}[which],
+                            "world_seen": dist.get_world_size(), "unique_id_via": "torch.distributed (c10d store)"}
         assert dist.get_world_size() == world
 
     from cppflow_amd import _hip
@@ -743,13 +878,15 @@ def main():
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
     shape = {"auto": _hip.SHAPE_AUTO, "row": _hip.SHAPE_ROW, "quad": _hip.SHAPE_QUAD}[args.shape]
-    solver = {"f32": _hip.SOLVER_F32, "f64": _hip.SOLVER_F64}[args.solver]
+    solver = {"auto": _hip.SOLVER_AUTO, "f32": _hip.SOLVER_F32, "f64": _hip.SOLVER_F64}[args.solver]
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
     S_cfg = args.seeds
     if scaling == "strong":
         assert S_cfg % world == 0 and (S_cfg // world) >= 1, f"--seeds {S_cfg} must be a multiple of --gpus {world} under strong scaling"
     S_main = S_cfg // world if scaling == "strong" else S_cfg
+
+    full_inputs = {}
 
     def inputs_for(S_local, mode, kind):
         """(x0 [S_local*W, d], target, description).  Strong scaling: every rank builds the SAME S_cfg seeds (seed 0) and keeps
@@ -760,6 +897,8 @@ def main():
         else:
             x_all, tgt = make_inputs(robot, S_cfg, W, device, seed=gen_seed)
             desc = "per waypoint q* ~ U(limits), target = FK(q*), seeds = clamp(q* + 0.1 randn) (SURVEY 8d fall-back inputs)"
+        if mode == "strong" or world == 1:
+            full_inputs[kind] = (x_all, tgt)  # all S_cfg seeds: the single-process reference of the selection check
         if mode == "strong" and world > 1:
             b, e = seed_shard(S_cfg, rank, world)
             x_all = x_all[b * W : e * W].contiguous()
@@ -788,17 +927,41 @@ def main():
     use_graphs = args.graphs == "on" or (args.graphs == "auto" and rows_main <= 65536)
     run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver, graphs=use_graphs)
     n = run.n
-    elapsed = max_over_ranks(run.timed(args.steps, args.warmup, args.prewarm_ms, barrier))
+    # the timed region, `--repeats` times back to back; every repetition is the maximum over ranks, the headline the median one
+    reps_s = [max_over_ranks(t) for t in run.timed(args.steps, args.warmup, args.prewarm_ms, barrier, args.repeats)]
+    elapsed = float(np.median(reps_s))
     host_us = run.host_enqueue_us()
-    kernel_ms = run.kernel_ms(min(max(args.steps, 50), 2000))
+    kstats = run.kernel_ms(max(200, args.kernel_reps))
+    kernel_ms = kstats["median"]
 
     # sanity on the result of the last step (not timed): most rows converged
     outputs = run.outputs
     conv_frac = float((outputs["pos_err_m"] < 1e-4).float().mean().item())
     selected = None
+    selection_check = None
     if run.selected is not None:
         torch.cuda.synchronize()
         selected = [int(v) for v in run.selected[0][0].cpu()]
+        # Self-verification of the exchange step (every step is the same computation on the same inputs, so ONE answer is right):
+        # (1) every rank must hold the same selection -- it is computed on each rank from the gathered summaries of all ranks;
+        # (2) under strong scaling it must equal what ONE process selects over the same S_cfg seeds (every rank built all of
+        # them; this rank runs one unsharded launch and the same selection kernel over its own [S_cfg, 8] summary).
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, selected)
+        same = all(e == everyone[0] for e in everyone)
+        single = None
+        if scaling == "strong" or world == 1:
+            x_full, tgt_full = full_inputs[args.inputs]
+            summ = torch.empty((S_cfg, 8), dtype=torch.float32, device=device)
+            pk = torch.empty(robot.PACKED_BYTES_PER_ROW * S_cfg * W, dtype=torch.uint8, device=device)
+            robot.lm_pose_steps(x_full, tgt_full, n_steps=K, packed_out=pk, summary_out=summ, shape=shape, solver=solver, **run.prm)
+            single = [int(v) for v in robot.select_valid_seed(summ.view(1, 1, S_cfg, 8), run.constraints).reshape(-1).cpu()]
+            del pk
+        selection_check = {"selected_by_rank": everyone, "identical_on_every_rank": same, "single_process_selection": single,
+                           "equals_single_process": (single == selected) if single is not None else None,
+                           "fields": "[first valid seed or -1, number of valid seeds, seed of smallest summed cost, 0] over all ranks' seeds"}
+        assert same, f"ranks disagree on the selected seed: {everyone}"
+        assert single is None or single == selected, f"sharded selection {selected} != single-process selection {single}"
 
     # Once per planning call (not per step): every rank gets ALL ranks' per-row costs / masks and candidate paths with one
     # all-gather each and runs dp_search over them (cppflow/search.py:146-173 consumes every candidate's cost row).  Untimed
@@ -831,8 +994,8 @@ def main():
         """a second workload / pipeline depth measured like the headline (same barriers, same max over ranks)"""
         xs, tg, _ = inputs_for(S_local, mode, kind)
         r2 = Runner(robot, xs, tg, K, collide, streams, G, transport, world, shape, device, solver)
-        el = max_over_ranks(r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier))
-        km = r2.kernel_ms(min(max(steps, 50), 500))
+        el = float(np.median([max_over_ranks(t) for t in r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier, 3)]))
+        km = r2.kernel_ms(200, prewarm=200)["median"]
         rows = float(r2.n) * world
         del r2
         torch.cuda.empty_cache()
@@ -886,6 +1049,7 @@ def main():
             if collide and d <= 12 and W >= 2:
                 siblings["neighbour_stages"] = measure_neighbour_stages(robot, run, W, d, device)
 
+    census = device_census(dist, rank, dev_index) if not share_gpu else None
     if rank == 0:
         iters = float(n) * K * args.steps * world
         alg_flops = n * (K * algorithmic_flops_per_row_iter(d)
@@ -894,7 +1058,11 @@ def main():
         t_k = kernel_ms * 1e-3
         alg_tflops = alg_flops / t_k / 1e12
         ach_gbps = bytes_launch / t_k / 1e9
-        rec = issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs) if args.solver == "f32" else None
+        build_id = _hip.lib().cppf_build_id().decode()
+        rec, rec_why = (issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs, build_id) if args.solver == "auto"
+                        else (None, "no record for this solver"))
+        kname = "lm_fused_kernel" if shape != _hip.SHAPE_QUAD else "lm_quad_kernel"
+        kprof, kprof_why = kernel_profile_from_profiles(f"{kname}<cppf::StaRobot<cppf::gen::{''.join(p.capitalize() for p in args.robot.split('_'))}>, {1 if collide else 0}", build_id)
         roof = {
             # the binding resource is the fp32 VALU issue rate (157.3 TFLOP/s of FMAs = one wave-instruction per SIMD per 2
             # cycles); the contract's vocabulary has no word for it, so `bound` says what it is and `mfma_used` that no
@@ -903,15 +1071,23 @@ def main():
             "mfma_used": False,
             "peak": F32_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "kernel": "lm_fused_kernel" if shape != _hip.SHAPE_QUAD else "lm_quad_kernel",
+            "kernel": kname,
             "kernel_ms": kernel_ms,
+            "kernel_ms_how": f"median of {kstats['n']} isolated launches (HIP events on the launch stream, one in flight) after a pre-warm",
+            "kernel_ms_stats": kstats,
+            # the same kernel's average duration in the committed `rocprofv3 --kernel-trace --stats` summary of this command
+            # (profiles/r3_fused_kernel_stats.csv), when that summary was taken with this build of the library
+            "kernel_ms_profile": kprof["ms"] if kprof else None,
+            "kernel_profile": kprof if kprof else {"unavailable": kprof_why},
+            "drift": (kernel_ms / kprof["ms"]) if kprof else None,
+            "library_build_id": build_id,
             "algorithmic": {
                 "tflops": alg_tflops,
                 "frac": alg_tflops / F32_PEAK_TFLOPS,
                 "note": "SURVEY 8d flop model (primal J^T J + d^3/3 Cholesky, every collision test counted) / kernel time: "
                 "what the reference's formulation would need, NOT what this kernel executes (dual 6x6 solve, broad-phase culls)",
             },
-            "traffic": traffic_from_profiles(args.robot, run.S, W, K, collide),
+            "traffic": traffic_from_profiles(args.robot, run.S, W, K, collide, build_id),
             "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
         }
         if rec is not None:
@@ -921,7 +1097,7 @@ def main():
             roof.update({
                 "achieved": exe_tflops,
                 "frac": exe_tflops / F32_PEAK_TFLOPS,
-                "basis": "executed flops: SQ_INSTS_VALU of the matching launch (profiles/r2_issue.json) x 64 lanes x flops per VALU "
+                "basis": "executed flops: SQ_INSTS_VALU of the matching launch (profiles/r3_issue.json, same library build) x 64 lanes x flops per VALU "
                 "lane-op from the kernel's ISA (FMA = 2, mul / add = 1, moves / selects / compares = 0), / live kernel time",
                 "valu_issue_frac": issue_s / t_k,
                 "valu_issue_frac_at_step_rate": issue_s / (elapsed / args.steps),
@@ -931,9 +1107,12 @@ def main():
             roof.update({
                 "achieved": alg_tflops if capped <= 1.0 else None,
                 "frac": capped if capped <= 1.0 else None,
-                "basis": "algorithmic flop model (no SQ_INSTS_VALU record for this workload under profiles/)"
+                "basis": f"algorithmic flop model ({rec_why})"
                 + ("" if capped <= 1.0 else "; the model counts collision tests the broad phase skips, so the fraction would exceed 1 and is withheld"),
             })  # fmt: skip
+        if kprof and abs(kernel_ms / kprof["ms"] - 1.0) > 0.15:
+            print(f"bench: WARNING: live kernel time {1e3 * kernel_ms:.1f} us differs from the committed rocprofv3 average "
+                  f"{1e3 * kprof['ms']:.1f} us by more than 15 % (drift {kernel_ms / kprof['ms']:.2f})", file=sys.stderr)
         roof["at_step_rate"] = {
             "ms_per_step": 1e3 * elapsed / args.steps,
             "batches_in_flight": run.n_streams,
@@ -959,10 +1138,15 @@ def main():
                 + (" + self/env collision masks + jlim mask + search cost" if collide else " (FK+Jacobian+LM only)"),
                 "inputs": inputs_desc,
                 "streams": run.n_streams,
+                "timed_region": {"repeats": len(reps_s), "reported": "median", "ms_per_step_min": 1e3 * min(reps_s) / args.steps,
+                                 "ms_per_step_max": 1e3 * max(reps_s) / args.steps,
+                                 "ms_per_step_all": [1e3 * t / args.steps for t in reps_s]},
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 "hip_graphs": (f"on: each stream's {run.G} consecutive steps replayed as one captured graph" if run.graphs is not None else "off (one host call per step)"),
                 "kernel_shape": args.shape,
-                "solver": args.solver + (" (the reference's dtype)" if args.solver == "f32" else " (J J^T, factorisation, substitutions, J^T y in double precision)"),
+                "solver": {"auto": "auto: fp32 (the reference's dtype) + conditioning-gated double-precision redo of the rows whose estimated "
+                                   "task-space error exceeds 1e-5 (cppf_lm_params.solver = CPPF_SOLVER_AUTO, the default)",
+                           "f32": "f32, no gate", "f64": "f64: every row in double precision"}[args.solver],
                 "early_out": "off (every row runs all K iterations: the metric counts K iterations per row)",
                 "prewarm_ms": args.prewarm_ms,
                 "host_enqueue_us_per_step": host_us,
@@ -990,7 +1174,18 @@ def main():
         }
         if plan_search is not None:
             line["plan_search"] = plan_search
+        if rccl_rec is not None:
+            line["rccl"] = dict(rccl_rec, ranks=census)
+        elif census is not None:
+            line["devices"] = census
+        if selection_check is not None:
+            line["selection_check"] = selection_check
         line.update(siblings)
+        if "weak_scaling" in siblings and world > 1:
+            # what ONE GPU of this run does with the whole N = 1 workload (S_cfg seeds): comparable with the N = 1 BENCH record
+            w = siblings["weak_scaling"]
+            line["n1_equivalent"] = {"value": w["value"] / world, "ms_per_step": w["ms_per_step"],
+                                     "how": f"the weak-scaling sibling ({S_cfg} seeds on every GPU, the N = 1 workload) divided by {world}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_torch(args.robot, obstacles, d, W, K)
             line["cpu_baseline_c"] = cpu_baseline_c(args.robot, obstacles, d, W, K)

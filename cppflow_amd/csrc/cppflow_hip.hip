@@ -16,13 +16,16 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
+#include "../../include/cppflow_hip_debug.h"
 #include "lmik_device.h"
 #include "robots_gen.h"
 
@@ -90,7 +93,19 @@ struct cppf_robot {
     size_t lds_bytes;  // generic path only: capsule end points, 6 floats per capsule per lane
     void* d_quad;      // device: QuadPairRec[CPPF_MAX_PAIRS] then QuadCapRec[CPPF_MAX_CAPSULES] (quad shape's striped collision stage)
     RtcModule* rtc;    // kernels compiled for this description by cppf_robot_specialize (hipRTC), else NULL
+    // Test / tuning switches of THIS handle (cppf_debug_set, include/cppflow_hip_debug.h): no process-wide dispatch state, two
+    // handles on two threads can hold different settings.  Atomics: a setter may race with a launch on another thread.
+    mutable std::atomic<int> tune[CPPF_TUNE_COUNT];
 };
+
+namespace {
+// defaults of the switches (the measured crossovers; see include/cppflow_hip_debug.h)
+constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
+    /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
+    /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
+};
+inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
+}  // namespace
 
 #include "rtc_specialize.h"
 
@@ -177,7 +192,7 @@ int find_static_robot(const cppf_robot_desc& d) {
     } break;
 
 #define CPPF_DISPATCH_RB(robot)                                                                                       \
-    if ((robot)->static_id >= 0 && !g_force_generic) {                                                                \
+    if ((robot)->static_id >= 0 && !tune((robot), CPPF_TUNE_FORCE_GENERIC)) {                                                                \
         switch ((robot)->static_id) { CPPF_FOR_EACH_STATIC_ROBOT(CPPF_STATIC_CASE) default: break; }                  \
     } else {                                                                                                          \
         switch ((robot)->desc.ndof) {                                                                                 \
@@ -189,28 +204,17 @@ int find_static_robot(const cppf_robot_desc& d) {
             case 8: { using RB = DynRobot<8>; CPPF_BODY; } break;                                                     \
             case 9: { using RB = DynRobot<9>; CPPF_BODY; } break;                                                     \
             case 10: { using RB = DynRobot<10>; CPPF_BODY; } break;                                                   \
+            case 11: { using RB = DynRobot<11>; CPPF_BODY; } break;                                                   \
             case 12: { using RB = DynRobot<12>; CPPF_BODY; } break;                                                   \
-            default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {3..10, 12}");     \
+            default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in 3..12");     \
         }                                                                                                             \
     }
 
-int g_quad_max_rows = 16384;    // CPPF_SHAPE_AUTO: four lanes per row up to this many rows = one wavefront per SIMD (measured: beyond
-                                // that the shape's extra wavefronts cost more than its shorter ones save), one row per lane beyond
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
-int g_occ4_min_rows = 131072;  // fused masks-only fp32 launch: the 128-VGPR instantiation from this many rows up (see kernels_fused.h)
-bool g_rows_pose = false;      // coupled step WITH the pose block through the row-per-lane kernels too (cppf_debug_set_rows_pose)
-bool g_pcr_split = true;       // ... and two half-workgroups per waypoint (cppf_debug_set_pcr_lds(2) / (1) toggles it)
-bool g_pcr_lds = true;         // coupled step, parallel-in-time form, W <= 256: the state in LDS instead of the workspace (cppf_debug_set_pcr_lds)
-bool g_full_rows = true;       // coupled step, d <= 8: eight trajectories per wavefront, one row per lane (DPP) instead of one
-                               // wavefront per trajectory (ds_bpermute); cppf_debug_set_full_rows
-bool g_dp_persistent = true;    // dp_search: the whole recurrence in one resident launch (k <= 256, the measured range in which it wins), else one launch per waypoint
-bool g_quad_mfma = false;       // J J^T of the quad shape by v_mfma_f32_4x4x1 (robot-specialised instantiations only)
-bool g_force_generic = false;  // test hook (cppf_debug_force_generic): run the generic kernels even for shipped robots
 // coupled step: parallel-in-time elimination up to this many (trajectory, waypoint) rows -- the measured crossovers with the
 // two-ended row-per-lane kernels at d <= 7 (x 0.5 at d = 8): 512 trajectories x 256 waypoints with the state in LDS (W <= 256: one
 // workgroup per compute unit, so the time steps up at every multiple of 256 trajectories), 192 x 256 with the state in the workspace
 constexpr int kPcrMaxRowsLds = 131072, kPcrMaxRowsGlobal = 49152;
-int g_pcr_max_rows = -1;  // < 0: the defaults above
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -223,14 +227,15 @@ int g_pcr_max_rows = -1;  // < 0: the defaults above
         case 8: { constexpr int D = 8; __VA_ARGS__; } break;                                                  \
         case 9: { constexpr int D = 9; __VA_ARGS__; } break;                                                  \
         case 10: { constexpr int D = 10; __VA_ARGS__; } break;                                                \
+        case 11: { constexpr int D = 11; __VA_ARGS__; } break;                                                \
         case 12: { constexpr int D = 12; __VA_ARGS__; } break;                                                \
-        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in {3..10, 12}");  \
+        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in 3..12");  \
     }
 
 // launch one of the run-time-specialised kernels of a handle (same argument lists as the compiled-in instantiations)
 int rtc_launch(const cppf_robot* rb, RtcKernel which, unsigned grid, size_t lds, hipStream_t st, void** args);
 
-inline bool use_rtc(const cppf_robot* rb) { return rb->rtc != nullptr && !g_force_generic; }
+inline bool use_rtc(const cppf_robot* rb) { return rb->rtc != nullptr && !tune(rb, CPPF_TUNE_FORCE_GENERIC); }
 
 int check_launch(const cppf_robot* rb) {
     CPPF_HIP(hipGetLastError());
@@ -268,6 +273,19 @@ struct DeviceGuard {
 }  // namespace
 
 namespace {
+// cppf_debug_rcp_sweep: rcp_rn (lmik_device.h) against the correctly rounded division, bit for bit, by biased exponent
+__global__ __launch_bounds__(kBlock) void rcp_sweep_kernel(uint64_t first, uint64_t count, unsigned long long* mism) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = (uint32_t)(first + i);
+        const float x = __uint_as_float(bits);
+        const float want = fabsf(x) >= 0x1p-100f ? 1.0f / x : 0.f;  // IEEE division (-fhip-fp32-correctly-rounded-divide-sqrt)
+        const float got = rcp_rn(x);
+        const bool both_nan = want != want && got != got;
+        if (!both_nan && __float_as_uint(want) != __float_as_uint(got)) atomicAdd(&mism[(bits >> 23) & 0xffu], 1ull);
+    }
+}
+
 int rtc_launch(const cppf_robot* rb, RtcKernel which, unsigned grid, size_t lds, hipStream_t st, void** args) {
     hipFunction_t f = rb->rtc->fn[which];
     if (!f) return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: this kernel is not part of the handle's specialised module");
@@ -329,6 +347,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     if (!rb) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
     rb->desc = *desc;
     rb->device = device;
+    for (int k = 0; k < CPPF_TUNE_COUNT; ++k) rb->tune[k].store(kTuneDefaults[k], std::memory_order_relaxed);
     std::memset(&rb->chain, 0, sizeof(ChainK));
     std::memset(&rb->coll, 0, sizeof(CollK));
     rb->chain.ndof = d;
@@ -456,6 +475,18 @@ int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
 
 int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
 
+int cppf_debug_rcp_sweep(int device, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream) {
+    CPPF_REQUIRE(mismatches, "mismatches is NULL");
+    CPPF_REQUIRE(first <= (1ull << 32) && count <= (1ull << 32) - first, "first + count exceeds 2^32 bit patterns");
+    if (count == 0) return CPPF_OK;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the device failed: ") + hipGetErrorString(guard.err));
+    hipLaunchKernelGGL(rcp_sweep_kernel, dim3(4096), dim3(kBlock), 0, (hipStream_t)stream, first, count,
+                       reinterpret_cast<unsigned long long*>(mismatches));
+    CPPF_HIP(hipGetLastError());
+    return CPPF_OK;
+}
+
 int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir) {
     cppf_robot* rb = nullptr;
     if (int rc = cppf_robot_create(desc, kNoDevice, &rb)) return rc;
@@ -472,23 +503,19 @@ int cppf_robot_specialization(const cppf_robot* robot) {
     return robot->static_id >= 0 ? robot->static_id : (robot->rtc ? CPPF_SPECIALIZATION_RTC : -1);
 }
 
-void cppf_debug_force_generic(int on) { g_force_generic = on != 0; }
+int cppf_debug_set(cppf_robot* robot, int key, int value) {
+    CPPF_REQUIRE(robot, "robot handle is NULL");
+    CPPF_REQUIRE(key >= 0 && key < CPPF_TUNE_COUNT, "unknown tuning key");
+    robot->tune[key].store(value == CPPF_TUNE_DEFAULT ? kTuneDefaults[key] : value, std::memory_order_relaxed);
+    return CPPF_OK;
+}
 
-void cppf_debug_set_pcr_max_rows(int n) { g_pcr_max_rows = n < 0 ? -1 : n; }
-
-void cppf_debug_set_quad_max_rows(int n) { g_quad_max_rows = n; }
-
-void cppf_debug_set_dp_persistent(int on) { g_dp_persistent = on != 0; }
-
-void cppf_debug_set_full_rows(int on) { g_full_rows = on != 0; }
-
-void cppf_debug_set_occ_min_rows(int n) { g_occ4_min_rows = n < 0 ? 131072 : n; }
-
-void cppf_debug_set_pcr_lds(int on) { g_pcr_lds = on != 0, g_pcr_split = on != 1; }
-
-void cppf_debug_set_rows_pose(int on) { g_rows_pose = on != 0; }
-
-void cppf_debug_set_quad_mfma(int on) { g_quad_mfma = on != 0; }
+int cppf_debug_get(const cppf_robot* robot, int key, int* value) {
+    CPPF_REQUIRE(robot && value, "robot / value is NULL");
+    CPPF_REQUIRE(key >= 0 && key < CPPF_TUNE_COUNT, "unknown tuning key");
+    *value = tune(robot, key);
+    return CPPF_OK;
+}
 
 int cppf_set_obstacles(cppf_robot* robot, int n_obs, const float* cuboids, const float* Rt) {
     CPPF_REQUIRE(robot, "robot handle is NULL");
@@ -581,10 +608,27 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     if (n == 0) return CPPF_OK;
     CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
     CPPF_REQUIRE(x_in && target, "x_in / target is NULL");
+    CPPF_REQUIRE(params->alpha_position > 0.f && params->alpha_rotation > 0.f, "alpha_position / alpha_rotation must be > 0");
+    CPPF_REQUIRE(params->solver == CPPF_SOLVER_AUTO || params->solver == CPPF_SOLVER_F32 || params->solver == CPPF_SOLVER_F64,
+                 "unknown solver");
+    CPPF_REQUIRE(params->solver_gate >= 0.f, "solver_gate must be >= 0 (0 = the default tolerance)");
     LmK prm;
     prm.lm_lambda = params->lm_lambda;
     prm.a_pos = params->alpha_position;
     prm.a_rot = params->alpha_rotation;
+    // the damping per row of the dual system (kernels_chain.h), formed once here instead of by every wavefront
+    prm.lam_r_d = (double)params->lm_lambda / ((double)params->alpha_rotation * (double)params->alpha_rotation);
+    prm.lam_p_d = (double)params->lm_lambda / ((double)params->alpha_position * (double)params->alpha_position);
+    prm.lam_r = (float)prm.lam_r_d;
+    prm.lam_p = (float)prm.lam_p_d;
+    // conditioning gate (lm_solve_gated): redo a row's solve in double precision when eps * a_max * max diag(A) * max |y| > tau
+    {
+        const float tau = params->solver_gate > 0.f ? params->solver_gate : CPPF_SOLVER_GATE_DEFAULT;
+        const float a_max = std::fmax(params->alpha_position, params->alpha_rotation);
+        prm.gate_thr = params->solver == CPPF_SOLVER_F32 ? INFINITY
+                       : params->solver == CPPF_SOLVER_F64 ? -INFINITY
+                                                           : tau / (6e-8f * a_max);
+    }
     prm.n_steps = params->n_steps;
     prm.clamp = params->clamp;
     prm.n = (int)n;
@@ -614,17 +658,13 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                                   out->env_mask && out->jlim_mask && out->ext_cost));
     CPPF_REQUIRE(params->shape == CPPF_SHAPE_AUTO || params->shape == CPPF_SHAPE_ROW || params->shape == CPPF_SHAPE_QUAD,
                  "unknown kernel shape");
-    CPPF_REQUIRE(params->solver == CPPF_SOLVER_F32 || params->solver == CPPF_SOLVER_F64, "unknown solver");
-    CPPF_REQUIRE(!(params->solver == CPPF_SOLVER_F64 && params->shape == CPPF_SHAPE_QUAD),
-                 "CPPF_SOLVER_F64 is built for the row shape");
     CPPF_REQUIRE(params->shape != CPPF_SHAPE_QUAD || quad_can,
                  "CPPF_SHAPE_QUAD needs ndof >= 6, no J_out / e_out / min_self / min_env, and (with seed_summary) every per-row output");
     // AUTO: the quad shape when the batch is at most one of its wavefronts per SIMD AND no per-seed summary is asked for (in
     // this shape a seed's rows span several workgroups, so the summary needs the separate reduction launch, which costs more
     // than the shape saves: measured 28.5 against 26.2 us for K = 10 + collision + summary at <= 16 384 rows)
     const bool quad = params->shape == CPPF_SHAPE_QUAD ||
-                      (params->shape == CPPF_SHAPE_AUTO && quad_can && !out->seed_summary && n <= (size_t)g_quad_max_rows &&
-                       params->solver == CPPF_SOLVER_F32);
+                      (params->shape == CPPF_SHAPE_AUTO && quad_can && !out->seed_summary && n <= (size_t)tune(robot, CPPF_TUNE_QUAD_MAX_ROWS));
     if (quad) {
         cppf_lm_outputs oq = *out;
         oq.seed_summary = nullptr;  // rows of a seed span several workgroups in this shape: the reduction kernel follows
@@ -633,7 +673,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                                      (size_t)kQuadRows * quad_row_stride(robot->coll.ncaps))
                                   : 0;
         const uint4* tab = static_cast<const uint4*>(robot->d_quad);
-        const bool mfma = g_quad_mfma && robot->static_id >= 0 && !g_force_generic;
+        const bool mfma = tune(robot, CPPF_TUNE_QUAD_MFMA) && robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC);
         if (use_rtc(robot) && robot->rtc->fn[RTC_QUAD0]) {
             void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&oq, (void*)&tab};
             if (int rc = rtc_launch(robot, coll ? RTC_QUAD1 : RTC_QUAD0, grid, lds_q, st, args)) return rc;
@@ -675,40 +715,27 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                      oq.jlim_mask, summary_dst, stream);
         return CPPF_OK;
     }
-    const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
-    const bool f64 = params->solver == CPPF_SOLVER_F64;
-    if (use_rtc(robot) && !f64) {
+    const size_t lds = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
+    if (use_rtc(robot)) {
         void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)out};
         const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
         if (int rc = rtc_launch(robot, which, grid_for(n), 0, st, args)) return rc;
     } else if (coll && (out->min_self || out->min_env)) {
-        CPPF_REQUIRE(!f64, "CPPF_SOLVER_F64 is built for the launches without min_self / min_env");
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
                        prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else if (coll) {
-#define CPPF_BODY                                                                                                          \
-    if (f64)                                                                                                               \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, true>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain,          \
-                           robot->coll, prm, x_in, target, *out);                                                          \
-    else if (n >= (size_t)g_occ4_min_rows) /* >= 2 wavefronts per SIMD: the 128-VGPR build (168 beyond 8 joints) */          \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 1, false, (RB::D <= 8 ? 4 : 3)>), dim3(grid_for(n)), dim3(kBlock), lds, st, \
-                           robot->chain, robot->coll, prm, x_in, target, *out);                                            \
-    else                                                                                                                   \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll,   \
-                           prm, x_in, target, *out)
+#define CPPF_BODY                                                                                                 \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
+                       prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else {
-#define CPPF_BODY                                                                                                          \
-    if (f64)                                                                                                               \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 0, true>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain,            \
-                           robot->coll, prm, x_in, target, *out);                                                          \
-    else                                                                                                                   \
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll,     \
-                           prm, x_in, target, *out)
+#define CPPF_BODY                                                                                               \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
+                       prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     }
@@ -728,7 +755,7 @@ int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, 
     CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
     CPPF_REQUIRE(q, "q is NULL");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (robot->static_id >= 0 && !g_force_generic) ? 0 : robot->lds_bytes;
+    const size_t lds = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
     if (use_rtc(robot)) {
         int n_i = (int)n;
         void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&n_i, (void*)&q, (void*)&self_mask, (void*)&env_mask,
@@ -934,7 +961,10 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.S = S;
     prm.W = W;
     // which elimination kernel: see the comments at the launches below
-    const size_t pcr_rows = g_pcr_max_rows >= 0 ? (size_t)g_pcr_max_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
+    const int t_pcr_rows = tune(robot, CPPF_TUNE_PCR_MAX_ROWS), t_pcr_lds = tune(robot, CPPF_TUNE_PCR_LDS);
+    const bool g_pcr_lds = t_pcr_lds != 0, g_pcr_split = t_pcr_lds != 1;
+    const bool g_rows_pose = tune(robot, CPPF_TUNE_ROWS_POSE) != 0, g_full_rows = tune(robot, CPPF_TUNE_FULL_ROWS) != 0;
+    const size_t pcr_rows = t_pcr_rows >= 0 ? (size_t)t_pcr_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
     const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 50) / 100;
     const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
     const bool use_rows = !use_pcr && (!prm.use_pose || g_rows_pose) && g_full_rows && robot->desc.ndof >= 3 &&
@@ -1066,7 +1096,7 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     hipStream_t st = (hipStream_t)stream;
     const int d = robot->desc.ndof;
     const size_t total = (size_t)k * T * d;
-    const bool persistent = g_dp_persistent && k <= 256 && T >= 2;
+    const bool persistent = tune(robot, CPPF_TUNE_DP_PERSISTENT) && k <= 256 && T >= 2;
     if (persistent)  // every cost word starts as "not yet" (kernels_dp.h); 16-byte multiple, from the allocation's start
         CPPF_HIP(hipMemsetAsync(work_costsT, 0xFF, sizeof(float) * (size_t)k * T, st));
     hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
@@ -1172,9 +1202,11 @@ struct RcclApi {
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
-RcclApi g_rccl;
+RcclApi g_rccl;      // (the communicator's side of the library: the one piece of process-wide state)
+std::mutex g_rccl_mu;  // two threads may create their communicators at the same time
 
 int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.handle) return CPPF_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
@@ -1213,6 +1245,8 @@ struct cppf_comm {
     RcclComm comm;
     int rank, world, device;
 };
+
+int cppf_comm_available(void) { return load_rccl(); }
 
 int cppf_comm_unique_id(void* id_out) {
     CPPF_REQUIRE(id_out, "id_out is NULL");

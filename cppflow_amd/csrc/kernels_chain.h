@@ -166,16 +166,17 @@ __device__ __forceinline__ void pose_metrics(const float (&Rt)[9], const float (
 // (optimization.py:77-80) and solves (Js^T Js + lambda I) delta = Js^T es; here the scaling is folded into the 6x6 system:
 //     A = S (J J^T) S + lambda I,   A y = S e,   delta = J^T (S y)
 // (21 + 6 + 6 multiplies instead of 6 d + 6), identical in exact arithmetic.  J and e are left UNscaled.
+// `est` = max diag(A) * max |y|: the a-posteriori size of the rounding error of this fp32 solve in task space, up to the factor
+// eps * a_max (lm_solve_gated).
 template <int D>
-__device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
-                                              float a_rot, float (&delta)[D]) {
+__device__ __forceinline__ void lm_dual_solve_y(const float (&J)[6][D], const float (&e)[6], float lam_r, float lam_p,
+                                                float (&y)[6], float& est) {
     // With S = diag(a_rot x3, a_pos x3):  Js^T (Js Js^T + lambda I)^-1 es  =  J^T (J J^T + lambda S^-2)^-1 e,  so the row
     // scaling never has to be applied: it only changes the damping per row (lambda / a^2).  Cholesky A = L L^T with
     // reciprocal pivots and the damping as pivot floor (every exact pivot of A is >= its smallest eigenvalue >= the
     // smallest damping term, so the floor only acts on rounding noise).
-    // wave-uniform, once per launch
-    const float lam_r = lambda * __builtin_amdgcn_rcpf(a_rot * a_rot), lam_p = lambda * __builtin_amdgcn_rcpf(a_pos * a_pos);
-    float L[6][6], inv[6];
+    // (lam_r = lambda / a_rot^2, lam_p = lambda / a_pos^2: LmK, formed by the host)
+    float L[6][6], inv[6], dmax = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const float lam = j < 3 ? lam_r : lam_p;
@@ -184,6 +185,7 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
             float s = (i == j) ? lam : 0.f;
 #pragma unroll
             for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
+            if (i == j) dmax = fmaxf(dmax, s);  // A[j][j], before the elimination terms
 #pragma unroll
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
             if (i == j) {
@@ -195,7 +197,6 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
             }
         }
     }
-    float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         float s = e[i];
@@ -210,6 +211,12 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
         for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
         y[i] = s * inv[i];
     }
+    est = dmax * fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))), fmaxf(fabsf(y[4]), fabsf(y[5])));
+}
+
+// delta = J^T y, the second half of the dual solve
+template <int D>
+__device__ __forceinline__ void lm_dual_apply(const float (&J)[6][D], const float (&y)[6], float (&delta)[D]) {
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         float s = 0.f;
@@ -217,6 +224,14 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
         for (int i = 0; i < 6; ++i) s = CPPF_FMA(J[i][k], y[i], s);
         delta[k] = s;
     }
+}
+
+template <int D>
+__device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const float (&e)[6], float lam_r, float lam_p,
+                                              float (&delta)[D], float& est) {
+    float y[6];
+    lm_dual_solve_y<D>(J, e, lam_r, lam_p, y, est);
+    lm_dual_apply<D>(J, y, delta);
 }
 
 // The same dual solve with everything after the Jacobian in fp64 (cppf_lm_params.solver = CPPF_SOLVER_F64).  In fp32 the step is
@@ -228,9 +243,8 @@ __device__ __forceinline__ void lm_dual_solve(const float (&J)[6][D], const floa
 // ALL rows.  It needs A (21 sums), the factorisation, the BACK substitution and J^T y in fp64 (measured: leaving any of them in
 // fp32 gives the fp32 tail back); ~300 v_fma_f64 at half the fp32 rate plus 84 conversions: ~1.5x the iteration time.
 template <int D>
-__device__ __forceinline__ void lm_dual_solve_f64(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos,
-                                                  float a_rot, float (&delta)[D]) {
-    const double lam_r = (double)lambda / ((double)a_rot * (double)a_rot), lam_p = (double)lambda / ((double)a_pos * (double)a_pos);
+__device__ __forceinline__ void lm_dual_solve_f64(const float (&J)[6][D], const float (&e)[6], double lam_r, double lam_p,
+                                                  float (&delta)[D]) {
     double A[6][6];  // lower triangle
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -335,15 +349,142 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
     }
 }
 
-template <int D, bool F64 = false>
-__device__ __forceinline__ void lm_solve(const float (&J)[6][D], const float (&e)[6], float lambda, float a_pos, float a_rot,
-                                         float (&delta)[D]) {
-    if constexpr (D < 6)
-        lm_primal_solve<D>(J, e, lambda, a_pos, a_rot, delta);
-    else if constexpr (F64)
-        lm_dual_solve_f64<D>(J, e, lambda, a_pos, a_rot, delta);
-    else
-        lm_dual_solve<D>(J, e, lambda, a_pos, a_rot, delta);
+// ---- the conditioning-gated damped solve (cppf_lm_params.solver = CPPF_SOLVER_AUTO, the default) -------------------------------
+// The task-space error of the fp32 dual solve is E y with E the rounding error of forming / factoring A = J J^T + lambda S^-2,
+// |E| ~ eps |A|: it is  ~ eps * a_max * max diag(A) * max |y|  (measured: the true error is 0.2x that in the median, <= 3x over
+// 16 384 random rows of the four robots), known only AFTER the fp32 solve because |y| = |A^-1 e| is what blows up
+// on a near-singular row whose residual has a component in the weak direction.  A row whose estimate exceeds tau (1e-5 by
+// default, in the scaled task-space units of the residual) redoes the solve in double precision.  gate_thr = tau / (eps a_max)
+// is formed by the host; +inf gives the pure fp32 solve, -inf the pure fp64 one.  Fewer than 6 joints: the primal fp32 solve.
+//
+// Row-per-lane kernels: the double-precision solve must not cost the hot path a register (inlined next to the fp32 solve it
+// takes the kernel from 115 to 232 VGPRs; capped at 128 the compiler spills 83 registers INSIDE the LM loop).  So the flagged
+// lanes of a wavefront hand their J and e to up to kGateSlots LDS slots of their wavefront, and lanes 0 .. n-1 of the same
+// wavefront solve one slot each reading J from LDS (twice: forming A, then J^T y), so the solver holds only L, the pivots and y
+// besides its own row's state.  Everything stays inside one wavefront: no barrier, LDS accesses of a wavefront complete in
+// order.  On a planner's inputs 17 % of the wavefronts take the detour in the first iteration and <= 3 % later (bench.py's C4
+// workload, scripts/gate_census.py); independent random configurations (13 % of the rows flagged at first) are the worst case.
+constexpr int kGateSlots = 16;
+template <int D>
+struct GateLds {
+    static constexpr int kFloats = (6 * D + 6) * kGateSlots;  // per wavefront: slot s, element i at [i * kGateSlots + s]
+};
+
+// solve slot `s` (J [6][D] at elements i * D + k, e at 6 D + i) in double precision; delta [D] comes back in elements 0 .. D-1.
+// The two passes over J are ROLLED loops over the joints (6 LDS reads per trip): unrolled, the compiler issues all 6 D reads up
+// front and the conversions of the first pass stay alive for the second -- 188 VGPRs for the kernel instead of < 128.
+template <int D>
+__device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, double lam_r, double lam_p) {
+    float* const ws = w + s;
+    double A[6][6];  // lower triangle; L overwrites it
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[i][j] = (i == j) ? (i < 3 ? lam_r : lam_p) : 0.0;
+    float nx[6];  // the next column of J, requested one trip ahead (a lone wavefront: the LDS latency is otherwise paid D times)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D) * kGateSlots];
+#pragma unroll 1
+    for (int k = 0; k < D; ++k) {
+        double c[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c[i] = (double)nx[i];
+        const int kn = k + 1 < D ? k + 1 : k;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D + kn) * kGateSlots];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) A[i][j] = __builtin_fma(c[i], c[j], A[i][j]);
+    }
+    double inv[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const double lam = j < 3 ? lam_r : lam_p;
+#pragma unroll
+        for (int i = j; i < 6; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t = __builtin_fma(-A[i][k], A[j][k], t);
+            if (i == j) {
+                t = t > lam ? t : lam;
+                double r = __builtin_amdgcn_rsq(t);  // v_rsq_f64 (~2^-26), two Newton steps on r = t^-1/2
+                r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
+                r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
+                inv[j] = r;
+            } else {
+                A[i][j] = t * inv[j];
+            }
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double t = (double)ws[(6 * D + i) * kGateSlots];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t = __builtin_fma(-A[i][k], y[k], t);
+        y[i] = t * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double t = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-A[k][i], y[k], t);
+        y[i] = t * inv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D) * kGateSlots];
+#pragma unroll 1
+    for (int k = 0; k < D; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t = __builtin_fma((double)nx[i], y[i], t);
+        const int kn = k + 1 < D ? k + 1 : k;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D + kn) * kGateSlots];  // (column k + 1 is read before element k is written)
+        ws[k * kGateSlots] = (float)t;  // element k = J[0][k]: read one trip ago, never again
+    }
+}
+
+// One round of the gate, in two halves.  `todo` = ballot of `flag`, non-zero; must be called by every active lane of the wavefront;
+// `w`: this wavefront's GateLds<D>::kFloats floats of LDS.
+// lm_gate_hand_over: up to kGateSlots of the wavefront's flagged rows write J and e to their slot.  Called BETWEEN the two halves of
+// the fp32 solve (y is known, so is the estimate; J^T y is still to come), so that J is not kept in registers a moment longer than
+// the fp32 solve itself needs it.  A wavefront with more flagged rows than slots comes back for another round with J recomputed
+// (lm_row_iterate) rather than parking 48 floats per row in registers meanwhile.
+// lm_gate_solve: lanes 0 .. cnt-1 solve one slot each in double precision; the flagged rows pick their delta up and clear `flag`.
+template <int D>
+__device__ __forceinline__ int lm_gate_hand_over(const float (&J)[6][D], const float (&e)[6], unsigned long long todo,
+                                                 float* __restrict__ w, bool flag) {
+    // rank of this lane among the flagged lanes
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
+    if (flag && rank < kGateSlots) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) w[(i * D + k) * kGateSlots + rank] = J[i][k];
+            w[(6 * D + i) * kGateSlots + rank] = e[i];
+        }
+    }
+    return rank;
+}
+
+template <int D>
+__device__ __forceinline__ void lm_gate_solve(double lam_r, double lam_p, unsigned long long todo, int rank,
+                                              float* __restrict__ w, bool& flag, float (&delta)[D]) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int cnt = min((int)__builtin_popcountll(todo), kGateSlots);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are written (one wavefront: its LDS accesses complete in order)
+    // The solvers are the first `cnt` lanes that entered this call (a prefix of the wavefront's active lanes, whose rows are
+    // consecutive), not necessarily flagged themselves.
+    if (lane < cnt) gate_solve_slot<D>(w, lane, lam_r, lam_p);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (flag && rank < kGateSlots) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) delta[k] = w[k * kGateSlots + rank];
+        flag = false;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read back before a later round's writes
 }
 
 template <class RB>

@@ -118,32 +118,81 @@ __device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restr
 // One LM iteration of one row.  Returns true when the row was ALREADY converged at this linearisation point (early-out
 // tolerances of cppf_lm_params, off when 0): such a row is left untouched -- the reference's loop likewise stops stepping
 // once the pose is valid (cppflow/optimization.py:251-258, 326-358).
-template <class RB, bool F64>
+// The damped solve is conditioning-gated (kernels_chain.h): a row whose fp32 solve is estimated to be off by more than the gate's
+// tolerance is re-solved in double precision by a lane of its own wavefront through an LDS slot.  The common case -- no row of
+// the wavefront flagged -- is straight-line code behind ONE scalar branch.  Inside a clamped loop (K > 1) a row whose fp32 step
+// leaves the joint limits is not re-solved: where it lands is decided by the clamp, not by the last digits of the solve (these
+// are the rows that sit against a limit iteration after iteration; re-solving them bought nothing and put one wavefront per
+// such row 2 us per iteration behind the others).  The single bare step (clamp = 0, the reference's own cadence) re-solves every
+// flagged row.
+template <class RB>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
-                                               const float (&Rt)[9], const float (&tt)[3], float (&q)[RB::D]) {
+                                               const float (&Rt)[9], const float (&tt)[3], float* __restrict__ gate_lds,
+                                               float (&q)[RB::D]) {
     constexpr int D = RB::D;
-    float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6], delta[D];
-    fk_ee_axes<RB>(rb, q, R, p, ax, og);
-    pose_error(Rt, tt, R, p, e);
+    float delta[D];
     bool conv = false;
-    if (prm.tol_pos2 > 0.f) {  // wave-uniform
-        conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
-        if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
-    }
-    jacobian_from_axes<RB>(rb, p, ax, og, J);
-    lm_solve<D, F64>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
-    if (last) {
-        // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
-        if (out.J_out) {
-            float* Jo = out.J_out + row * 6 * D;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
+    {
+        float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6];
+        fk_ee_axes<RB>(rb, q, R, p, ax, og);
+        pose_error(Rt, tt, R, p, e);
+        if (prm.tol_pos2 > 0.f) {  // wave-uniform
+            conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
+            if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
         }
-        if (out.e_out) {
+        jacobian_from_axes<RB>(rb, p, ax, og, J);
+        float est = 0.f;
+        if constexpr (D < 6) {
+            lm_primal_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
+        } else {
+            float y[6];
+            lm_dual_solve_y<D>(J, e, prm.lam_r, prm.lam_p, y, est);
+            lm_dual_apply<D>(J, y, delta);
+        }
+        if (last) {
+            // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
+            if (out.J_out) {
+                float* Jo = out.J_out + row * 6 * D;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
+            }
+            if (out.e_out) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+            }
+        }
+        if constexpr (D >= 6) {
+            bool flag = !conv && est > prm.gate_thr;  // NaN: not flagged (the row is NaN either way)
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(flag) != 0ull, 0)) {  // wave-uniform; rare
+                if (prm.clamp) {
+                    bool cut = false;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const float v = q[j] + delta[j];
+                        cut |= (v < rb.lo(j)) | (v > rb.hi(j));
+                    }
+                    flag = flag && !cut;
+                }
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(flag);
+                if (todo != 0ull) {
+                    int rank = lm_gate_hand_over<D>(J, e, todo, gate_lds, flag);  // (the last use of J and e)
+                    lm_gate_solve<D>(prm.lam_r_d, prm.lam_p_d, todo, rank, gate_lds, flag, delta);
+                    // more flagged rows than slots (independent random configurations, first iteration): further rounds, each with
+                    // the Jacobian formed again rather than parked in registers while other rows were being solved
+                    while ((todo = __builtin_amdgcn_ballot_w64(flag)) != 0ull) {
+                        float R2[9], p2[3], ax2[D][3], og2[D][3], J2[6][D], e2[6];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) asm volatile("" : "+v"(q[j]));  // (unchanged, but the compiler must not know)
+                        fk_ee_axes<RB>(rb, q, R2, p2, ax2, og2);
+                        pose_error(Rt, tt, R2, p2, e2);
+                        jacobian_from_axes<RB>(rb, p2, ax2, og2, J2);
+                        rank = lm_gate_hand_over<D>(J2, e2, todo, gate_lds, flag);
+                        lm_gate_solve<D>(prm.lam_r_d, prm.lam_p_d, todo, rank, gate_lds, flag, delta);
+                    }
+                }
+            }
         }
     }
     if (prm.tol_pos2 > 0.f) {  // wave-uniform: the predicated update only exists on the early-out path
@@ -214,24 +263,30 @@ __device__ __forceinline__ void lm_row_finish(const RB& rb, const CollK& co, con
     }
 }
 
+// Wavefronts per SIMD the fused kernel is compiled for (128 / 168 / 256 VGPRs): the robot-specialised instantiations fit 128
+// registers up to 7 joints (168 beyond) without touching scratch; the generic ones (chain constants in SGPRs, capsules in LDS) get
+// one step more room.
+template <class RB>
+constexpr int lm_waves() {
+    return RB::kStatic ? (RB::D <= 7 ? 4 : 3) : (RB::D <= 6 ? 4 : (RB::D <= 8 ? 3 : 2));
+}
+
 // COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
 // out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
-// F64: the damped solve in double precision (lm_dual_solve_f64).
-// OCC = 4: the instantiation is held to 128 VGPRs (4 wavefronts per SIMD resident: all of a 262 144-row launch at once instead
-// of 3 + a second round) at the price of ~8 registers spilled to scratch outside the LM loop.  Same-process A/B
-// (scripts/occ_ab.py, two launches in flight): C4 41.8 -> 41.5 us per step, Fetch 512 x 256 32.6 -> 32.3 -- about 1 %; a launch
-// that uses scratch dispatches more slowly, which costs the small shards in flight on four queues more than the occupancy gives
-// (32 768 rows: 7.0 -> 8.2 us per step), so the host picks by size.
-// OCC = 3 (168 VGPRs) is the same trade for the 12-joint chain's table build (212 VGPRs, 39 spills): C5 621 -> 581 us per step.
-template <class RB, int COLL, bool F64 = false, int OCC = 0>
-__global__ __launch_bounds__(kBlock, OCC ? OCC : CPPF_WAVES_LM) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
+// The precision of the damped solve is a run-time parameter (prm.gate_thr, lm_solve_gated).
+// Registers: the masks-only instantiations of the shipped robots need <= 128 VGPRs without being told to (Panda 115; round 2
+// needed a second, occupancy-capped build with 36 B of scratch per lane for that), so all four wavefronts per SIMD of a
+// 262 144-row launch are resident at once and no launch touches scratch.
+template <class RB, int COLL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves<RB>(), lm_waves<RB>()))) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                           const float* __restrict__ x_in,
                                                           const float* __restrict__ target, const cppf_lm_outputs out) {
     extern __shared__ float lds[];
     constexpr int D = RB::D;
+    __shared__ float s_gate[kBlock / 64][GateLds<D>::kFloats];  // the conditioning gate's slots, per wavefront (lm_solve_gated)
     const RB rb{ch, co};
     const int tid = threadIdx.x;
-    const size_t row = (size_t)blockIdx.x * kBlock + tid;
+    const size_t row = (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid);  // n < 2^31 (host): one register across the LM loop
     const bool active = row < (size_t)prm.n;
     float q[D];
 #pragma unroll
@@ -247,22 +302,36 @@ __global__ __launch_bounds__(kBlock, OCC ? OCC : CPPF_WAVES_LM) void lm_fused_ke
         for (int j = 0; j < D; ++j) chk += q[j];
 #pragma unroll
         for (int k = 0; k < 9; ++k) chk += Rt[k];
-        const bool bad = !(fabsf(chk) < INFINITY);
+        // (as a wavefront mask, formed NOW: left alone the compiler sinks the whole sum behind the LM loop and keeps its 19
+        // inputs -- the row's initial q among them -- alive across it, which is what the last spilled registers were)
+        unsigned long long bad_mask = __builtin_amdgcn_ballot_w64(!(fabsf(chk) < INFINITY));
+        asm volatile("" : "+s"(bad_mask));
+        float* const gate_lds = s_gate[__builtin_amdgcn_readfirstlane(tid >> 6)];  // wave-uniform: a scalar base
         int iters = 0;
         for (int it = 0; it < prm.n_steps; ++it) {
-            const bool conv = lm_row_iterate<RB, F64>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, q);
+            const bool conv = lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, gate_lds, q);
             iters += conv ? 0 : 1;
             if (prm.tol_pos2 > 0.f && __builtin_amdgcn_ballot_w64(!conv) == 0ull) break;
         }
-        if (out.n_iters) out.n_iters[row] = iters;
-        if (bad) {
+        // Row index and everything derived from it (the byte offsets of a dozen outputs) are formed AGAIN behind the loop
+        // from the work-item id -- opaque to the compiler, which would otherwise carry five registers of them across the loop
+        // (the last ones it spilled to scratch at 128 VGPRs): the loop itself only needs the index when it stores J / e.
+        int tid_b = threadIdx.x;
+        asm volatile("" : "+v"(tid_b));
+        const size_t row_b = (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid_b);
+        if (out.n_iters) out.n_iters[row_b] = iters;
+        if ((bad_mask >> (tid_b & 63)) & 1ull) {
 #pragma unroll
             for (int j = 0; j < D; ++j) q[j] = __builtin_nanf("");
         }
-        lm_row_finish<RB, COLL>(rb, co, out, lds, tid, row, Rt, tt, q, rs);
+        lm_row_finish<RB, COLL>(rb, co, out, lds, tid_b, row_b, Rt, tt, q, rs);
     }
     if constexpr (COLL != 0) {
-        if (out.seed_summary) block_seed_summary<RB>(rb, prm.W, row, active, q, rs, out.seed_summary);
+        if (out.seed_summary) {
+            int tid_c = threadIdx.x;
+            asm volatile("" : "+v"(tid_c));
+            block_seed_summary<RB>(rb, prm.W, (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid_c), active, q, rs, out.seed_summary);
+        }
     }
 }
 

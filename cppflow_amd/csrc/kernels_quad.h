@@ -291,6 +291,31 @@ __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const
     float delta[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) delta[j] = quad_sum(CPPF_FMA(V[j], yl, Z[j] * ya));
+    // The conditioning gate of the damped solve (kernels_chain.h): a row whose fp32 solve is estimated to be off by more than the
+    // gate's tolerance redoes it in double precision.  This shape runs one wavefront per SIMD with registers to spare, so the
+    // double-precision solve is simply inlined -- replicated in the quad's four lanes like the fp32 one, on the gathered Jacobian.
+    {
+        const float dmax = fmaxf(fmaxf(fmaxf(A[0][0], A[1][1]), A[2][2]) + lam_r, fmaxf(fmaxf(A[3][3], A[4][4]), A[5][5]) + lam_p);
+        const float ymax = fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))), fmaxf(fabsf(y[4]), fabsf(y[5])));
+        const bool flag = !conv && dmax * ymax > prm.gate_thr;  // the same value in the quad's four lanes; NaN: not flagged
+        if (__builtin_amdgcn_ballot_w64(flag) != 0ull) {      // wave-uniform
+            float Jf[6][D], d64[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    Jf[i][j] = quad_bcast(Z[j], i);
+                    Jf[3 + i][j] = quad_bcast(V[j], i);
+                    // (opaque: the compiler otherwise folds the DPP move into the f32 -> f64 conversion that follows, and
+                    // v_cvt_f64_f32 with a quad_perm control is not an instruction -- hipRTC's build rejects it)
+                    asm volatile("" : "+v"(Jf[i][j]), "+v"(Jf[3 + i][j]));
+                }
+            }
+            lm_dual_solve_f64<D>(Jf, e, prm.lam_r_d, prm.lam_p_d, d64);
+#pragma unroll
+            for (int j = 0; j < D; ++j) delta[j] = flag ? d64[j] : delta[j];
+        }
+    }
     if (prm.tol_pos2 > 0.f) {
         if (!conv) {
 #pragma unroll
@@ -339,8 +364,7 @@ __global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, con
 #pragma unroll
     for (int i = 0; i < 9; ++i) chk += Rt[i];
     const bool bad = !(fabsf(chk) < INFINITY);  // non-finite input: the reference propagates NaN (see lm_fused_kernel)
-    const float lam_r = prm.lm_lambda * __builtin_amdgcn_rcpf(prm.a_rot * prm.a_rot),
-                lam_p = prm.lm_lambda * __builtin_amdgcn_rcpf(prm.a_pos * prm.a_pos);
+    const float lam_r = prm.lam_r, lam_p = prm.lam_p;
     int iters = 0;
     for (int it = 0; it < prm.n_steps; ++it) {
         const bool conv = quad_iterate<RB, MFMA>(rb, prm, k, Rt, tt_own, lam_r, lam_p, q);

@@ -57,10 +57,14 @@ struct CollK {
 };
 
 struct LmK {
+    double lam_r_d, lam_p_d;  // the damping per row of the dual system, lambda / a_rot^2 and lambda / a_pos^2, formed by the host:
+    float lam_r, lam_p;       // wave-uniform values a kernel would otherwise compute with the VALU and park in VGPRs for the whole loop
     float lm_lambda, a_pos, a_rot;
     int32_t n_steps, clamp;
     int32_t n, W;
     float tol_pos2, tol_rot2;  // early-out (cppf_lm_params.tol_*), squared; 0 = off
+    float gate_thr;            // conditioning gate of the damped solve: a row whose  max diag(A) * max |y|  exceeds this redoes the
+                               // solve in double precision (lm_solve_gated); +inf = never (pure fp32), -inf = always (pure fp64)
 };
 
 // ---- multiply / fma by a chain constant --------------------------------------------------------------------------------------

@@ -27,9 +27,9 @@ namespace {
 enum RtcKernel { RTC_FUSED0 = 0, RTC_FUSED1, RTC_FUSED2, RTC_COLL_MASK, RTC_COLL_MIN, RTC_QUAD0, RTC_QUAD1, RTC_COUNT };
 
 const char* const kRtcNameExpr[RTC_COUNT] = {
-    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 0, false>",
-    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 1, false>",
-    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 2, false>",
+    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 0>",
+    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 1>",
+    "cppf_rtc::lm_fused_kernel<cppf::StaRobot<cppf::gen::Custom>, 2>",
     "cppf_rtc::collision_kernel<cppf::StaRobot<cppf::gen::Custom>, false>",
     "cppf_rtc::collision_kernel<cppf::StaRobot<cppf::gen::Custom>, true>",
     "cppf_rtc::lm_quad_kernel<cppf::StaRobot<cppf::gen::Custom>, 0, false>",

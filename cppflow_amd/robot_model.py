@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-MAX_DOF = 16
+MAX_DOF = 12
 MAX_CAPSULES = 24
 MAX_PAIRS = 128
 MAX_OBSTACLES = 8

@@ -80,6 +80,7 @@ class Robot:
             )
         self._desc = _hip.chain_to_desc(self.chain)
         self._handles: Dict[int, ctypes.c_void_p] = {}
+        self._tuning: Dict[int, int] = {}  # cppf_debug_set switches, re-applied to every handle this Robot creates
         self._obstacles: Optional[Tuple[np.ndarray, np.ndarray]] = None
         self._jl_padding: Optional[Tuple[np.ndarray, np.ndarray]] = None
 
@@ -104,6 +105,14 @@ class Robot:
         return urdf_forward_kinematics(self.spec, np.zeros(self.ndof), link=link_name)
 
     # ---- handle management ---------------------------------------------------------------------------------------------
+    def debug_set(self, key: str, value: Optional[int] = None) -> None:
+        """Test / tuning switch of THIS robot's handles (include/cppflow_hip_debug.h; `None` restores the default).  Per
+        handle: no other Robot in the process is affected."""
+        k = _hip.TUNE_KEYS[key]
+        self._tuning[k] = _hip.TUNE_DEFAULT if value is None else int(value)
+        for h in self._handles.values():
+            _hip.check(_hip.lib().cppf_debug_set(h, k, self._tuning[k]))
+
     def _handle(self, device: torch.device) -> ctypes.c_void_p:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         h = self._handles.get(idx)
@@ -112,6 +121,8 @@ class Robot:
             _hip.check(_hip.lib().cppf_robot_create(ctypes.byref(self._desc), idx, ctypes.byref(out)))
             h = out
             self._handles[idx] = h
+            for k, v in self._tuning.items():
+                _hip.check(_hip.lib().cppf_debug_set(h, k, v))
             self._apply_obstacles(h)
             self._apply_jl_padding(h)
             if self.specialize and _hip.lib().cppf_robot_specialization(h) < 0:
@@ -330,7 +341,7 @@ class Robot:
         tol_rot_rad: float = 0.0,
         want_iters: bool = False,
         shape: int = _hip.SHAPE_AUTO,
-        solver: int = _hip.SOLVER_F32,
+        solver: int = _hip.SOLVER_AUTO,
     ) -> Dict[str, torch.Tensor]:
         """K fused { levenberg_marquardt_only_pose ; clamp_to_joint_limits } iterations in ONE kernel launch, plus
         (optionally) pose-error metrics and collision masks / search cost of the result.  x is [S*W, d]; target [W, 7].
@@ -347,8 +358,9 @@ class Robot:
         start of an iteration are left untouched and a wavefront of such rows leaves the loop (cppflow/optimization.py:326-358
         stops the same way once the pose is valid); `want_iters` returns the per-row number of steps applied.  `shape` picks
         the kernel shape (`_hip.SHAPE_ROW`: one row per lane; `_hip.SHAPE_QUAD`: four lanes per row; default: by batch size);
-        `solver` the precision of the damped solve (`_hip.SOLVER_F32`, the reference's dtype, or `_hip.SOLVER_F64`: exact to
-        rounding on near-singular rows too, ~1.5x the iteration time)."""
+        `solver` the precision of the damped solve: `_hip.SOLVER_AUTO` (default: the reference's dtype with the conditioning gate --
+        rows whose fp32 solve is estimated to be off by more than 1e-5 in task space redo it in double precision),
+        `_hip.SOLVER_F64` (every row in double precision, ~1.9x the iteration time) or `_hip.SOLVER_F32` (no gate)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
@@ -409,7 +421,7 @@ class Robot:
     def lm_launch_plan(self, x: torch.Tensor, target: torch.Tensor, lm_lambda: float, alpha_position: float,
                        alpha_rotation: float, n_steps: int, x_out: torch.Tensor, packed_out: Optional[torch.Tensor] = None,
                        clamp: bool = True, summary_out: Optional[torch.Tensor] = None,
-                       shape: int = _hip.SHAPE_AUTO, solver: int = _hip.SOLVER_F32,
+                       shape: int = _hip.SHAPE_AUTO, solver: int = _hip.SOLVER_AUTO,
                        errors_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> "LmLaunchPlan":  # fmt: skip
         """Pre-marshalled arguments for repeated fused launches over fixed buffers (what a planner loop or a benchmark
         holds on to): `plan.launch()` is then a single C call on torch's current stream, no Python-side allocation.
@@ -671,7 +683,7 @@ def _check_summary_buffer(t: torch.Tensor, S: int, dev) -> None:
 
 class LmLaunchPlan:
     def __init__(self, robot: Robot, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
-                 summary_out=None, shape=_hip.SHAPE_AUTO, solver=_hip.SOLVER_F32, errors_out=None):  # fmt: skip
+                 summary_out=None, shape=_hip.SHAPE_AUTO, solver=_hip.SOLVER_AUTO, errors_out=None):  # fmt: skip
         x = robot._x2d(x)
         x_out = _require_output_tensor(x_out, "x_out")
         target = _require_device_tensor(target, "target_path")

@@ -38,9 +38,9 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 3
+#define CPPF_ABI_VERSION 4
 
-#define CPPF_MAX_DOF 16
+#define CPPF_MAX_DOF 12 /* every ndof in 3..12 is built (the reference's robots have 7 and 8) */
 #define CPPF_MAX_CAPSULES 24
 #define CPPF_MAX_PAIRS 128
 #define CPPF_MAX_OBSTACLES 8
@@ -87,15 +87,25 @@ typedef struct cppf_lm_params {
     /* Kernel shape: CPPF_SHAPE_AUTO picks by batch size; CPPF_SHAPE_ROW = one (seed, waypoint) row per lane (throughput
      * shape); CPPF_SHAPE_QUAD = four lanes cooperate on one row (latency shape for batches that cannot fill the chip). */
     int32_t shape;
-    /* Precision of the damped solve: CPPF_SOLVER_F32 (default; the reference's dtype) or CPPF_SOLVER_F64 -- J J^T, its
-     * factorisation, the substitutions and J^T y in double precision: the step then equals the exactly solved step of the fp32
-     * Jacobian on EVERY row, near-singular ones included (task-space difference to the fp64 oracle <= 6e-7), at ~1.5x the
-     * iteration time.  Row shape, ndof >= 6, launches without min_self / min_env. */
+    /* Precision of the damped solve (ndof >= 6; below that the primal fp32 solve).
+     *   CPPF_SOLVER_AUTO (0, the default): the reference's dtype, conditioning-gated -- every row is solved in fp32; a row whose
+     *     a-posteriori error estimate  eps * a_max * max diag(A) * max |y|  (the task-space size of the rounding error of forming
+     *     and factoring A = J J^T + lambda S^-2, known once y = A^-1 e is) exceeds `solver_gate` redoes the solve in double
+     *     precision.  The step is then never farther from the exactly solved one than the reference's own fp32 arithmetic
+     *     (torch.linalg.solve on the primal system, cppflow/optimization.py:85-88) gets -- near-singular rows included.
+     *   CPPF_SOLVER_F64: every row in double precision (J J^T, its factorisation, the substitutions and J^T y): the exactly
+     *     solved step of the fp32 Jacobian on every row (task-space difference to the fp64 oracle <= 6e-7); ~1.9x the iteration.
+     *   CPPF_SOLVER_F32: fp32 only, no gate (the round-2 behaviour; up to 6e-2 off in task space on near-singular rows). */
     int32_t solver;
+    /* Tolerance of CPPF_SOLVER_AUTO's gate in the scaled task-space units of the residual (rad * alpha_rotation, m *
+     * alpha_position); 0 = CPPF_SOLVER_GATE_DEFAULT. */
+    float solver_gate;
 } cppf_lm_params;
 
-#define CPPF_SOLVER_F32 0
+#define CPPF_SOLVER_AUTO 0
 #define CPPF_SOLVER_F64 1
+#define CPPF_SOLVER_F32 2
+#define CPPF_SOLVER_GATE_DEFAULT 1e-5f
 
 #define CPPF_SHAPE_AUTO 0
 #define CPPF_SHAPE_ROW 1
@@ -145,40 +155,7 @@ int cppf_robot_specialization(const cppf_robot* robot);
  * (cppflow/data_type_utils.py:197).  A no-op (CPPF_OK) for a handle that already runs a generated table. */
 #define CPPF_SPECIALIZATION_RTC 1000
 int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir);
-/* Test hook that needs no GPU: generates the table for `desc`, compiles it with hipRTC and writes the cache entry (everything
- * cppf_robot_specialize does before it loads the code object); returns the error of the load stage (CPPF_ERR_HIP) on a machine
- * without a device and CPPF_OK never -- look for the cache file. */
-int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
-/* Test hook: non-zero forces every later launch through the generic kernels (process-wide). */
-void cppf_debug_force_generic(int on);
-/* Test / tuning hook: cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per
- * trajectory) when S*W <= n rows (x 0.5 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both
- * ends of the path (eight trajectories per wavefront) otherwise; n < 0 restores the defaults, the measured crossovers:
- * 131072 rows with the state in LDS (W <= 256), 49152 with it in the workspace (process-wide). */
-void cppf_debug_set_pcr_max_rows(int n);
-/* Tuning hooks (process-wide): CPPF_SHAPE_AUTO runs four lanes per row up to n rows (default 16384 = one wavefront of that shape
- * per SIMD, the measured crossover) unless a per-seed summary is requested;
- * non-zero `on` forms J J^T of that shape with v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
- * measured comparison of DESIGN.md section 4; default off). */
-void cppf_debug_set_quad_max_rows(int n);
-/* Test hook: 0 makes cppf_dp_search issue one launch per waypoint instead of the single resident launch (k <= 256). */
-void cppf_debug_set_dp_persistent(int on);
-/* Test hook: 0 makes cppf_lm_full_step eliminate with one wavefront per trajectory, first waypoint to last (cross-lane reads
- * through the LDS pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the
- * path; d <= 8, beyond the parallel-in-time range. */
-void cppf_debug_set_full_rows(int on);
-/* Tuning hook: cppf_lm_pose_steps launches with masks (no minimum distances, fp32 solve) use the instantiation held to 128
- * VGPRs (168 beyond 8 joints; a few registers spilled outside the LM loop, one more wavefront per SIMD resident) from n rows
- * up; n < 0 restores the default 131072, a huge n switches it off (process-wide). */
-void cppf_debug_set_occ_min_rows(int n);
-/* Test hook: 0 makes the parallel-in-time elimination of cppf_lm_full_step keep its state in the caller's workspace (as it does
- * for W > 256) instead of LDS; 1 = LDS, one lane per waypoint; any other value (the default) = LDS, two half-workgroups per
- * waypoint (process-wide). */
-void cppf_debug_set_pcr_lds(int on);
-/* Tuning hook: non-zero sends cppf_lm_full_step WITH the pose block (rank-deficient d x d blocks) through the row-per-lane
- * Gauss-Jordan kernels as well instead of the one-lane-per-trajectory Cholesky kernel (process-wide). */
-void cppf_debug_set_rows_pose(int on);
-void cppf_debug_set_quad_mfma(int on);
+/* (Test and tuning hooks live in cppflow_hip_debug.h; none of them is process-wide.) */
 
 /* Replaces Problem.obstacles_cuboids / obstacles_Tcuboids (cppflow/data_type_utils.py:87-145).
  * cuboids [O,6] = (-sx/2,-sy/2,-sz/2, sx/2,sy/2,sz/2); Rt [O,12] = rotation row-major (9) then translation (3), HOST
@@ -351,6 +328,9 @@ int cppf_dp_search_tabled(const cppf_robot* robot, const float* q, const float* 
 typedef struct cppf_comm cppf_comm;
 #define CPPF_COMM_ID_BYTES 128
 
+/* CPPF_OK when RCCL can be loaded into this process (dlopen + every symbol the library uses), else CPPF_ERR_UNSUPPORTED with
+ * the reason in cppf_last_error(): lets every rank of a job agree on a transport BEFORE anyone enters a collective. */
+int cppf_comm_available(void);
 int cppf_comm_unique_id(void* id_out /* CPPF_COMM_ID_BYTES */);
 int cppf_comm_init_rank(const void* id, int rank, int world, int device, cppf_comm** out);
 int cppf_comm_init_all(int n_devices, const int* devices, cppf_comm** out /* [n_devices] */);

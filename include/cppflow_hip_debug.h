@@ -1,0 +1,65 @@
+/*
+ * cppflow_hip_debug.h -- test and tuning hooks of libcppflow_hip.so.  NOT part of the drop-in boundary (cppflow_hip.h): nothing
+ * here replaces an interface of the reference; the hooks exist so that tests can force every code path and measurement scripts
+ * can A/B a dispatch decision.  Every switch belongs to ONE robot handle ("no global mutable state besides the
+ * communicator"): two handles on two threads can hold different settings, and a test that flips a switch changes nothing for
+ * any other handle in the process.
+ */
+#ifndef CPPFLOW_HIP_DEBUG_H
+#define CPPFLOW_HIP_DEBUG_H
+
+#include "cppflow_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* keys of cppf_debug_set / cppf_debug_get; CPPF_TUNE_DEFAULT as the value restores the built-in default */
+#define CPPF_TUNE_DEFAULT (-2147483647 - 1)
+/* non-zero: every launch of the handle runs the generic kernels (description in the kernel-argument segment) even when a
+ * generated table or a run-time-specialised module exists.  Default 0. */
+#define CPPF_TUNE_FORCE_GENERIC 0
+/* cppf_lm_full_step eliminates in parallel over the waypoints (cyclic reduction, one workgroup per trajectory) when S*W <= n
+ * rows (x 0.5 at d = 8; and W <= 512, d <= 8, no pose block), waypoint after waypoint from both ends of the path (eight
+ * trajectories per wavefront) otherwise.  Default -1 = the measured crossovers: 131072 rows with the state in LDS (W <= 256),
+ * 49152 with it in the workspace. */
+#define CPPF_TUNE_PCR_MAX_ROWS 1
+/* CPPF_SHAPE_AUTO runs four lanes per row up to n rows unless a per-seed summary is requested.  Default 16384 = one wavefront
+ * of that shape per SIMD, the measured crossover. */
+#define CPPF_TUNE_QUAD_MAX_ROWS 2
+/* 0: cppf_dp_search issues one launch per waypoint instead of the single resident launch (k <= 256).  Default 1. */
+#define CPPF_TUNE_DP_PERSISTENT 3
+/* 0: cppf_lm_full_step eliminates with one wavefront per trajectory, first waypoint to last (cross-lane reads through the LDS
+ * pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the path; d <= 8, beyond
+ * the parallel-in-time range.  Default 1. */
+#define CPPF_TUNE_FULL_ROWS 4
+/* parallel-in-time elimination of cppf_lm_full_step, W <= 256: 0 = state in the caller's workspace (as for W > 256), 1 = in
+ * LDS, one lane per waypoint, 2 (default) = in LDS, two half-workgroups per waypoint. */
+#define CPPF_TUNE_PCR_LDS 5
+/* non-zero: cppf_lm_full_step WITH the pose block (rank-deficient d x d blocks) goes through the row-per-lane Gauss-Jordan
+ * kernels as well instead of the one-lane-per-trajectory Cholesky kernel.  Default 0. */
+#define CPPF_TUNE_ROWS_POSE 6
+/* non-zero: J J^T of the four-lanes-per-row shape by v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
+ * measured comparison of DESIGN.md section 4.2).  Default 0. */
+#define CPPF_TUNE_QUAD_MFMA 7
+#define CPPF_TUNE_COUNT 8
+
+int cppf_debug_set(cppf_robot* robot, int key, int value);
+int cppf_debug_get(const cppf_robot* robot, int key, int* value);
+
+/* Needs no GPU: generates the table for `desc`, compiles it with hipRTC and writes the cache entry (everything
+ * cppf_robot_specialize does before it loads the code object); returns the error of the load stage (CPPF_ERR_HIP) on a machine
+ * without a device and CPPF_OK never -- look for the cache file. */
+int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
+
+/* The proof behind the collision stage's reciprocal (csrc/lmik_device.h: rcp_rn = v_rcp_f32 + one Newton step): compares it with
+ * the correctly rounded 1 / x on `count` consecutive fp32 BIT PATTERNS starting at `first` and adds, per biased exponent of x
+ * (0..255), the number of patterns on which the two differ in bits to mismatches[256] (DEVICE pointer, uint64, caller-zeroed).
+ * NaN results on both sides count as equal.  device = the GPU to run on.  The oracle spells rcp_rn as `1 / x`, so the masks are
+ * bit-exact across the two only if this stays 0 over the range the kernels use (2^-100 <= |x| < 2^126). */
+int cppf_debug_rcp_sweep(int device, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPPFLOW_HIP_DEBUG_H */

@@ -1157,18 +1157,18 @@ void orc_env_dists_grads(const void* h, const double* x, int n, const double* bo
     }
 }
 
-/* Dense residual r [rows] and Jacobian J [rows, T*d] of ONE trajectory x [T,d], stacked in the reference's order
- * (LmResidual.get_r, optimization_utils.py:59-72): pose, differencing, virtual configs, self collisions, env collisions.
- * Returns the number of rows; r_out / J_out must hold max_rows rows. */
-static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const REAL* x, const REAL* target, const REAL* xv,
-                        int T, int nobs, const REAL* box_lo, const REAL* box_hi, REAL* r, REAL* J, int max_rows) {
-    const int d = rb->ndof, N = T * d;
+/* The residual rows of ONE trajectory x [T,d] in the reference's stacking order (LmResidual.get_r, optimization_utils.py:59-72):
+ * pose, differencing, virtual configs, self collisions, env collisions.  Every row touches the d columns of ONE waypoint t,
+ * except a differencing row, which touches one column of t and the same column of t + 1.  Rows are handed to a sink:
+ *   emit(ctx, r, t, jt [d], jt2 [d] or NULL)   -- J[row, t*d + j] = jt[j],  J[row, (t+1)*d + j] = jt2[j]
+ * which returns non-zero to abort (row storage exhausted).  Returns the number of rows, or -1. */
+typedef int (*row_sink)(void* ctx, REAL r, int t, const REAL* jt, const REAL* jt2);
+
+static int full_rows(const orc_robot* rb, const orc_full_params* pm, const REAL* x, const REAL* target, const REAL* xv, int T,
+                     int nobs, const REAL* box_lo, const REAL* box_hi, row_sink emit, void* ctx) {
+    const int d = rb->ndof;
     int row = 0;
-#define NEW_ROW()                                    \
-    do {                                             \
-        if (row >= max_rows) return -1;              \
-        for (int c_ = 0; c_ < N; ++c_) J[(size_t)row * N + c_] = 0; \
-    } while (0)
+    REAL jt[ORC_MAX_DOF], jt2[ORC_MAX_DOF];
     if (pm->use_pose) { /* optimization_utils.py:503-543: r = pose errors, J = FK Jacobian, rows scaled by the alphas */
         for (int t = 0; t < T; ++t) {
             REAL Jt[6 * ORC_MAX_DOF], e[6], cur[7];
@@ -1178,9 +1178,8 @@ static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const RE
             pose_error_row(cur, target + (size_t)t * 7, e);
             for (int i = 0; i < 6; ++i) {
                 const REAL a = (REAL)(i < 3 ? pm->alpha_rotation : pm->alpha_position);
-                NEW_ROW();
-                r[row] = a * e[i];
-                for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = a * Jt[i * d + j];
+                for (int j = 0; j < d; ++j) jt[j] = a * Jt[i * d + j];
+                if (emit(ctx, a * e[i], t, jt, NULL)) return -1;
                 ++row;
             }
         }
@@ -1190,10 +1189,10 @@ static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const RE
             for (int j = 0; j < d; ++j) {
                 REAL a = (REAL)pm->alpha_differencing;
                 if (rb->jtype[j] == 1) a *= (REAL)pm->alpha_differencing_prismatic_scaling;
-                NEW_ROW();
-                r[row] = a * wrap_pi(x[(size_t)(t + 1) * d + j] - x[(size_t)t * d + j]);
-                J[(size_t)row * N + t * d + j] = a;
-                J[(size_t)row * N + (t + 1) * d + j] = -a;
+                for (int c = 0; c < d; ++c) jt[c] = jt2[c] = 0;
+                jt[j] = a;
+                jt2[j] = -a;
+                if (emit(ctx, a * wrap_pi(x[(size_t)(t + 1) * d + j] - x[(size_t)t * d + j]), t, jt, jt2)) return -1;
                 ++row;
             }
     }
@@ -1204,9 +1203,9 @@ static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const RE
             for (int i = 0; i < nv; ++i) {
                 const int t = side == 0 ? i : T - nv + i;
                 for (int j = 0; j < d; ++j) {
-                    NEW_ROW();
-                    r[row] = b * wrap_pi(x[(size_t)t * d + j] - xv[(size_t)t * d + j]);
-                    J[(size_t)row * N + t * d + j] = -b;
+                    for (int c = 0; c < d; ++c) jt[c] = 0;
+                    jt[j] = -b;
+                    if (emit(ctx, b * wrap_pi(x[(size_t)t * d + j] - xv[(size_t)t * d + j]), t, jt, NULL)) return -1;
                     ++row;
                 }
             }
@@ -1218,9 +1217,8 @@ static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const RE
             for (int p = 0; p < rb->npairs; ++p) {
                 const REAL rv = -(REAL)pm->alpha_self_collision * dist[p];
                 if (!(rv > 0)) continue;
-                NEW_ROW();
-                r[row] = rv;
-                for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = (REAL)pm->alpha_self_collision * grad[p * d + j];
+                for (int j = 0; j < d; ++j) jt[j] = (REAL)pm->alpha_self_collision * grad[p * d + j];
+                if (emit(ctx, rv, t, jt, NULL)) return -1;
                 ++row;
             }
         }
@@ -1233,15 +1231,131 @@ static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const RE
                 for (int c = 0; c < rb->ncaps; ++c) {
                     const REAL rv = -(REAL)pm->alpha_env_collision * dist[c];
                     if (!(rv > 0)) continue;
-                    NEW_ROW();
-                    r[row] = rv;
-                    for (int j = 0; j < d; ++j) J[(size_t)row * N + t * d + j] = (REAL)pm->alpha_env_collision * grad[c * d + j];
+                    for (int j = 0; j < d; ++j) jt[j] = (REAL)pm->alpha_env_collision * grad[c * d + j];
+                    if (emit(ctx, rv, t, jt, NULL)) return -1;
                     ++row;
                 }
             }
     }
-#undef NEW_ROW
     return row;
+}
+
+/* sink 1: the dense r [rows] and J [rows, T*d] the reference builds (torch.block_diag of the per-waypoint Jacobians) */
+typedef struct {
+    REAL *r, *J;
+    int row, max_rows, d, N;
+} dense_sink;
+
+static int dense_emit(void* ctx, REAL rv, int t, const REAL* jt, const REAL* jt2) {
+    dense_sink* k = (dense_sink*)ctx;
+    if (k->row >= k->max_rows) return 1;
+    REAL* Jr = k->J + (size_t)k->row * k->N;
+    for (int c = 0; c < k->N; ++c) Jr[c] = 0;
+    for (int j = 0; j < k->d; ++j) Jr[t * k->d + j] = jt[j];
+    if (jt2)
+        for (int j = 0; j < k->d; ++j) Jr[(t + 1) * k->d + j] = jt2[j];
+    k->r[k->row++] = rv;
+    return 0;
+}
+
+static int full_r_and_J(const orc_robot* rb, const orc_full_params* pm, const REAL* x, const REAL* target, const REAL* xv,
+                        int T, int nobs, const REAL* box_lo, const REAL* box_hi, REAL* r, REAL* J, int max_rows) {
+    dense_sink k = {r, J, 0, max_rows, rb->ndof, T * rb->ndof};
+    return full_rows(rb, pm, x, target, xv, T, nobs, box_lo, box_hi, dense_emit, &k);
+}
+
+/* sink 2: A = J^T J and b = J^T r accumulated straight into BAND storage.  Two columns of one row are at most d apart (a
+ * differencing row: column j of waypoints t and t + 1), so A has half-bandwidth d:  Ab[i * (d + 1) + k] = A[i][i - k], k = 0..d. */
+typedef struct {
+    REAL *Ab, *b;
+    int d;
+} band_sink;
+
+static int band_emit(void* ctx, REAL rv, int t, const REAL* jt, const REAL* jt2) {
+    band_sink* k = (band_sink*)ctx;
+    const int d = k->d, w = d + 1;
+    /* the row's non-zeros: columns t*d + j (jt) and (t+1)*d + j (jt2) */
+    for (int half = 0; half < (jt2 ? 2 : 1); ++half) {
+        const REAL* ja = half ? jt2 : jt;
+        for (int j = 0; j < d; ++j) {
+            if (ja[j] == 0) continue;
+            const int i = (t + half) * d + j;
+            k->b[i] += ja[j] * rv;
+            for (int half2 = 0; half2 <= half; ++half2) { /* columns c <= i */
+                const REAL* jb = half2 ? jt2 : jt;
+                for (int j2 = 0; j2 < d; ++j2) {
+                    const int c = (t + half2) * d + j2;
+                    if (c > i || jb[j2] == 0) continue;
+                    k->Ab[(size_t)i * w + (i - c)] += ja[j] * jb[j2];
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* banded Cholesky A = L L^T in place (L in the same band storage) and the two substitutions; 0 on success */
+static int band_chol_solve(REAL* Ab, REAL* b, int N, int bw) {
+    const int w = bw + 1;
+#define LB(i, c) Ab[(size_t)(i) * w + ((i) - (c))]
+    for (int j = 0; j < N; ++j) {
+        REAL s = LB(j, j);
+        for (int c = j - bw > 0 ? j - bw : 0; c < j; ++c) s -= LB(j, c) * LB(j, c);
+        if (!(s > 0)) return 1;
+        const REAL ljj = SQRT(s);
+        LB(j, j) = ljj;
+        for (int i = j + 1; i < N && i <= j + bw; ++i) {
+            REAL v = LB(i, j);
+            for (int c = i - bw > 0 ? i - bw : 0; c < j; ++c) v -= LB(i, c) * LB(j, c);
+            LB(i, j) = v / ljj;
+        }
+    }
+    for (int i = 0; i < N; ++i) {
+        REAL v = b[i];
+        for (int c = i - bw > 0 ? i - bw : 0; c < i; ++c) v -= LB(i, c) * b[c];
+        b[i] = v / LB(i, i);
+    }
+    for (int i = N - 1; i >= 0; --i) {
+        REAL v = b[i];
+        for (int c = i + 1; c < N && c <= i + bw; ++c) v -= LB(c, i) * b[c];
+        b[i] = v / LB(i, i);
+    }
+#undef LB
+    return 0;
+}
+
+/* The coupled step of orc_lm_full_step without the dense dT x dT matrix: the same residual rows (full_rows), A = J^T J +
+ * lambda I in band storage (half-bandwidth d), banded Cholesky -- O(T d^3) per trajectory instead of O((dT)^3), so the oracle
+ * reaches the planner's path lengths (T = 256 .. 512) and seed counts.  Identical in exact arithmetic to the dense step;
+ * tests/test_oracle_kats.py holds the two together at T <= 64.  Returns the number of failed factorisations. */
+int orc_lm_full_step_banded(const void* h, const double* x, const double* target, const double* xv, int S, int T,
+                            const orc_full_params* pm, int nobs, const double* box_lo, const double* box_hi, double* x_new) {
+    const orc_robot* rb = (const orc_robot*)h;
+    const int d = rb->ndof, N = T * d, w = d + 1;
+    REAL* tg = (REAL*)malloc(sizeof(REAL) * (size_t)T * 7);
+    REAL lo[3 * ORC_MAX_OBS], hi[3 * ORC_MAX_OBS];
+    for (int i = 0; i < T * 7; ++i) tg[i] = (REAL)target[i];
+    for (int i = 0; i < 3 * nobs; ++i) lo[i] = (REAL)box_lo[i], hi[i] = (REAL)box_hi[i];
+    int fails = 0;
+#pragma omp parallel for schedule(dynamic) reduction(+ : fails)
+    for (int s = 0; s < S; ++s) {
+        REAL* xs = (REAL*)malloc(sizeof(REAL) * (size_t)N);
+        REAL* xvs = (REAL*)malloc(sizeof(REAL) * (size_t)N);
+        REAL* Ab = (REAL*)calloc((size_t)N * w, sizeof(REAL));
+        REAL* b = (REAL*)calloc((size_t)N, sizeof(REAL));
+        for (int i = 0; i < N; ++i) {
+            xs[i] = (REAL)x[(size_t)s * N + i];
+            xvs[i] = xv ? (REAL)xv[(size_t)s * N + i] : xs[i];
+        }
+        band_sink k = {Ab, b, d};
+        full_rows(rb, pm, xs, tg, xvs, T, nobs, lo, hi, band_emit, &k);
+        for (int i = 0; i < N; ++i) Ab[(size_t)i * w] += (REAL)pm->lm_lambda;
+        if (band_chol_solve(Ab, b, N, d) != 0) ++fails;
+        for (int i = 0; i < N; ++i) x_new[(size_t)s * N + i] = xs[i] + b[i];
+        free(xs), free(xvs), free(Ab), free(b);
+    }
+    free(tg);
+    return fails;
 }
 
 static int chol_solve_n(REAL* A, REAL* b, int n); /* below */

@@ -95,6 +95,10 @@ def _lib(f32: bool):
             ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FullParams), ctypes.c_int, _dp, _dp,
             _dp, _dp, _ip,
         ]  # fmt: skip
+        lib.orc_lm_full_step_banded.restype = ctypes.c_int
+        lib.orc_lm_full_step_banded.argtypes = [
+            ctypes.c_void_p, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(FullParams), ctypes.c_int, _dp, _dp, _dp,
+        ]  # fmt: skip
         lib.orc_dp_search.argtypes = [ctypes.c_void_p, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, _ip, _dp]
         _LIBS[name] = lib
     return _LIBS[name]
@@ -305,9 +309,12 @@ class Oracle:
         self.lib.orc_env_dists_grads(self.h, _p(x), n, _p(lo), _p(hi), _p(dists), _p(grads))
         return dists, grads
 
-    def lm_full_step(self, x, target, params, S, T, virtual_configs=None, boxes_lo=None, boxes_hi=None, return_residual=False):
+    def lm_full_step(self, x, target, params, S, T, virtual_configs=None, boxes_lo=None, boxes_hi=None, return_residual=False,
+                     banded=False):
         """One coupled LM step (cppflow/optimization.py:95-144) for S trajectories x [S*T,d]; target [T,7] shared.
-        `params` is an OptimizationParameters-like object.  Returns x_new (and the first trajectory's stacked residual)."""
+        `params` is an OptimizationParameters-like object.  Returns x_new (and the first trajectory's stacked residual).
+        `banded`: the same rows accumulated into band storage and solved by a banded Cholesky (O(T d^3) per trajectory instead of
+        the reference's dense O((dT)^3)) -- identical in exact arithmetic, usable at T = 256 .. 512 and hundreds of seeds."""
         x, target = self._x(x), _d(target)
         assert x.shape[0] == S * T and target.shape == (T, 7)
         xv = _d(virtual_configs) if virtual_configs is not None else None
@@ -315,6 +322,15 @@ class Oracle:
         hi = _d(boxes_hi).reshape(-1, 3) if boxes_hi is not None and len(boxes_hi) else np.zeros((0, 3))
         fp = FullParams.from_params(params)
         out = np.empty_like(x)
+        if banded:
+            assert not return_residual
+            null = ctypes.cast(None, _dp)
+            fails = self.lib.orc_lm_full_step_banded(
+                self.h, _p(x), _p(target), _p(xv) if xv is not None else null, S, T, ctypes.byref(fp), lo.shape[0],
+                _p(lo) if lo.shape[0] else null, _p(hi) if lo.shape[0] else null, _p(out),
+            )  # fmt: skip
+            assert fails == 0, f"{fails} Cholesky failures"
+            return out
         max_rows = 6 * T + self.ndof * T + 2 * self.ndof * max(fp.n_virtual_configs, 0) + T * (self.n_pairs + self.n_caps * lo.shape[0]) + 8
         r = np.zeros(max_rows)
         rows = ctypes.c_int(0)

@@ -60,12 +60,12 @@ def main():
             fn = lambda: rb.lm_full_step(x0, target, ALT_LOSS_V2_1_DIFF)  # noqa: E731
             res, outs = {}, {}
             for mode, (pcr, rows) in {"pcr": (1 << 30, 1), "rows": (0, 1), "wave": (0, 0)}.items():
-                L.cppf_debug_set_pcr_max_rows(pcr)
-                L.cppf_debug_set_full_rows(rows)
+                rb.debug_set("pcr_max_rows", pcr)
+                rb.debug_set("full_rows", rows)
                 outs[mode] = fn().clone()
                 res[mode] = timed(fn, args.reps, args.rounds)
-            L.cppf_debug_set_pcr_max_rows(-1)
-            L.cppf_debug_set_full_rows(1)
+            rb.debug_set("pcr_max_rows", -1)
+            rb.debug_set("full_rows", 1)
             auto = timed(fn, args.reps, args.rounds)
             step = float((outs["wave"] - x0).abs().max())
             d_rows = float((outs["rows"] - outs["wave"]).abs().max())

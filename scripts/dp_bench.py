@@ -19,7 +19,7 @@ for name in ("panda", "fetch", "chain12"):
             _hip.check(_hip.lib().cppf_dp_search(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), bp.data_ptr(), bi.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
         out = []
         for mode in (1, 0):
-            _hip.lib().cppf_debug_set_dp_persistent(mode)
+            rb.debug_set("dp_persistent", mode)
             for _ in range(5): call()
             torch.cuda.synchronize()
             ts = []
@@ -27,7 +27,7 @@ for name in ("panda", "fetch", "chain12"):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); call(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
             out.append(np.median(ts))
-        _hip.lib().cppf_debug_set_dp_persistent(1)
+        rb.debug_set("dp_persistent", 1)
         tabled = float("nan")
         if k <= 256:
             import ctypes

@@ -17,16 +17,16 @@ for name in ("panda", "fetch"):
     for S in (1, 64, 256, 512):
         x0, target, _ = make_inputs_problem(rb, S, 256, dev, 0)
         fn = lambda: rb.lm_full_step(x0, target, ALT_LOSS_V2_1_DIFF)
-        L.cppf_debug_set_pcr_max_rows(1 << 30)
+        rb.debug_set("pcr_max_rows", 1 << 30)
         res = {0: [], 1: [], 2: []}
         for rnd in range(5):
             for mode in (0, 1, 2):
-                L.cppf_debug_set_pcr_lds(mode)
+                rb.debug_set("pcr_lds", mode)
                 fn(); torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for _ in range(10): fn()
                 b.record(); torch.cuda.synchronize()
                 res[mode].append(a.elapsed_time(b) / 10 * 1e3)
-        L.cppf_debug_set_pcr_lds(2); L.cppf_debug_set_pcr_max_rows(-1)
+        rb.debug_set("pcr_lds", 2); rb.debug_set("pcr_max_rows", -1)
         print(f"{name:6s} S={S:4d} T=256: workspace {np.median(res[0]):7.1f}   LDS {np.median(res[1]):7.1f}   LDS + split {np.median(res[2]):7.1f} us", flush=True)

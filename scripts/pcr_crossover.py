@@ -18,7 +18,7 @@ for name in ("panda", "fetch"):
         x0, target = make_inputs(rb, S, 256, dev, 0)
         res = {}
         for mode, lim in (("pcr", 1 << 30), ("seq", 0)):
-            _hip.lib().cppf_debug_set_pcr_max_rows(lim)
+            rb.debug_set("pcr_max_rows", lim)
             for _ in range(3): rb.lm_full_step(x0, target, ALT_LOSS_V2_1_DIFF)
             torch.cuda.synchronize()
             ts = []

@@ -41,7 +41,7 @@ xo2 = torch.empty_like(xc2)
 x16 = xp[: 64 * 256].contiguous()
 xo16 = torch.empty_like(x16)
 ROW, QUAD = _hip.SHAPE_ROW, _hip.SHAPE_QUAD
-mfma = _hip.lib().cppf_debug_set_quad_mfma
+mfma = lambda on: rb.debug_set("quad_mfma", on)  # noqa: E731
 
 variants = [
     ("A: row, 262144 rows, K=10, no collision (random inputs)", lambda: rb.lm_pose_steps(x0, target, *LM, n_steps=10, x_out=xo, want_errors=True, shape=ROW)),
@@ -49,7 +49,7 @@ variants = [
     ("C: row, K=10 + collision (random inputs, no summary)", lambda: rb.lm_pose_steps(x0, target, *LM, n_steps=10, x_out=xo, packed_out=pk, shape=ROW)),
     ("D: collision_masks alone (random inputs)", lambda: rb.collision_masks(x0.reshape(S, W, -1))),
     ("E: the bench launch: row, K=10 + collision + per-seed summary, problem inputs", lambda: rb.lm_pose_steps(xp, tp, *LM, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=ROW)),
-    ("F: E with the fp64 solve (CPPF_SOLVER_F64)", lambda: rb.lm_pose_steps(xp, tp, *LM, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=ROW, solver=_hip.SOLVER_F64)),
+    ("F: E with every row solved in double precision (CPPF_SOLVER_F64)", lambda: rb.lm_pose_steps(xp, tp, *LM, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=ROW, solver=_hip.SOLVER_F64)),
     ("G: C2 = 128 x 64 rows, K=10, no collision, row shape", lambda: rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=ROW)),
     ("H: C2, quad shape (VALU J J^T)", lambda: (mfma(0), rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=QUAD))),
     ("I: C2, quad shape, J J^T by v_mfma_f32_4x4x1", lambda: (mfma(1), rb.lm_pose_steps(xc2, tc2, *LM, n_steps=10, x_out=xo2, shape=QUAD), mfma(0))),

@@ -16,7 +16,7 @@ for S in (1, 64, 1024):
     fn = lambda: rb.lm_full_step(x0, target, pm)
     outs = {}
     for mode in (0, 1):
-        _hip.lib().cppf_debug_set_rows_pose(mode)
+        rb.debug_set("rows_pose", mode)
         outs[mode] = fn().clone(); torch.cuda.synchronize()
         ts = []
         for _ in range(5):
@@ -25,6 +25,6 @@ for S in (1, 64, 1024):
             for _ in range(5): fn()
             b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / 5 * 1e3)
         print(f"panda coupled step WITH the pose block, S={S} T=256, {'row-per-lane kernels' if mode else 'one lane per trajectory'}: {np.median(ts):.1f} us", flush=True)
-    _hip.lib().cppf_debug_set_rows_pose(0)
+    rb.debug_set("rows_pose", 0)
     fk0, fk1 = rb.forward_kinematics(outs[0]), rb.forward_kinematics(outs[1])
     print(f"   |x_rows - x_lane| max {float((outs[1]-outs[0]).abs().max()):.3g}  median {float((outs[1]-outs[0]).abs().median()):.3g};  end-effector position difference max {float((fk1[:, :3]-fk0[:, :3]).abs().max()):.3g} m;  step max {float((outs[0]-x0).abs().max()):.3g}", flush=True)

@@ -75,7 +75,7 @@ def main():
         for _ in range(50):
             warm.launch()
         torch.cuda.synchronize()
-    _hip.lib().cppf_debug_set_quad_mfma(args.mfma)
+    rb.debug_set("quad_mfma", args.mfma)
     streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
     for shape in args.shapes.split(","):
         sh = SHAPES[shape]

@@ -98,3 +98,45 @@ def random_chain_spec(ndof, seed, n_prismatic=1, general_axes=True):
     joints.append(JointSpec("tool", "tool", (0.02, -0.01, 0.1), (0.3, -0.2, 0.5), jtype="fixed"))
     capsules.append(CapsuleSpec("tool", (0, 0, -0.05), (0, 0.02, 0.02), 0.025))
     return RobotSpec(f"random{ndof}_{seed}", f"random {ndof}-dof chain", "base", joints, capsules, min_link_gap=2)
+
+
+# ---- hand-derived FK pins ---------------------------------------------------------------------------------
+# jrl is absent, so no FK value of the reference can be imported; these are computed ON PAPER from the public URDF constants the
+# models cite (franka_description / fetch_description) -- every joint frame of these configurations is a
+# signed axis permutation, so the chain is a sum of link offsets along known world axes -- and written down as literals.  They pin
+# the canonical rewrite (robot_model.py), the oracle's FK and the HIP FK to the URDF semantics (parent -> joint xyz / rpy, axis),
+# independently of any code of this repository.  Pose = [x y z qw qx qy qz], base frame = the spec's base link.
+#   Panda, q = 0:            z = 0.333 + 0.316 + 0.384 - 0.107 = 0.926, x = 0.0825 - 0.0825 + 0.088; hand = Rx(pi) Rz(-pi/4)
+#   Panda, q4 = -pi/2, q6 = pi/2:  the forearm points along +x: x = 0.0825 + 0.384 + 0.088, z = 0.333 + 0.316 + 0.0825 - 0.107
+#   Fetch, q = 0:            x = sum of the link offsets = 1.1281, z = 0.37743 + 0.34858 + 0.06
+#   Fetch, torso 0.2, pan pi/2:   the arm points along +y: y = 1.09545, x = -0.086875 + 0.119525, z = 0.78601 + 0.2
+#   Fetch, torso 0.2, pan pi/2, elbow pi/2:  the forearm points down: y = 0.117 + 0.219 + 0.133, z = 0.98601 - 0.62645
+_C8, _S8 = 0.9238795325112867, 0.3826834323650898  # cos, sin of pi/8
+FK_PINS = {
+    "panda": [
+        ([0, 0, 0, 0, 0, 0, 0], [0.088, 0.0, 0.926, 0.0, _C8, _S8, 0.0]),
+        ([0, 0, 0, -np.pi / 2, 0, np.pi / 2, 0], [0.5545, 0.0, 0.6245, 0.0, _C8, _S8, 0.0]),
+    ],
+    "fetch": [
+        ([0, 0, 0, 0, 0, 0, 0, 0], [1.1281, 0.0, 0.78601, 1.0, 0.0, 0.0, 0.0]),
+        ([0.2, np.pi / 2, 0, 0, 0, 0, 0, 0], [0.03265, 1.09545, 0.98601, np.sqrt(0.5), 0.0, 0.0, np.sqrt(0.5)]),
+        ([0.2, np.pi / 2, 0, 0, np.pi / 2, 0, 0, 0], [0.03265, 0.469, 0.35956, 0.5, -0.5, 0.5, 0.5]),
+    ],
+    "fetch_arm": [
+        ([0, 0, 0, 0, 0, 0, 0], [1.1281, 0.0, 0.78601, 1.0, 0.0, 0.0, 0.0]),
+        ([np.pi / 2, 0, 0, np.pi / 2, 0, 0, 0], [0.03265, 0.469, 0.15956, 0.5, -0.5, 0.5, 0.5]),
+    ],
+}
+
+
+def fk_pin_arrays(name):
+    q = np.array([p[0] for p in FK_PINS[name]], dtype=np.float64)
+    pose = np.array([p[1] for p in FK_PINS[name]], dtype=np.float64)
+    return q, pose
+
+
+def pose_close(got, want, tol_p, tol_q):
+    """position within tol_p; quaternion equal up to sign within tol_q"""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    dq = np.minimum(np.abs(got[:, 3:] - want[:, 3:]).max(axis=1), np.abs(got[:, 3:] + want[:, 3:]).max(axis=1))
+    return np.abs(got[:, :3] - want[:, :3]).max() <= tol_p and dq.max() <= tol_q

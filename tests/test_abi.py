@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/cppflow_hip.h declares (no compute calls)."""
+"""The C-ABI library loads without a GPU and exports every symbol include/cppflow_hip.h and include/cppflow_hip_debug.h declare
+(no compute calls)."""
 
 import ctypes
 import os
@@ -8,6 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "cppflow_hip.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "cppflow_hip_debug.h")
 
 
 def build_c_client(out_dir: str) -> str:
@@ -29,10 +31,12 @@ def build_c_client(out_dir: str) -> str:
     return exe
 
 
-def declared_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cppf_[a-z_0-9]+)\s*\(", text)))
+def declared_functions(headers=(HEADER, DEBUG_HEADER)):
+    names = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(cppf_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +61,28 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_hip.SIGNATURES), set(names) ^ set(_hip.SIGNATURES)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.cppf_abi_version() == 3
+    assert lib.cppf_abi_version() == 4
+
+
+def test_debug_header_holds_every_hook_and_nothing_of_the_boundary():
+    """include/cppflow_hip_debug.h: every cppf_debug_* symbol lives there and only there (the public header declares none), its
+    tuning keys are the ones the Python binding uses, and there is no process-wide setter left (every hook that changes dispatch
+    takes the robot handle)."""
+    from cppflow_amd import _hip
+
+    public, debug = declared_functions((HEADER,)), declared_functions((DEBUG_HEADER,))
+    assert not [n for n in public if n.startswith("cppf_debug_")]
+    assert debug and all(n.startswith("cppf_debug_") for n in debug), debug
+    text = open(DEBUG_HEADER).read()
+    keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define CPPF_TUNE_([A-Z_]+) (\d+)\n", text)}
+    count = keys.pop("count")
+    assert keys == _hip.TUNE_KEYS and count == len(keys)
+    assert re.search(r"int cppf_debug_set\(cppf_robot\* robot, int key, int value\);", text)
+    assert "process-wide" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    # without a device a handle cannot be created, but the argument checks run first
+    lib_ = _hip.lib()
+    assert lib_.cppf_debug_set(None, 0, 1) == _hip.CPPF_ERR_INVALID
+    assert b"NULL" in lib_.cppf_last_error()
 
 
 def test_struct_layouts_match_header_constants():
@@ -68,9 +93,9 @@ def test_struct_layouts_match_header_constants():
     for name, val in (("CPPF_MAX_DOF", MAX_DOF), ("CPPF_MAX_CAPSULES", MAX_CAPSULES), ("CPPF_MAX_PAIRS", MAX_PAIRS),
                       ("CPPF_MAX_OBSTACLES", MAX_OBSTACLES)):  # fmt: skip
         assert int(re.search(rf"#define {name} (\d+)", text).group(1)) == val
-    # sizeof(cppf_robot_desc): 4 + 16*48 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
-    assert ctypes.sizeof(_hip.RobotDesc) == 4 + 768 + 48 + 64 + 64 + 64 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
-    assert ctypes.sizeof(_hip.LmParams) == 36
+    # sizeof(cppf_robot_desc): 4 + 12*48 + 48 + 48 + 48 + 48 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
+    assert ctypes.sizeof(_hip.RobotDesc) == 4 + 576 + 48 + 48 + 48 + 48 + 4 + 96 + 288 + 288 + 96 + 4 + 1024
+    assert ctypes.sizeof(_hip.LmParams) == 40
     assert ctypes.sizeof(_hip.LmOutputs) == 13 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_hip.Constraints) == 24
 
@@ -106,8 +131,9 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
     links against the in-tree library (it is run on the GPU by tests/test_gpu_c_client.py)."""
     import subprocess
 
-    for lang, std in (("c", "-std=c99"), ("c++", "-std=c++17")):
-        run = subprocess.run(["gcc", "-x", lang, std, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", HEADER],
+    for lang, std, header in (("c", "-std=c99", HEADER), ("c++", "-std=c++17", HEADER), ("c", "-std=c99", DEBUG_HEADER),
+                              ("c++", "-std=c++17", DEBUG_HEADER)):
+        run = subprocess.run(["gcc", "-x", lang, std, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", header],
                              capture_output=True, text=True)  # fmt: skip
         assert run.returncode == 0, run.stderr
     exe = build_c_client(str(tmp_path))

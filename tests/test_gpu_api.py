@@ -381,15 +381,15 @@ def test_coupled_lm_step_matches_dense_reference_order_oracle(robots, name, vari
     got = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
     # the other elimination order (waypoint after waypoint instead of parallel cyclic reduction over the waypoints) must
     # land on the same step
-    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    rb.debug_set("pcr_max_rows", 0)
     try:
         sequential = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
         # ... and so must the one-wavefront-per-trajectory kernel the row-per-lane one replaced (d <= 8 only)
-        _hip.lib().cppf_debug_set_full_rows(0)
+        rb.debug_set("full_rows", 0)
         per_wave = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
     finally:
-        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
-        _hip.lib().cppf_debug_set_full_rows(1)
+        rb.debug_set("pcr_max_rows", -1)
+        rb.debug_set("full_rows", 1)
     want, r = H.oracle64(name).lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi, return_residual=True)
     n_fixed = (6 * T if pm.use_pose else 0) + ((T - 1) * rb.ndof if pm.use_differencing else 0) + (8 * rb.ndof if pm.use_virtual_configs else 0)
     if variant != "pose_only":
@@ -441,39 +441,41 @@ def test_coupled_step_parallel_in_time_equals_sequential_elimination(robots, nam
     # per waypoint: the same arithmetic, bit for bit; the default (two half-workgroups per waypoint, the t + s side accumulated
     # separately) differs from them by rounding only
     try:
-        _hip.lib().cppf_debug_set_pcr_lds(0)
+        rb.debug_set("pcr_lds", 0)
         pcr_ws = host(rb.lm_full_step(dev(x), dev(target), pm))
-        _hip.lib().cppf_debug_set_pcr_lds(1)
+        rb.debug_set("pcr_lds", 1)
         pcr_one = host(rb.lm_full_step(dev(x), dev(target), pm))
     finally:
-        _hip.lib().cppf_debug_set_pcr_lds(2)
+        rb.debug_set("pcr_lds", 2)
     assert np.array_equal(pcr_one, pcr_ws)
     assert np.abs(pcr - pcr_ws).max() < 1e-6 + 1e-4 * np.abs(pcr_ws - x).max()
-    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    rb.debug_set("pcr_max_rows", 0)
     try:
         seq = host(rb.lm_full_step(dev(x), dev(target), pm))
     finally:
-        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
+        rb.debug_set("pcr_max_rows", -1)
     step = np.abs(seq - x).max()
     assert np.isfinite(pcr).all() and np.abs(pcr - seq).max() < 1e-5 + 1e-3 * step, (np.abs(pcr - seq).max(), step)
     # eight trajectories per wavefront (the default beyond the parallel-in-time range) vs one wavefront per trajectory, on a
     # ragged count of trajectories: 11 = one full wavefront of eight + three groups of a second one
     S11 = 11
     x11 = H.f32(np.clip(base[None] + 0.01 * rng.randn(S11, T, rb.ndof), ch.lo, ch.hi).reshape(S11 * T, rb.ndof))
-    _hip.lib().cppf_debug_set_pcr_max_rows(0)
+    rb.debug_set("pcr_max_rows", 0)
     try:
         rows = host(rb.lm_full_step(dev(x11), dev(target), pm))
-        _hip.lib().cppf_debug_set_full_rows(0)
+        rb.debug_set("full_rows", 0)
         wave = host(rb.lm_full_step(dev(x11), dev(target), pm))
     finally:
-        _hip.lib().cppf_debug_set_pcr_max_rows(-1)
-        _hip.lib().cppf_debug_set_full_rows(1)
+        rb.debug_set("pcr_max_rows", -1)
+        rb.debug_set("full_rows", 1)
     step11 = np.abs(wave - x11).max()
     assert np.isfinite(rows).all() and np.abs(rows - wave).max() < 1e-5 + 1e-3 * step11, (np.abs(rows - wave).max(), step11)
-    if T <= 64:
-        lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
-        want = H.oracle64(name).lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi)
-        assert np.abs(pcr - want).max() < 2e-4 + 2e-3 * step
+    # the oracle at EVERY path length: the same residual rows in band storage, banded Cholesky (oracle/lmik_oracle.c:
+    # orc_lm_full_step_banded; held equal to the reference's dense formulation at T <= 64 by tests/test_oracle_kats.py)
+    lo, hi = H.box_corners([c for c, _ in obs], [T_ for _, T_ in obs])
+    want = H.oracle64(name).lm_full_step(x, target, pm, S, T, boxes_lo=lo, boxes_hi=hi, banded=True)
+    assert np.abs(pcr - want).max() < 2e-4 + 2e-3 * step
+    assert np.abs(seq - want).max() < 2e-4 + 2e-3 * step
     rb.set_obstacles([], [])
 
 
@@ -575,7 +577,7 @@ def test_in_launch_seed_summary_equals_separate_reduction(robots, name, generic)
     obs = H.PANDA_2CUBES if name == "panda" else obstacle_arrays([(0.7, 0.1, 0.8, 0.3, 0.3, 0.3)])
     rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
     rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
-    _hip.lib().cppf_debug_force_generic(int(generic))
+    rb.debug_set("force_generic", int(generic))
     try:
         for S, W in ((5, 1), (9, 2), (7, 32), (5, 64), (3, 128), (3, 256), (4, 100), (2, 300)):
             x0, target = H.lm_problem(name, S, W, seed=100 + W)
@@ -595,7 +597,7 @@ def test_in_launch_seed_summary_equals_separate_reduction(robots, name, generic)
                                      summary_out=torch.empty((S, 8), dtype=torch.float32, device=DEV))  # fmt: skip
         assert float(want[:, 4:].sum()) >= 0
     finally:
-        _hip.lib().cppf_debug_force_generic(0)
+        rb.debug_set("force_generic", 0)
         rb.set_obstacles([], [])
         rb.set_joint_limit_padding(None, None)
 

@@ -19,6 +19,7 @@ DEV = "cuda:0"
 
 @pytest.mark.parametrize("name,S,W", [("panda", 6, 128), ("fetch", 9, 37)])
 def test_c_client_matches_python_mirror(tmp_path, name, S, W):
+    from cppflow_amd.robot_model import MAX_DOF
     from cppflow_amd.robots import get_robot
 
     exe = build_c_client(str(tmp_path))
@@ -28,7 +29,7 @@ def test_c_client_matches_python_mirror(tmp_path, name, S, W):
     Rt = np.stack([np.concatenate([np.asarray(T)[:3, :3].ravel(), np.asarray(T)[:3, 3]]) for _, T in obs]).astype(np.float32)
     rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
     rb.set_joint_limit_padding(np.deg2rad(1.5), 0.03)
-    jl_lo, jl_hi = (np.zeros(16, dtype=np.float32) for _ in range(2))
+    jl_lo, jl_hi = (np.zeros(MAX_DOF, dtype=np.float32) for _ in range(2))  # float[CPPF_MAX_DOF] in the C client
     lo, hi = rb.padded_joint_limits()
     jl_lo[: rb.ndof], jl_hi[: rb.ndof] = lo, hi
     K = 4

@@ -245,11 +245,11 @@ def test_specialised_kernels_equal_generic_kernels(robots, name):
     a = rb.lm_pose_steps(dev(x0), dev(target), **kw)
     ca = rb.collision_masks(dev(x0).reshape(S, W, -1), want_min_dists=True)
     try:
-        _hip.lib().cppf_debug_force_generic(1)
+        rb.debug_set("force_generic", 1)
         b = rb.lm_pose_steps(dev(x0), dev(target), **kw)
         cb = rb.collision_masks(dev(x0).reshape(S, W, -1), want_min_dists=True)
     finally:
-        _hip.lib().cppf_debug_force_generic(0)
+        rb.debug_set("force_generic", 0)
     for k in a:
         assert torch.equal(a[k], b[k]), k
     for k in ca:

@@ -200,7 +200,7 @@ def test_quad_shape_agrees_with_row_shape_and_oracle(robots, name, mfma):
     lo, hi = H.box_corners([c for c, _ in obs], [T for _, T in obs])
     jl_lo, jl_hi = rb.padded_joint_limits()
     o64, o32 = H.oracle64(name), H.oracle32(name)
-    _hip.lib().cppf_debug_set_quad_mfma(int(mfma))
+    rb.debug_set("quad_mfma", int(mfma))
     try:
         for S, W, K in ((3, 50, 1), (8, 64, 5), (5, 256, 10)):  # 150 rows: a partly filled last workgroup
             x0, target = H.lm_problem(name, S, W, seed=40 + K)
@@ -245,7 +245,7 @@ def test_quad_shape_agrees_with_row_shape_and_oracle(robots, name, mfma):
                                                                    q["jlim_mask"]]), S, W))  # fmt: skip
             assert np.array_equal(host(q["seed_summary"]), want_summ)
     finally:
-        _hip.lib().cppf_debug_set_quad_mfma(0)
+        rb.debug_set("quad_mfma", 0)
         rb.set_obstacles([], [])
         rb.set_joint_limit_padding(None, None)
 
@@ -294,12 +294,12 @@ def test_dp_search_single_launch_equals_per_waypoint_launches_and_oracle(robots,
     got = {}
     try:
         for mode in (1, 0):
-            _hip.lib().cppf_debug_set_dp_persistent(mode)
+            rb.debug_set("dp_persistent", mode)
             for rep in range(3):  # repeated calls reuse nothing: every call re-arms its own cost table
                 path, idx, costsT, memoT = rb.dp_search(dev(q), dev(ext), method="resident", return_memo=True)
             got[mode] = (host(path), idx.cpu().numpy(), host(costsT), memoT.cpu().numpy())
     finally:
-        _hip.lib().cppf_debug_set_dp_persistent(1)
+        rb.debug_set("dp_persistent", 1)
     for rep in range(2):
         path, idx, costsT, memoT = rb.dp_search(dev(q), dev(ext), method="table", return_memo=True)
     got["table"] = (host(path), idx.cpu().numpy(), host(costsT), memoT.cpu().numpy())
@@ -411,8 +411,8 @@ def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
             xv = H.f32(x + 0.01 * rng.randn(*x.shape)) if pm.use_virtual_configs else None
             got = {}
             for mode, (pcr, rows) in {"pcr": (1 << 30, 1), "rows": (0, 1), "wave": (0, 0)}.items():
-                L.cppf_debug_set_pcr_max_rows(pcr)
-                L.cppf_debug_set_full_rows(rows)
+                rb.debug_set("pcr_max_rows", pcr)
+                rb.debug_set("full_rows", rows)
                 got[mode] = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=dev(xv) if xv is not None else None))
             want = o64.lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi)
             step = np.abs(want - x).max()
@@ -421,8 +421,8 @@ def test_coupled_step_on_arbitrary_chains_all_elimination_orders(ndof, seed):
                 assert np.abs(g - want).max() < 2e-4 + 2e-3 * step, (mode, S, T, np.abs(g - want).max(), step)
             assert np.abs(got["rows"] - got["wave"]).max() < 1e-5 + 1e-3 * step, (S, T)
     finally:
-        L.cppf_debug_set_pcr_max_rows(-1)
-        L.cppf_debug_set_full_rows(1)
+        rb.debug_set("pcr_max_rows", -1)
+        rb.debug_set("full_rows", 1)
         rb.set_obstacles([], [])
 
 
@@ -478,7 +478,7 @@ def test_coupled_step_two_ended_elimination_over_a_sweep_of_shapes(robots):
     L = _hip.lib()
     worst = 0.0
     try:
-        L.cppf_debug_set_pcr_max_rows(0)
+        rb.debug_set("pcr_max_rows", 0)
         for T in (1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 33, 40):
             d = dict(ALT_LOSS_V2_1_DIFF.__dict__)
             d["use_virtual_configs"] = 2 * d["n_virtual_configs"] < T
@@ -489,17 +489,17 @@ def test_coupled_step_two_ended_elimination_over_a_sweep_of_shapes(robots):
                 base = np.clip(rng.uniform(ch.lo, ch.hi)[None, :] * 0.5 + np.cumsum(0.03 * rng.randn(T, rb.ndof), axis=0), ch.lo, ch.hi)
                 x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, rb.ndof), ch.lo, ch.hi).reshape(S * T, rb.ndof))
                 target = dev(H.f32(H.oracle64("panda").fk(H.f32(base))))
-                L.cppf_debug_set_full_rows(1)
+                rb.debug_set("full_rows", 1)
                 rows = host(rb.lm_full_step(dev(x), target, pm))
-                L.cppf_debug_set_full_rows(0)
+                rb.debug_set("full_rows", 0)
                 wave = host(rb.lm_full_step(dev(x), target, pm))
                 step = np.abs(wave - x).max()
                 err = np.abs(rows - wave).max()
                 worst = max(worst, err / (1e-5 + 1e-3 * step))
                 assert np.isfinite(rows).all() and err < 1e-5 + 1e-3 * step, (S, T, err, step)
     finally:
-        L.cppf_debug_set_pcr_max_rows(-1)
-        L.cppf_debug_set_full_rows(1)
+        rb.debug_set("pcr_max_rows", -1)
+        rb.debug_set("full_rows", 1)
         rb.set_obstacles([], [])
     assert worst < 1.0
 
@@ -511,7 +511,7 @@ def test_dp_search_table_form_over_a_sweep_of_shapes(robots):
 
     rb, ch = robots["panda"], H.chain("panda")
     try:
-        _hip.lib().cppf_debug_set_dp_persistent(0)
+        rb.debug_set("dp_persistent", 0)
         for k in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 128, 129, 161, 191, 192, 193, 255, 256):
             for T in (1, 2, 3, 4, 5, 6, 7, 12):
                 rng = np.random.RandomState(31 * k + T)
@@ -522,4 +522,4 @@ def test_dp_search_table_form_over_a_sweep_of_shapes(robots):
                 for i, (u, v) in enumerate(zip(a, b)):
                     assert torch.equal(u, v), (k, T, i)
     finally:
-        _hip.lib().cppf_debug_set_dp_persistent(1)
+        rb.debug_set("dp_persistent", 1)
