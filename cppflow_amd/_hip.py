@@ -89,7 +89,10 @@ class FullParams(ctypes.Structure):
                                   "alpha_differencing_prismatic_scaling", "alpha_virtual_configs", "alpha_self_collision",
                                   "alpha_env_collision")] + [(k, _i32) for k in (
         "use_pose", "use_differencing", "use_virtual_configs", "n_virtual_configs", "use_self_collisions",
-        "use_env_collisions")]  # fmt: skip
+        "use_env_collisions")] + [
+        ("pose_do_scale_down_satisfied", _i32), ("pose_threshold_m", _f), ("pose_threshold_rad", _f), ("pose_scale_down", _f),
+        ("differencing_mode", _i32), ("differencing_threshold_rad", _f), ("differencing_threshold_m", _f),
+        ("differencing_scale_down", _f), ("differencing_shift_invalid_to_threshold", _i32)]  # fmt: skip
 
 
 class LmOutputs(ctypes.Structure):

@@ -960,24 +960,44 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     prm.use_env = params->use_env_collisions;
     prm.S = S;
     prm.W = W;
+    // the "satisfied" row options (cppflow/optimization_utils.py:514-533, 548-606)
+    CPPF_REQUIRE(params->differencing_mode >= 0 && params->differencing_mode <= 2, "differencing_mode must be 0, 1 or 2");
+    CPPF_REQUIRE(!params->pose_do_scale_down_satisfied || (params->pose_scale_down >= 0.f && params->pose_scale_down < 1.f),
+                 "pose scale-down must be in [0, 1) (optimization_utils.py:305)");
+    CPPF_REQUIRE(params->differencing_mode != 2 || (params->differencing_scale_down >= 0.f && params->differencing_scale_down < 1.f),
+                 "differencing scale-down must be in [0, 1) (optimization_utils.py:367)");
+    prm.pose_scale_satisfied = params->use_pose && params->pose_do_scale_down_satisfied;
+    prm.pose_thr_m = params->pose_threshold_m;
+    prm.pose_thr_rad = params->pose_threshold_rad;
+    prm.pose_scale = params->pose_scale_down;
+    prm.diff_mode = params->use_differencing ? params->differencing_mode : 0;
+    prm.diff_thr_rad = params->differencing_threshold_rad;
+    prm.diff_thr_m = params->differencing_threshold_m;
+    prm.diff_scale = params->differencing_scale_down;
+    prm.diff_shift_invalid = params->differencing_shift_invalid_to_threshold;
+    // Individually weighted differencing rows: the coupling between waypoints t and t + 1 is no longer the same constant for
+    // every t, which the tuned elimination kernels assume; such a step goes through the one-lane-per-trajectory kernel with the
+    // couplings read from memory (w2next: the spare tail of work_G -- that kernel keeps d(d+1)/2 of the d*d floats per row).
+    const bool var_coupling = prm.diff_mode != 0;
+    float* const w2next = work_G + n * (size_t)(robot->desc.ndof * (robot->desc.ndof + 1) / 2);
     // which elimination kernel: see the comments at the launches below
     const int t_pcr_rows = tune(robot, CPPF_TUNE_PCR_MAX_ROWS), t_pcr_lds = tune(robot, CPPF_TUNE_PCR_LDS);
     const bool g_pcr_lds = t_pcr_lds != 0, g_pcr_split = t_pcr_lds != 1;
     const bool g_rows_pose = tune(robot, CPPF_TUNE_ROWS_POSE) != 0, g_full_rows = tune(robot, CPPF_TUNE_FULL_ROWS) != 0;
     const size_t pcr_rows = t_pcr_rows >= 0 ? (size_t)t_pcr_rows : (size_t)((W <= 256 && g_pcr_lds) ? kPcrMaxRowsLds : kPcrMaxRowsGlobal);
     const size_t pcr_limit = pcr_rows * (robot->desc.ndof <= 7 ? 100 : 50) / 100;
-    const bool use_pcr = !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
-    const bool use_rows = !use_pcr && (!prm.use_pose || g_rows_pose) && g_full_rows && robot->desc.ndof >= 3 &&
+    const bool use_pcr = !var_coupling && !prm.use_pose && W <= 512 && n <= pcr_limit && robot->desc.ndof >= 3 && robot->desc.ndof <= 8;
+    const bool use_rows = !var_coupling && !use_pcr && (!prm.use_pose || g_rows_pose) && g_full_rows && robot->desc.ndof >= 3 &&
                           robot->desc.ndof <= 12 && W <= (1 << 19);
-    prm.fold = use_rows;
+    prm.fold = use_rows || var_coupling;
     hipStream_t st = (hipStream_t)stream;
 #define CPPF_BODY                                                                                                     \
     if (n >= 131072)                                                                                                  \
         hipLaunchKernelGGL((full_blocks_kernel<RB, (RB::D <= 8)>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, \
-                           robot->chain, robot->coll, prm, x_in, target, virtual_configs, work_blocks);              \
+                           robot->chain, robot->coll, prm, x_in, target, virtual_configs, work_blocks, w2next);      \
     else                                                                                                              \
         hipLaunchKernelGGL((full_blocks_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, robot->chain, \
-                           robot->coll, prm, x_in, target, virtual_configs, work_blocks)
+                           robot->coll, prm, x_in, target, virtual_configs, work_blocks, w2next)
     CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     // Trajectories are eliminated one per wavefront (8 x 8 lane tile) up to 8 joints, one per lane beyond.  With the pose
@@ -985,6 +1005,12 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     // floored pivots copes with that better than the explicit Gauss-Jordan inverse, so it keeps that case.
     // Up to ~128k rows (the planner's cadence is one trajectory): parallel cyclic reduction, one workgroup per trajectory, one
     // lane per waypoint; beyond that its O(T log T) work and traffic lose against the waypoint-after-waypoint kernels
+    if (var_coupling) {
+        CPPF_DISPATCH_D(robot->desc.ndof,
+                        hipLaunchKernelGGL((full_solve_kernel<D, true>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,
+                                           robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out, w2next));
+        return check_launch(robot);
+    }
     if (use_pcr) {
         switch (robot->desc.ndof) {
 #define CPPF_PCR_CASE(DD)                                                                                              \
@@ -1056,15 +1082,15 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
                                robot->chain.pris_mask, x_in, work_blocks, work_G, work_y, x_out);                       \
         } else                                                                                                          \
             hipLaunchKernelGGL((full_solve_kernel<DD>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, robot->chain, \
-                               prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out);                         \
+                               prm, x_in, virtual_configs, work_blocks, work_G, work_y, x_out, nullptr);                \
         break;
-        CPPF_ROWS16_CASE(9) CPPF_ROWS16_CASE(10) CPPF_ROWS16_CASE(12)
+        CPPF_ROWS16_CASE(9) CPPF_ROWS16_CASE(10) CPPF_ROWS16_CASE(11) CPPF_ROWS16_CASE(12)
 #undef CPPF_ROWS16_CASE
         default:
             CPPF_DISPATCH_D(robot->desc.ndof,
                             hipLaunchKernelGGL((full_solve_kernel<D>), dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st,
                                                robot->chain, prm, x_in, virtual_configs, work_blocks, work_G, work_y,
-                                               x_out));
+                                               x_out, nullptr));
     }
     return check_launch(robot);
 }

@@ -26,7 +26,34 @@ struct FullK {
     int32_t S, W;
     int32_t fold;  // full_blocks_kernel also adds the differencing / virtual-config / lambda terms of its own waypoint (what
                    // full_rows_eliminate_kernel expects ready-made; the other elimination kernels add them in their own loops)
+    // The "satisfied" row options of LmResidualFns.get_r_and_J (cppflow/optimization_utils.py:514-533, 548-606; off in both
+    // presets).  Every one of them is a per-row weight (and, for rows left at full weight, a shift of the residual towards zero by
+    // the threshold): pose rows whose |error| is below the threshold are scaled down (:288-333); differencing rows whose |joint
+    // change| is below the threshold are dropped (filter_rows_from_r_J_differencing, :736-768) or scaled down (:352-398).
+    int32_t pose_scale_satisfied;  // pose_do_scale_down_satisfied
+    float pose_thr_m, pose_thr_rad, pose_scale;
+    int32_t diff_mode;  // 0 none, 1 differencing_do_ignore_satisfied (filter + shift to threshold), 2 differencing_do_scale_satisfied
+    float diff_thr_rad, diff_thr_m, diff_scale;
+    int32_t diff_shift_invalid;  // differencing_scale_down_satisfied_shift_invalid_to_threshold
 };
+
+// Weight (squared) and residual of ONE differencing row under the "satisfied" options.  rho = the wrapped joint change of the row,
+// a = alpha_differencing (x the prismatic scaling where the reference applies it: not in filter mode, optimization_utils.py:601).
+__device__ __forceinline__ void diff_row_options(const FullK& prm, bool pris, float rho, float& w2, float& rho_out) {
+    const float thr = pris ? prm.diff_thr_m : prm.diff_thr_rad;
+    float a = prm.a_diff * ((pris && prm.diff_mode != 1) ? prm.a_diff_pris : 1.f);
+    const float shifted = rho < -thr ? rho + thr : (rho > thr ? rho - thr : rho);
+    rho_out = rho;
+    if (prm.diff_mode == 1) {  // keep the rows with |rho| > thr, shifted to the threshold; the others are not in the system
+        a = fabsf(rho) > thr ? a : 0.f;
+        rho_out = shifted;
+    } else if (prm.diff_mode == 2) {
+        const bool valid = fabsf(rho) < thr;
+        a = valid ? a * prm.diff_scale : a;
+        rho_out = (!valid && prm.diff_shift_invalid) ? shifted : rho;
+    }
+    w2 = a * a;
+}
 
 // gradient of a point rigidly attached to moving link `link`, projected on n:  n . d(c)/dq_j  for every joint j
 template <class RB>
@@ -152,9 +179,30 @@ template <class RB>
 __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm, size_t row, const float (&q)[RB::D],
                                                  const float* __restrict__ x, const float* __restrict__ xv,
                                                  float (&M)[RB::D * (RB::D + 1) / 2], float (&m)[RB::D],
-                                                 float* __restrict__ blocks) {
+                                                 float* __restrict__ blocks, float* __restrict__ w2next) {
     constexpr int D = RB::D, NT = D * (D + 1) / 2;
-    if (prm.fold) {
+    if (prm.fold && prm.diff_mode != 0) {
+        // differencing rows carry individual weights: the two rows this waypoint is part of, (t, j) with its successor and
+        // (t-1, j) with its predecessor (the latter recomputed here: the same value bit for bit that waypoint t-1 computes), and
+        // the coupling of (t, j) goes to w2next for the elimination (full_solve_kernel<D, true>)
+        const int t = (int)(row % (size_t)prm.W), T = prm.W;
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float wn = 0.f, rn = 0.f, wp = 0.f, rp = 0.f;
+            if (prm.use_diff && has_next) diff_row_options(prm, rb.pris(j), wrap_pi(x[(row + 1) * D + j] - q[j]), wn, rn);
+            if (prm.use_diff && has_prev) diff_row_options(prm, rb.pris(j), wrap_pi(q[j] - x[(row - 1) * D + j]), wp, rp);
+            M[k] += wn + wp + (vq ? beta2 : 0.f) + prm.lm_lambda;
+            k += D - j;
+            m[j] = CPPF_FMA(wn, rn, m[j]);
+            m[j] = CPPF_FMA(-wp, rp, m[j]);
+            if (vq && xv) m[j] = CPPF_FMA(-beta2, wrap_pi(q[j] - xv[row * D + j]), m[j]);
+            w2next[row * D + j] = wn;
+        }
+    } else if (prm.fold) {
         const int t = (int)(row % (size_t)prm.W), T = prm.W;
         const bool has_next = t + 1 < T, has_prev = t > 0;
         const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
@@ -192,7 +240,8 @@ template <class RB, bool OCC4 = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4 : 1, OCC4 ? 4 : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ target,
-                                                             const float* __restrict__ xv, float* __restrict__ blocks) {
+                                                             const float* __restrict__ xv, float* __restrict__ blocks,
+                                                             float* __restrict__ w2next) {
     extern __shared__ float lds[];
     constexpr int D = RB::D;
     constexpr int NT = D * (D + 1) / 2;
@@ -242,7 +291,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
             for (int k = 0; k < NT; ++k) M[k] = 0.f;
 #pragma unroll
             for (int j = 0; j < D; ++j) m[j] = 0.f;
-            full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks);
+            full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks, w2next);
             return;
         }
     }
@@ -294,7 +343,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
         jacobian_from_axes<RB>(rb, pe, ax, og, J);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const float a = i < 3 ? prm.a_rot : prm.a_pos;
+            float a = i < 3 ? prm.a_rot : prm.a_pos;
+            // pose_do_scale_down_satisfied (optimization_utils.py:288-333, applied BEFORE the alphas at :514-533): a row whose
+            // unscaled |error| is below the threshold is scaled down, r and J alike
+            if (prm.pose_scale_satisfied && fabsf(e[i]) < (i < 3 ? prm.pose_thr_rad : prm.pose_thr_m)) a *= prm.pose_scale;
             float g[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) g[j] = a * J[i][j];
@@ -350,7 +402,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
                 }
             }
     }
-    full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks);
+    full_block_store<RB>(rb, prm, row, q, x, xv, M, m, blocks, w2next);
 }
 
 // inverse of a symmetric positive definite D x D matrix (full storage in, full storage out) by Cholesky; pivots floored
@@ -398,11 +450,13 @@ __device__ __forceinline__ void spd_inverse(const float (&A)[D][D], float floor_
         }
 }
 
-template <int D>
+// VAR: the differencing rows carry individual weights (the "satisfied" options): the blocks arrive with every waypoint-local term
+// folded in (full_block_store) and the coupling of waypoints t and t + 1 is -diag(w2next[t]) instead of the constant -diag(a^2).
+template <int D, bool VAR = false>
 __global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
                                                         const float* __restrict__ xv, const float* __restrict__ blocks,
                                                         float* __restrict__ workG, float* __restrict__ worky,
-                                                        float* __restrict__ x_out) {
+                                                        float* __restrict__ x_out, const float* __restrict__ w2next) {
     constexpr int NT = D * (D + 1) / 2;
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= prm.S) return;
@@ -436,21 +490,25 @@ __global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const F
             for (int j = 0; j < D; ++j) b[j] = blk[NT + j];
         }
         const bool has_next = t + 1 < T, has_prev = t > 0;
-        if (has_next) load_x<D>(x, base + t + 1, xn);
-        const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
-        const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+        if constexpr (VAR) {
+            if (has_prev) load_x<D>(w2next, base + t - 1, a2);  // the coupling with the predecessor
+        } else {
+            if (has_next) load_x<D>(x, base + t + 1, xn);
+            const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
+            const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            A[j][j] += cnt * a2[j] + (vq ? beta2 : 0.f) + prm.lm_lambda;
-            // J^T r of the differencing rows: +a^2 w_t at (t,j), -a^2 w_{t-1} at (t,j)   (w = wrapped joint change)
-            if (has_next) b[j] = CPPF_FMA(a2[j], wrap_pi(xn[j] - xc[j]), b[j]);
-            if (has_prev) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xp[j]), b[j]);
-        }
-        if (vq) {  // r = beta * wrap(x - x_virtual), J = -beta I  (optimization_utils.py:430-484)
-            float v[D];
-            if (xv) load_x<D>(xv, base + t, v);
+            for (int j = 0; j < D; ++j) {
+                A[j][j] += cnt * a2[j] + (vq ? beta2 : 0.f) + prm.lm_lambda;
+                // J^T r of the differencing rows: +a^2 w_t at (t,j), -a^2 w_{t-1} at (t,j)   (w = wrapped joint change)
+                if (has_next) b[j] = CPPF_FMA(a2[j], wrap_pi(xn[j] - xc[j]), b[j]);
+                if (has_prev) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xp[j]), b[j]);
+            }
+            if (vq) {  // r = beta * wrap(x - x_virtual), J = -beta I  (optimization_utils.py:430-484)
+                float v[D];
+                if (xv) load_x<D>(xv, base + t, v);
 #pragma unroll
-            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? wrap_pi(xc[j] - v[j]) : 0.f, b[j]);
+                for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? wrap_pi(xc[j] - v[j]) : 0.f, b[j]);
+            }
         }
         if (has_prev) {
             // D' = A - E G E ,  y = b - E G y_prev   with E = -diag(a2)
@@ -507,6 +565,9 @@ __global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const F
                     Gt[i][j] = v;
                     Gt[j][i] = v;
                 }
+        }
+        if constexpr (VAR) {
+            if (t + 1 < T) load_x<D>(w2next, base + t, a2);  // the coupling with the successor
         }
 #pragma unroll
         for (int j = 0; j < D; ++j) rhs[j] = (t + 1 < T) ? CPPF_FMA(a2[j], dl[j], yin[j]) : yin[j];

@@ -112,7 +112,8 @@ class LmResidualFns:
                                                    shift_invalid_to_threshold: bool = False):  # fmt: skip
         """Down-weight the pose rows that already satisfy their threshold (cppflow/optimization_utils.py:287-330; pinned by
         the known answer of tests/optimization_utils_test.py:405-456).  r [6n,1] and J are modified in place; returns
-        (r, J, rows that were NOT down-weighted).  Off in both presets: the device step does not apply it."""
+        (r, J, rows that were NOT down-weighted).  Off in both presets; the device step applies it row by row when switched on
+        (cppf_full_params.pose_do_scale_down_satisfied)."""
         assert r.shape[0] == J.shape[0] and r.shape[0] % 6 == 0 and r.numel() == r.shape[0] and 0.0 <= scale < 1.0
         rot_rows, _ = _get_rotation_and_position_row_mask(r.shape[0] // 6)
         thr = torch.where(rot_rows.to(r.device), error_threshold_rad, error_threshold_m).to(r.dtype)
@@ -189,23 +190,39 @@ class LmResidualFns:
 
     @staticmethod
     def get_r_and_J(pms, robot, x: torch.Tensor, target_path: torch.Tensor, Tcuboids: Optional[List] = None,
-                    cuboids: Optional[List] = None) -> Tuple[LmJacobian, LmResidual]:  # fmt: skip
-        # The three "satisfied" options are off in both presets; in the reference they read `pms.constraints`, a field
-        # OptimizationParameters does not have (optimization_utils.py:514-519, 562-567), so that path cannot run there either.
-        # The row operations themselves are provided above and pinned by the reference's known answers.
-        assert not pms.pose_do_scale_down_satisfied and not pms.differencing_do_ignore_satisfied, "option not implemented"
-        assert not pms.differencing_do_scale_satisfied, "option not implemented"
+                    cuboids: Optional[List] = None, constraints=None) -> Tuple[LmJacobian, LmResidual]:  # fmt: skip
+        """The dense residual / Jacobian of cppflow/optimization_utils.py:486-731, the three "satisfied" options included
+        (:514-533 pose scale-down, :562-598 differencing filter / scale-down).  In the reference those options read
+        `pms.constraints`, a field OptimizationParameters does not have, so that path cannot run there as committed; here the
+        Constraints come from the argument, else from `pms.constraints` if present, else DEFAULT_CONSTRAINTS."""
+        assert not (pms.differencing_do_scale_satisfied and pms.differencing_do_ignore_satisfied), "use one or the other, not both"
+        thr = satisfied_thresholds(pms, constraints)
         n, d = x.shape
         residual, jacobian = LmResidual(), LmJacobian()
         if pms.use_pose:
             r_pose, _ = LmResidualFns._get_residual_pose(robot, x, target_path)
             J_pose = LmResidualFns._get_jacobian_pose(robot, x)
+            if pms.pose_do_scale_down_satisfied:  # before the alphas (optimization_utils.py:514-533)
+                r_pose, J_pose, invalid = LmResidualFns._scale_down_rows_from_r_J_pose_below_error(
+                    r_pose, J_pose, error_threshold_m=thr["pose_threshold_m"], error_threshold_rad=thr["pose_threshold_rad"],
+                    scale=pms.pose_ignore_satisfied_scale_down)  # fmt: skip
+                residual.pose_invalid_row_idxs = jacobian.pose_invalid_row_idxs = invalid
             scale = torch.tensor([pms.alpha_rotation] * 3 + [pms.alpha_position] * 3, dtype=x.dtype, device=x.device).repeat(n)
             residual.pose, jacobian.pose = r_pose * scale[:, None], J_pose * scale[:, None]
         if pms.use_differencing:
             r_diff = LmResidualFns._get_residual_differencing(robot, x)
             J_diff = LmResidualFns._get_jacobian_differencing(robot, x)
-            if robot.has_prismatic_joints:
+            if pms.differencing_do_ignore_satisfied:  # option 1 (:572-580): drop the satisfied rows, shift the others
+                r_diff, J_diff = filter_rows_from_r_J_differencing(
+                    robot, r_diff, J_diff, threshold_rad=thr["differencing_threshold_rad"],
+                    threshold_m=thr["differencing_threshold_m"], shift_to_threshold=True)  # fmt: skip
+            if pms.differencing_do_scale_satisfied:  # option 2 (:583-597): scale the satisfied rows down
+                J_diff, r_diff, invalid = LmResidualFns._scale_down_rows_from_r_J_differencing_below_error(
+                    robot, r_diff, J_diff, mjac_threshold_m=thr["differencing_threshold_m"],
+                    mjac_threshold_rad=thr["differencing_threshold_rad"], scale=pms.differencing_scale_down_satisfied_scale,
+                    shift_invalid_to_threshold=bool(pms.differencing_scale_down_satisfied_shift_invalid_to_threshold))  # fmt: skip
+                residual.differencing_invalid_row_idxs = jacobian.differencing_invalid_row_idxs = invalid
+            if robot.has_prismatic_joints and not pms.differencing_do_ignore_satisfied:  # (:601: not in filter mode)
                 _, pris_rows = _get_prismatic_and_revolute_row_mask(robot, r_diff.shape[0])
                 r_diff[pris_rows] *= pms.alpha_differencing_prismatic_scaling
                 J_diff[pris_rows] *= pms.alpha_differencing_prismatic_scaling
@@ -232,6 +249,27 @@ class LmResidualFns:
                 residual.env_collisions, jacobian.env_collisions = torch.cat(rs, dim=0), torch.cat(Js, dim=0)
         jacobian.verify_r(residual)
         return jacobian, residual
+
+
+def satisfied_thresholds(pms, constraints=None) -> dict:
+    """The thresholds of the "satisfied" row options exactly as LmResidualFns.get_r_and_J forms them
+    (cppflow/optimization_utils.py:515-520, 562-567) -- including that the ROTATION threshold of the pose option is
+    `scale * max_allowed_rotation_error_deg` used as radians (:518-520 pass degrees where radians are compared) -- for the dense
+    mirror below and for the device step (Robot.lm_full_step -> cppf_full_params)."""
+    import numpy as np
+
+    from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
+    from cppflow_amd.utils import cm_to_m
+
+    c = constraints if constraints is not None else (getattr(pms, "constraints", None) or DEFAULT_CONSTRAINTS)
+    out = {"pose_threshold_m": 0.0, "pose_threshold_rad": 0.0, "differencing_threshold_rad": 0.0, "differencing_threshold_m": 0.0}
+    if pms.pose_do_scale_down_satisfied:
+        out["pose_threshold_m"] = float(pms.pose_ignore_satisfied_threshold_scale * c.max_allowed_position_error_m)
+        out["pose_threshold_rad"] = float(pms.pose_ignore_satisfied_threshold_scale * c.max_allowed_rotation_error_deg)
+    if pms.differencing_do_ignore_satisfied or pms.differencing_do_scale_satisfied:
+        out["differencing_threshold_rad"] = float(np.deg2rad(c.max_allowed_mjac_deg - pms.differencing_ignore_satisfied_margin_deg))
+        out["differencing_threshold_m"] = float(cm_to_m(c.max_allowed_mjac_cm - pms.differencing_ignore_satisfied_margin_cm))
+    return out
 
 
 def _down_weight_rows(r: torch.Tensor, J: torch.Tensor, thr: torch.Tensor, scale: float, shift: bool):

@@ -533,16 +533,20 @@ class Robot:
         return out
 
     def lm_full_step(self, x: torch.Tensor, target: torch.Tensor, opt_params, virtual_configs: Optional[torch.Tensor] = None,
-                     x_out: Optional[torch.Tensor] = None) -> torch.Tensor:  # fmt: skip
+                     x_out: Optional[torch.Tensor] = None, constraints=None) -> torch.Tensor:  # fmt: skip
         """One coupled LM step (levenberg_marquardt_full, cppflow/optimization.py:95-144) for every trajectory in
-        x [S*W, d]; target [W,7].  `opt_params` is an OptimizationParameters (e.g. ALT_LOSS_V2_1_DIFF)."""
+        x [S*W, d]; target [W,7].  `opt_params` is an OptimizationParameters (e.g. ALT_LOSS_V2_1_DIFF); its "satisfied" row
+        options (pose scale-down, differencing filter / scale-down: cppflow/optimization_utils.py:514-533, 562-598) are applied
+        on the device, with thresholds from `constraints` (default: opt_params.constraints if present, else DEFAULT_CONSTRAINTS)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]
         assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0
         p = opt_params
-        assert not p.pose_do_scale_down_satisfied and not p.differencing_do_ignore_satisfied, "option not implemented"
-        assert not p.differencing_do_scale_satisfied, "option not implemented"
+        assert not (p.differencing_do_scale_satisfied and p.differencing_do_ignore_satisfied), "use one or the other, not both"
+        from cppflow_amd.optimization_utils import satisfied_thresholds
+
+        thr = satisfied_thresholds(p, constraints)
         xv = None
         if virtual_configs is not None and p.use_virtual_configs and virtual_configs.numel() > 0:
             xv = self._x2d(virtual_configs, "virtual_configs")
@@ -555,7 +559,13 @@ class Robot:
                               f(p.alpha_differencing_prismatic_scaling), f(p.alpha_virtual_configs),
                               f(p.alpha_self_collision), f(p.alpha_env_collision), int(bool(p.use_pose)),
                               int(bool(p.use_differencing)), int(bool(p.use_virtual_configs)), int(p.n_virtual_configs or 0),
-                              int(bool(p.use_self_collisions)), int(bool(p.use_env_collisions)))  # fmt: skip
+                              int(bool(p.use_self_collisions)), int(bool(p.use_env_collisions)),
+                              int(bool(p.pose_do_scale_down_satisfied)), thr["pose_threshold_m"], thr["pose_threshold_rad"],
+                              f(p.pose_ignore_satisfied_scale_down),
+                              1 if p.differencing_do_ignore_satisfied else (2 if p.differencing_do_scale_satisfied else 0),
+                              thr["differencing_threshold_rad"], thr["differencing_threshold_m"],
+                              f(p.differencing_scale_down_satisfied_scale),
+                              int(bool(p.differencing_scale_down_satisfied_shift_invalid_to_threshold)))  # fmt: skip
         d = self.ndof
         nt = d * (d + 1) // 2
         dev = x.device

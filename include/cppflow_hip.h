@@ -272,11 +272,26 @@ typedef struct cppf_full_params {
     float alpha_virtual_configs;                 /* multiplies alpha_differencing */
     float alpha_self_collision, alpha_env_collision; /* 0.01, 0.01 */
     int32_t use_pose, use_differencing, use_virtual_configs, n_virtual_configs, use_self_collisions, use_env_collisions;
+    /* The "satisfied" row options of LmResidualFns.get_r_and_J (off in both presets; all zero = off).
+     *   pose_do_scale_down_satisfied (cppflow/optimization_utils.py:514-533, :288-333): a pose row whose unscaled |error| is below
+     *     pose_threshold_rad (rotation rows) / pose_threshold_m (position rows) is multiplied by pose_scale_down, r and J alike.
+     *     The caller forms the thresholds (the reference: pose_ignore_satisfied_threshold_scale x the constraint).
+     *   differencing_mode (:548-606): 1 = differencing_do_ignore_satisfied -- rows with |joint change| <= threshold leave the system,
+     *     the others are shifted towards zero by the threshold (filter_rows_from_r_J_differencing, :736-768; no prismatic scaling
+     *     in this mode, :601); 2 = differencing_do_scale_satisfied -- rows below the threshold are multiplied by
+     *     differencing_scale_down, the others optionally shifted (:352-398).  Thresholds: rad for revolute, m for prismatic
+     *     joints (the reference: max_allowed_mjac - margin).  A step with differencing_mode != 0 is eliminated by the
+     *     one-lane-per-trajectory kernel (the couplings between consecutive waypoints differ from row to row). */
+    int32_t pose_do_scale_down_satisfied;
+    float pose_threshold_m, pose_threshold_rad, pose_scale_down;
+    int32_t differencing_mode;
+    float differencing_threshold_rad, differencing_threshold_m, differencing_scale_down;
+    int32_t differencing_shift_invalid_to_threshold;
 } cppf_full_params;
 
 /* levenberg_marquardt_full (cppflow/optimization.py:95-144) with the residual / Jacobian of LmResidualFns.get_r_and_J
- * (cppflow/optimization_utils.py:486-731; the "satisfied" scaling / filtering options, off in both presets, are not
- * implemented): one coupled LM step for each of S trajectories x_in [S*W, d] (the reference: one trajectory, :128).
+ * (cppflow/optimization_utils.py:486-731, the "satisfied" scaling / filtering options included): one coupled LM step for each
+ * of S trajectories x_in [S*W, d] (the reference: one trajectory, :128).
  * target [W,7]; virtual_configs [S*W, d] or NULL (= x_in, which is what the loop sets at optimization.py:253).
  * Obstacles are those of cppf_set_obstacles.  The normal matrix is never formed densely: it is block-tridiagonal and is
  * eliminated per trajectory.  Workspace (device): work_blocks [S*W * (d(d+1)/2 + d)], work_G [S*W * d*d],

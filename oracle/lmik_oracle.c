@@ -1053,6 +1053,13 @@ typedef struct {
     double lm_lambda, alpha_position, alpha_rotation, alpha_differencing, alpha_differencing_prismatic_scaling,
         alpha_virtual_configs, alpha_self_collision, alpha_env_collision;
     int use_pose, use_differencing, use_virtual_configs, n_virtual_configs, use_self_collisions, use_env_collisions;
+    /* the "satisfied" row options of LmResidualFns.get_r_and_J (cppflow/optimization_utils.py:514-533, 562-598); thresholds as
+     * the reference forms them (oracle.py: FullParams.from_params) */
+    int pose_do_scale_down_satisfied;
+    double pose_threshold_m, pose_threshold_rad, pose_scale_down;
+    int differencing_mode; /* 0 none, 1 differencing_do_ignore_satisfied, 2 differencing_do_scale_satisfied */
+    double differencing_threshold_rad, differencing_threshold_m, differencing_scale_down;
+    int differencing_shift_invalid_to_threshold;
 } orc_full_params;
 
 /* d(point rigidly attached to moving link `link`)/dq_j, world frame: z_j x (c - o_j) (revolute) or z_j (prismatic) for
@@ -1177,7 +1184,12 @@ static int full_rows(const orc_robot* rb, const orc_full_params* pm, const REAL*
             frame_to_pose(&ee, cur);
             pose_error_row(cur, target + (size_t)t * 7, e);
             for (int i = 0; i < 6; ++i) {
-                const REAL a = (REAL)(i < 3 ? pm->alpha_rotation : pm->alpha_position);
+                REAL a = (REAL)(i < 3 ? pm->alpha_rotation : pm->alpha_position);
+                /* _scale_down_rows_from_r_J_pose_below_error (:288-333), applied to the UNSCALED rows before the alphas (:514-533):
+                 * rotation rows against the rad threshold, position rows against the m threshold */
+                if (pm->pose_do_scale_down_satisfied &&
+                    FABS(e[i]) < (REAL)(i < 3 ? pm->pose_threshold_rad : pm->pose_threshold_m))
+                    a *= (REAL)pm->pose_scale_down;
                 for (int j = 0; j < d; ++j) jt[j] = a * Jt[i * d + j];
                 if (emit(ctx, a * e[i], t, jt, NULL)) return -1;
                 ++row;
@@ -1188,11 +1200,24 @@ static int full_rows(const orc_robot* rb, const orc_full_params* pm, const REAL*
         for (int t = 0; t + 1 < T; ++t)
             for (int j = 0; j < d; ++j) {
                 REAL a = (REAL)pm->alpha_differencing;
-                if (rb->jtype[j] == 1) a *= (REAL)pm->alpha_differencing_prismatic_scaling;
+                REAL rho = wrap_pi(x[(size_t)(t + 1) * d + j] - x[(size_t)t * d + j]);
+                const REAL thr = (REAL)(rb->jtype[j] == 1 ? pm->differencing_threshold_m : pm->differencing_threshold_rad);
+                const REAL shifted = rho < -thr ? rho + thr : (rho > thr ? rho - thr : rho);
+                if (pm->differencing_mode == 1) { /* filter_rows_from_r_J_differencing (:736-768), shift_to_threshold = True (:572-580) */
+                    if (!(FABS(rho) > thr)) continue; /* the row is not in the system */
+                    rho = shifted;
+                } else if (pm->differencing_mode == 2) { /* _scale_down_rows_from_r_J_differencing_below_error (:352-398) */
+                    if (FABS(rho) < thr)
+                        a *= (REAL)pm->differencing_scale_down;
+                    else if (pm->differencing_shift_invalid_to_threshold)
+                        rho = shifted;
+                }
+                /* the prismatic scaling is skipped in filter mode (:601) */
+                if (rb->jtype[j] == 1 && pm->differencing_mode != 1) a *= (REAL)pm->alpha_differencing_prismatic_scaling;
                 for (int c = 0; c < d; ++c) jt[c] = jt2[c] = 0;
                 jt[j] = a;
                 jt2[j] = -a;
-                if (emit(ctx, a * wrap_pi(x[(size_t)(t + 1) * d + j] - x[(size_t)t * d + j]), t, jt, jt2)) return -1;
+                if (emit(ctx, a * rho, t, jt, jt2)) return -1;
                 ++row;
             }
     }

@@ -34,18 +34,40 @@ class FullParams(ctypes.Structure):
         "lm_lambda", "alpha_position", "alpha_rotation", "alpha_differencing", "alpha_differencing_prismatic_scaling",
         "alpha_virtual_configs", "alpha_self_collision", "alpha_env_collision")] + [(k, ctypes.c_int) for k in (
         "use_pose", "use_differencing", "use_virtual_configs", "n_virtual_configs", "use_self_collisions",
-        "use_env_collisions")]  # fmt: skip
+        "use_env_collisions")] + [
+        ("pose_do_scale_down_satisfied", ctypes.c_int), ("pose_threshold_m", ctypes.c_double), ("pose_threshold_rad", ctypes.c_double),
+        ("pose_scale_down", ctypes.c_double), ("differencing_mode", ctypes.c_int), ("differencing_threshold_rad", ctypes.c_double),
+        ("differencing_threshold_m", ctypes.c_double), ("differencing_scale_down", ctypes.c_double),
+        ("differencing_shift_invalid_to_threshold", ctypes.c_int)]  # fmt: skip
 
     @classmethod
-    def from_params(cls, p):
+    def from_params(cls, p, constraints=None):
+        """`constraints`: max_allowed_position_error_cm / rotation_error_deg / mjac_deg / mjac_cm (the reference reads
+        `pms.constraints`, which OptimizationParameters does not have; default = the values of its CLI, scripts/evaluate.py:51-56).
+        Thresholds restated from cppflow/optimization_utils.py:515-520 (pose: threshold_scale x max_allowed_position_error_m and
+        threshold_scale x max_allowed_rotation_error_DEG, the degrees compared with radians as the reference does) and :562-567
+        (differencing: deg2rad(max_allowed_mjac_deg - margin_deg), (max_allowed_mjac_cm - margin_cm) / 100)."""
         def f(v):
             return 0.0 if v is None else float(v)
 
+        c = constraints if constraints is not None else getattr(p, "constraints", None)
+        pos_cm, rot_deg, mj_deg, mj_cm = ((c.max_allowed_position_error_cm, c.max_allowed_rotation_error_deg, c.max_allowed_mjac_deg,
+                                           c.max_allowed_mjac_cm) if c is not None else (0.01, 0.1, 7.0, 2.0))
+        pose_on = bool(getattr(p, "pose_do_scale_down_satisfied", False))
+        mode = 1 if getattr(p, "differencing_do_ignore_satisfied", False) else (2 if getattr(p, "differencing_do_scale_satisfied", False) else 0)
+        assert not (getattr(p, "differencing_do_ignore_satisfied", False) and getattr(p, "differencing_do_scale_satisfied", False))
+        ts = f(getattr(p, "pose_ignore_satisfied_threshold_scale", None))
         return cls(f(p.lm_lambda), f(p.alpha_position), f(p.alpha_rotation), f(p.alpha_differencing),
                    f(p.alpha_differencing_prismatic_scaling), f(p.alpha_virtual_configs), f(p.alpha_self_collision),
                    f(p.alpha_env_collision), int(bool(p.use_pose)), int(bool(p.use_differencing)),
                    int(bool(p.use_virtual_configs)), int(p.n_virtual_configs or 0), int(bool(p.use_self_collisions)),
-                   int(bool(p.use_env_collisions)))  # fmt: skip
+                   int(bool(p.use_env_collisions)),
+                   int(pose_on), ts * pos_cm / 100.0 if pose_on else 0.0, ts * rot_deg if pose_on else 0.0,
+                   f(getattr(p, "pose_ignore_satisfied_scale_down", None)), mode,
+                   float(np.deg2rad(mj_deg - f(getattr(p, "differencing_ignore_satisfied_margin_deg", None)))) if mode else 0.0,
+                   (mj_cm - f(getattr(p, "differencing_ignore_satisfied_margin_cm", None))) / 100.0 if mode else 0.0,
+                   f(getattr(p, "differencing_scale_down_satisfied_scale", None)),
+                   int(bool(getattr(p, "differencing_scale_down_satisfied_shift_invalid_to_threshold", False))))  # fmt: skip
 
 
 def _lib(f32: bool):
@@ -310,7 +332,7 @@ class Oracle:
         return dists, grads
 
     def lm_full_step(self, x, target, params, S, T, virtual_configs=None, boxes_lo=None, boxes_hi=None, return_residual=False,
-                     banded=False):
+                     banded=False, constraints=None):
         """One coupled LM step (cppflow/optimization.py:95-144) for S trajectories x [S*T,d]; target [T,7] shared.
         `params` is an OptimizationParameters-like object.  Returns x_new (and the first trajectory's stacked residual).
         `banded`: the same rows accumulated into band storage and solved by a banded Cholesky (O(T d^3) per trajectory instead of
@@ -320,7 +342,7 @@ class Oracle:
         xv = _d(virtual_configs) if virtual_configs is not None else None
         lo = _d(boxes_lo).reshape(-1, 3) if boxes_lo is not None and len(boxes_lo) else np.zeros((0, 3))
         hi = _d(boxes_hi).reshape(-1, 3) if boxes_hi is not None and len(boxes_hi) else np.zeros((0, 3))
-        fp = FullParams.from_params(params)
+        fp = FullParams.from_params(params, constraints)
         out = np.empty_like(x)
         if banded:
             assert not return_residual

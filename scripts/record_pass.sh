@@ -34,8 +34,12 @@ echo "== bench, one-rank RCCL group (collective + seed selection on the dependen
 CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings > "$OUT/bench_dist1.json" 2>> "$OUT/bench.err"
 echo "== bench, two ranks sharing the one GPU (host-staged gloo: choreography rehearsal, NOT a multi-GPU result)"
 CPPF_BENCH_SHARE_GPU=1 timeout -k 10 300 python bench.py --gpus 2 --steps 300 --warmup 48 > "$OUT/bench_2ranks_rehearsal.json" 2>> "$OUT/bench.err"
-echo "== bench, the fp64 solve"
+echo "== bench, the other solver modes: every row in double precision / fp32 without the conditioning gate (what the gate costs)"
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings --solver f64 > "$OUT/bench_solver_f64.json" 2>> "$OUT/bench.err"
+timeout -k 10 300 python bench.py --no-cpu-baseline --solver f32 > "$OUT/bench_solver_f32.json" 2>> "$OUT/bench.err"
+echo "== which rows the gate flags, per iteration (bench inputs and independent random configurations)"
+timeout -k 10 200 python scripts/gate_census.py > "$OUT/gate_census_problem.txt" 2>> "$OUT/bench.err"
+timeout -k 10 200 python scripts/gate_census.py --inputs random > "$OUT/gate_census_random.txt" 2>> "$OUT/bench.err"
 for c in C2 C3 C5; do
     echo "== bench --config $c"
     timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings --config $c > "$OUT/bench_$c.json" 2>> "$OUT/bench.err"

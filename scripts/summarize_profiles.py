@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 databases of scripts/record_pass.sh (gpurun_out/rec/) into the small summaries kept under profiles/.
 
-    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r2]
+    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r3]
 
 Writes  <tag>_fused_kernel_stats.csv (rocprofv3's own kernel_stats), <tag>_pmc_summary.json (kernel-trace duration of the bench
 launch, FETCH / WRITE_SIZE, and per labelled variant of scripts/pmc_probe.py every SQ counter of the four counter passes with the
@@ -17,7 +17,7 @@ import sys
 
 REC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/rec"
 OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-TAG = sys.argv[3] if len(sys.argv) > 3 else "r2"
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r3"
 FUSED = "lm_fused_kernel"
 PROBE_KERNELS = ("lm_fused_kernel", "lm_quad_kernel", "collision_kernel")
 
@@ -27,10 +27,13 @@ def read_csv(rel):
         return list(csv.DictReader(f))
 
 
-def kernel_stats(grid):
-    """--kernel-trace --stats: rocprofv3's own kernel_stats.csv is kept as is; the bench launches are the dispatches of
+def kernel_stats(grid, build_id):
+    """--kernel-trace --stats: rocprofv3's own kernel_stats.csv is kept as is behind ONE comment line naming the library build it
+    was taken with (bench.py's roofline.kernel_ms_profile reads it only for that build); the bench launches are the dispatches of
     the fused kernel with the full grid (the input generator also runs it, on S rows at a time)."""
-    shutil.copy(os.path.join(REC, "kt/kt_kernel_stats.csv"), os.path.join(OUT, f"{TAG}_fused_kernel_stats.csv"))
+    with open(os.path.join(REC, "kt/kt_kernel_stats.csv")) as src, open(os.path.join(OUT, f"{TAG}_fused_kernel_stats.csv"), "w") as dst:
+        dst.write(f"# build_id={build_id}\n")
+        dst.write(src.read())
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in read_csv("kt/kt_kernel_trace.csv")
          if FUSED in r["Kernel_Name"] and int(r["Grid_Size_X"]) == grid]  # fmt: skip
     return {"calls": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d), "stdev_ns": statistics.pstdev(d)}
@@ -69,7 +72,8 @@ def main():
     bench = json.load(open(os.path.join(REC, "bench.json")))
     cfg = bench["config"]
     grid = cfg["seeds_per_gpu"] * cfg["waypoints"]
-    summary = {"kernel_trace": kernel_stats(grid)}
+    build_id = bench["roofline"]["library_build_id"]  # every record of this pass is keyed by the library build it was taken with
+    summary = {"library_build_id": build_id, "kernel_trace": kernel_stats(grid, build_id)}
     fetch = counter("pmc_fetch/pmc_counter_collection.csv", "FETCH_SIZE", grid)
     write = counter("pmc_write/pmc_counter_collection.csv", "WRITE_SIZE", grid)
     for key, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
@@ -118,6 +122,7 @@ def main():
     summary["sq_counters_scripts_pmc_probe_last_round"] = disp
     with open(os.path.join(OUT, f"{TAG}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    issue["_build_id"] = build_id
     issue["_how"] = ("rocprofv3 --pmc SQ_INSTS_VALU ... / --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32 "
                      "-- python3 scripts/pmc_probe.py (scripts/record_pass.sh): wave-instruction counts of ONE launch of the matching workload.  "
                      "flops_per_valu_lane_op = (2 FMA + ADD + MUL + TRANS) / VALU: executed flops per VALU lane-operation, measured, not modelled.")  # fmt: skip
@@ -145,6 +150,7 @@ def main():
     key = f"{cfg['robot']}_S{cfg['seeds_per_gpu']}_W{cfg['waypoints']}_K{cfg['lm_iterations_per_step']}_coll{int(cfg['collision_fused'])}"
     fk, wk = summary["FETCH_SIZE"]["mean_KB"], summary["WRITE_SIZE"]["mean_KB"]
     traffic = {
+        "_build_id": build_id,
         "_how": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 ; "
         "rocprofv3 --pmc WRITE_SIZE -- (same): scripts/record_pass.sh.  Mean over the lm_fused_kernel dispatches.  FETCH_SIZE (KB) is doubled "
         "(gfx950 reports half the bytes of a coalesced stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE (KB) is exact.",
@@ -158,7 +164,7 @@ def main():
     }
     with open(os.path.join(OUT, f"{TAG}_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=2)
-    for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_C2.json", "bench_C3.json",
+    for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_solver_f32.json", "bench_random_solver_f32.json", "gate_census_problem.txt", "gate_census_random.txt", "bench_C2.json", "bench_C3.json",
                 "bench_C5.json", "shard_streams.txt", "hwq_sweep.txt", "shard_bench.txt", "shard_bench_mfma.txt", "mfma_chain12.txt", "ksweep.txt", "dp_bench.txt", "coupled_bench.txt", "coupled_dp_kernels.txt", "lone_wave_micro.txt", "kbench.txt",
                 "kbench_small.txt", "launch_model.txt", "rtc_bench.txt", "pytest_gpu.txt", "valu_issue_rate_calibration.txt"):  # fmt: skip
         if os.path.exists(os.path.join(REC, src)):
