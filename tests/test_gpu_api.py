@@ -336,6 +336,17 @@ def test_c5_full_size(robots):
     assert np.array_equal(r["self_mask"][rows.to(DEV)].cpu().numpy(), m["self_mask"])
     assert np.array_equal(r["env_mask"][rows.to(DEV)].cpu().numpy(), m["env_mask"])
     assert np.array_equal(host(r["min_self"][rows.to(DEV)]), m["min_self"])
+    # the K-step LM result itself on the sampled rows against the fp64 reference-order oracle
+    o64 = H.oracle64("chain12")
+    x0_s = host(x0[rows.to(DEV)])
+    x_o = o64.lm_steps(x0_s, tgt, 10, 1e-6, 3.5, 0.35, solver=0)
+    pe_o, re_o = o64.pose_metrics_exact(x_o, tgt)
+    pe_g, re_g = host(r["pos_err_m"][rows.to(DEV)]), host(r["rot_err_rad"][rows.to(DEV)])
+    conv, conv_g = (pe_o < 1e-4) & (re_o < 1.2e-3), (pe_g < 1e-4) & (re_g < 1.2e-3)
+    assert conv.mean() > 0.9 and abs(conv_g.mean() - conv.mean()) < 0.01
+    settled = conv & conv_g & (pe_o < 5e-6)
+    assert settled.sum() > 0.8 * conv.sum()
+    assert np.abs(pe_g - pe_o)[settled].max() < 1e-5 and np.abs(re_g - re_o)[settled].max() < 1e-5
     rb.set_obstacles([], [])
 
 

@@ -202,6 +202,8 @@ def test_validity_flags_agree_with_reference_order_fp32_formula(robots, name):
     print(f"{name}: {n_band} of {S * W} rows inside the acos quantisation band, {n_disagree} flag disagreements, all inside it")
 
 
+CONV_FLOOR = {"C2": 0.95, "C3": 0.5, "C4": 0.95}  # measured 0.980 / 0.553 (Fetch: the prismatic torso runs into its limits) / 0.980
+
 CONFIGS = {
     "C2": ("panda", "panda__1cube_first64", 128, []),
     "C3": ("fetch", "fetch__hello_first256", 512, []),
@@ -224,12 +226,12 @@ def test_full_size_configs_sampled_against_the_oracle(robots, cfg):
     target = np.load(os.path.join(GOLDEN, "reference_paths.npz"))[key]
     W, K = target.shape[0], 10
     problem = problem_from_arrays(rb, target, obs, device=DEV)
-    ch = H.chain(name)
+    # the seeds bench.py itself measures on: per seed an IK branch tracking the path, + 0.1 randn, clamped
+    import bench
+
     g = torch.Generator().manual_seed(1)
-    lo, hi = torch.tensor(ch.lo, dtype=torch.float32), torch.tensor(ch.hi, dtype=torch.float32)
-    x_rand = (lo + (hi - lo) * (0.15 + 0.7 * torch.rand((S * W, rb.ndof), generator=g))).to(DEV)
-    ik = rb.lm_pose_steps(x_rand, problem.target_path, 1e-2, 3.5, 0.35, n_steps=60)
-    x0 = torch.minimum(torch.maximum(ik["x"] + 0.1 * torch.randn((S * W, rb.ndof), generator=g).to(DEV), lo.to(DEV)), hi.to(DEV)).contiguous()
+    x0, target_b, _ = bench.make_inputs_problem(rb, S, W, torch.device(DEV), seed=1)
+    assert torch.equal(target_b.cpu(), torch.tensor(target, dtype=torch.float32))
     r = run_lm_pose_refinement(problem, x0, n_steps=K)  # binds the obstacles and the default joint-limit padding
     rows = torch.randperm(S * W, generator=g)[:4096]
     rows_d = rows.to(DEV)
@@ -240,7 +242,8 @@ def test_full_size_configs_sampled_against_the_oracle(robots, cfg):
     x_o = o64.lm_steps(x0_s, tgt_s, K, solver=0, **LM)
     pe_o, re_o = o64.pose_metrics_exact(x_o, tgt_s)
     conv = (pe_o < 1e-4) & (re_o < 1.2e-3)
-    assert conv.mean() > 0.25, conv.mean()  # (the seeds are IK attempts from random starts: not every one is on a branch)
+    print(f"{cfg}: oracle converges on {conv.mean():.3f} of the sampled rows")
+    assert conv.mean() > CONV_FLOOR[cfg], conv.mean()
     pe_g, re_g = host(r.pos_err_m.view(-1)[rows_d]), host(r.rot_err_rad.view(-1)[rows_d])
     conv_g = (pe_g < 1e-4) & (re_g < 1.2e-3)
     both = conv & conv_g
@@ -260,15 +263,19 @@ def test_full_size_configs_sampled_against_the_oracle(robots, cfg):
     assert np.array_equal(r.env_mask.view(-1)[rows_d].cpu().numpy().astype(np.uint8), m["env_mask"])
     assert np.array_equal(r.jlim_mask.view(-1)[rows_d].cpu().numpy().astype(np.uint8), m["jlim_mask"])
     assert np.array_equal(host(r.ext_cost.view(-1)[rows_d]), m["ext_cost"])
-    # one step on the sampled rows: task space, fp64 solve on every row, fp32 solve by its bound
+    # one step on the sampled rows, task space: fp64 solve <= 2e-5 on every row; the default (conditioning-gated) solve never
+    # worse than the reference-order fp32 arithmetic on the same rows
     x64, Js, es, _ = o64.lm_step(x0_s, tgt_s, solver=0, **LM)
-    sv = np.linalg.svd(Js, compute_uv=False)
-    bound = 2e-5 + 2e-7 * sv[:, 0] ** 2 / (sv[:, -1] ** 2 + 1e-6) * np.linalg.norm(es, axis=1)
+    x32_ref, _, _, _ = o32.lm_step(x0_s, tgt_s, solver=0, **LM)
     full64 = rb.lm_pose_steps(x0, problem.target_path, n_steps=1, clamp=False, solver=_hip.SOLVER_F64, **LM)["x"]
-    full32 = rb.lm_pose_steps(x0, problem.target_path, n_steps=1, clamp=False, **LM)["x"]
+    full_auto = rb.lm_pose_steps(x0, problem.target_path, n_steps=1, clamp=False, **LM)["x"]
     ts64 = _task_space(Js, host(full64[rows_d]) - x64)
-    ts32 = _task_space(Js, host(full32[rows_d]) - x64)
+    ts_auto = _task_space(Js, host(full_auto[rows_d]) - x64)
+    ts_ref = _task_space(Js, x32_ref - x64)
     assert ts64.max() <= 2e-5, ts64.max()
-    assert (ts32 <= bound).all() and np.quantile(ts32, 0.9) <= 2e-5, (np.max(ts32 / bound), np.quantile(ts32, QS))
+    assert ts_auto.max() <= max(ts_ref.max(), 1e-4), (ts_auto.max(), ts_ref.max())
+    # (on these well-conditioned planner inputs both sit at the fp32 floor of FK + Jacobian, ~1e-6 in scaled task space: the
+    # quantile rule gets a floor of 5e-6 here; the all-rows test above holds it without one on the ill-conditioned random seeds)
+    assert np.quantile(ts_auto, 0.99) <= max(2.0 * np.quantile(ts_ref, 0.99), 5e-6), (np.quantile(ts_auto, QS), np.quantile(ts_ref, QS))
     rb.set_obstacles([], [])
     rb.set_joint_limit_padding(None, None)
