@@ -371,8 +371,12 @@ struct GateLds {
 };
 
 // solve slot `s` (J [6][D] at elements i * D + k, e at 6 D + i) in double precision; delta [D] comes back in elements 0 .. D-1.
-// The two passes over J are ROLLED loops over the joints (6 LDS reads per trip): unrolled, the compiler issues all 6 D reads up
-// front and the conversions of the first pass stay alive for the second -- 188 VGPRs for the kernel instead of < 128.
+// The wavefront that runs this is waiting for it (a round is pure latency for a launch of one wavefront per SIMD), so the code is
+// laid out for short dependency chains where registers allow: A is formed in a rolled loop over the joints with the next column
+// requested one trip ahead (21 independent accumulation chains; unrolled, the kernel spills 111 registers), J^T y is D independent
+// chains fully unrolled (A is dead by then), with a compiler barrier between the two passes over J (without it the 6 D
+// conversions of the first pass are kept alive across the factorisation: +84 VGPRs), and one Newton step on v_rsq_f64 (2^-26 ->
+// ~1e-15, ample next to the 6e-7 the step has to meet).
 template <int D>
 __device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, double lam_r, double lam_p) {
     float* const ws = w + s;
@@ -381,11 +385,11 @@ __device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, do
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) A[i][j] = (i == j) ? (i < 3 ? lam_r : lam_p) : 0.0;
-    float nx[6];  // the next column of J, requested one trip ahead (a lone wavefront: the LDS latency is otherwise paid D times)
+    float nx[6];  // the next column of J, requested one trip ahead
 #pragma unroll
     for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D) * kGateSlots];
 #pragma unroll 1
-    for (int k = 0; k < D; ++k) {
+    for (int k = 0; k < D; ++k) {  // rolled: unrolled, the 6 D loads and conversions of all trips are in flight at once
         double c[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) c[i] = (double)nx[i];
@@ -397,6 +401,7 @@ __device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, do
 #pragma unroll
             for (int j = 0; j <= i; ++j) A[i][j] = __builtin_fma(c[i], c[j], A[i][j]);
     }
+    asm volatile("" ::: "memory");  // (J is READ AGAIN below rather than kept)
     double inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -408,8 +413,7 @@ __device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, do
             for (int k = 0; k < j; ++k) t = __builtin_fma(-A[i][k], A[j][k], t);
             if (i == j) {
                 t = t > lam ? t : lam;
-                double r = __builtin_amdgcn_rsq(t);  // v_rsq_f64 (~2^-26), two Newton steps on r = t^-1/2
-                r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
+                double r = __builtin_amdgcn_rsq(t);
                 r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
                 inv[j] = r;
             } else {
@@ -432,18 +436,17 @@ __device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, do
         for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-A[k][i], y[k], t);
         y[i] = t * inv[i];
     }
+    asm volatile("" ::: "memory");
+    double t[D];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D) * kGateSlots];
-#pragma unroll 1
-    for (int k = 0; k < D; ++k) {
-        double t = 0.0;
+    for (int k = 0; k < D; ++k) t[k] = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t = __builtin_fma((double)nx[i], y[i], t);
-        const int kn = k + 1 < D ? k + 1 : k;
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D + kn) * kGateSlots];  // (column k + 1 is read before element k is written)
-        ws[k * kGateSlots] = (float)t;  // element k = J[0][k]: read one trip ago, never again
-    }
+        for (int k = 0; k < D; ++k) t[k] = __builtin_fma((double)ws[(i * D + k) * kGateSlots], y[i], t[k]);
+    asm volatile("" ::: "memory");  // every read of this slot's J is done
+#pragma unroll
+    for (int k = 0; k < D; ++k) ws[k * kGateSlots] = (float)t[k];
 }
 
 // One round of the gate, in two halves.  `todo` = ballot of `flag`, non-zero; must be called by every active lane of the wavefront;
