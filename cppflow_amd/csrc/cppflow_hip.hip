@@ -444,12 +444,13 @@ int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
     uint64_t key = fnv1a(source);
     for (int i = 0; i < kEmbeddedCount; ++i) key = fnv1a(kEmbeddedSources[i], key);
     for (int i = 0; i < kRtcOptionCount; ++i) key = fnv1a(kRtcOptions[i], key);
+    key = fnv1a(rtc_version_string(), key);  // (and the compiler that would produce it)
     char hex[32];
     std::snprintf(hex, sizeof hex, "%016llx", (unsigned long long)key);
     const std::string dir = rtc_cache_dir(cache_dir), file = dir + "/robot_" + hex + ".cppfrtc";
     std::vector<std::string> names;
     std::string code;
-    if (!rtc_cache_read(file, names, code)) {
+    if (!rtc_cache_read(dir, file, names, code)) {
         if (int rc = rtc_compile(source, with_quad, names, code)) return rc;
         rtc_cache_write(dir, file, names, code);
     }

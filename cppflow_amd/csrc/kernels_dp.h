@@ -118,16 +118,22 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
 // that does not depend on the costs -- the max joint change for this lane's (source, destination) pairs -- is computed BEFORE
 // the wait, so the exposed time per step is the hand-off latency plus the argmin reduction.
 // Same arithmetic, same reduction order as dp_step_kernel: the table, the argmins and the path stay bit-exact with the oracle.
-// Every spin is bounded (a workgroup that never gets its inputs falls through with +inf costs instead of hanging the GPU).
+// Every spin is bounded: a workgroup that never gets its inputs (the source workgroups are not resident with it -- a CU-masked or
+// partitioned device, a profiler that serialises workgroups) falls through with +inf costs instead of hanging the GPU, AND says
+// so: it raises kDpTimedOut in memoT[0] (row 0 of the memo table is zero-initialised and only ever read as a value), which
+// dp_backtrace_kernel turns into best_idx[*] = -1 / a NaN path.  A caller that sees best_idx[0] < 0 repeats the call with
+// CPPF_TUNE_DP_PERSISTENT = 0 (cppflow_amd.search.dp_search does).
 constexpr uint32_t kDpSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDpQuietNan = 0x7FC00000u;
+constexpr int32_t kDpTimedOut = 0x40000000;
 
-__device__ __forceinline__ float dp_wait_cost(const float* p) {
+__device__ __forceinline__ float dp_wait_cost(const float* p, int32_t* timed_out_flag) {
     uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t spins = 0; bits == kDpSentinel && spins < (1u << 22); ++spins) {
         __builtin_amdgcn_s_sleep(1);
         bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (bits == kDpSentinel) atomicOr(timed_out_flag, kDpTimedOut);
     return bits == kDpSentinel ? INFINITY : __uint_as_float(bits);
 }
 
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
         for (int s = 0; s < AMAX; ++s) {
             const int a = lane + 64 * s;
             if (s < A && a < k) {
-                const float c = dp_wait_cost(cost_prev + a);
+                const float c = dp_wait_cost(cost_prev + a, memoT);
                 const float v = fmaxf(m[s], c) + eb;  // search.py:157-158
                 if (v < best) {
                     best = v;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
         unsigned long long (*img)[256] = keys[t & 1];
         {
             float c = INFINITY;
-            if (a < k) c = dp_wait_cost(cost_prev + a);
+            if (a < k) c = dp_wait_cost(cost_prev + a, memoT);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float v = fmaxf(m[u], c) + eb[u];  // search.py:157-158
@@ -544,6 +550,11 @@ __global__ __launch_bounds__(256) void dp_backtrace_kernel(const float* __restri
     extern __shared__ uint8_t memo8[];
     __shared__ float red_v[4];
     __shared__ int red_a[4];
+    if (memoT[0] & kDpTimedOut) {  // (uniform) the resident launch could not hand its cost rows over: no result, and say so
+        for (int t = threadIdx.x; t < T; t += 256) best_idx[t] = -1;
+        for (int n = threadIdx.x; n < T * d; n += 256) best_path[n] = __builtin_nanf("");
+        return;
+    }
     if (stage) {
         const int n = T * k;
         for (int i = threadIdx.x; i < n; i += 256) memo8[i] = (uint8_t)memoT[i];

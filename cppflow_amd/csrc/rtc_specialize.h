@@ -59,6 +59,7 @@ struct RtcApi {
     int (*GetLoweredName)(RtcProgram, const char*, const char**) = nullptr;
     int (*DestroyProgram)(RtcProgram*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*Version)(int*, int*) = nullptr;  // optional (hiprtcVersion): part of the cache key
 };
 RtcApi g_rtc;
 
@@ -87,12 +88,23 @@ int load_hiprtc() {
     CPPF_SYM(DestroyProgram, "hiprtcDestroyProgram");
     CPPF_SYM(GetErrorString, "hiprtcGetErrorString");
 #undef CPPF_SYM
+    api.Version = reinterpret_cast<decltype(api.Version)>(dlsym(h, "hiprtcVersion"));
     g_rtc = api;
     return CPPF_OK;
 }
 
+// "major.minor" of the hipRTC in this process ("?" if it cannot say): a code object compiled by another compiler is not reused
+std::string rtc_version_string() {
+    int major = 0, minor = 0;
+    if (load_hiprtc() != CPPF_OK || !g_rtc.Version || g_rtc.Version(&major, &minor) != 0) return "?";
+    return std::to_string(major) + "." + std::to_string(minor);
+}
+
 // ---- the table, in the format of robots_gen.h (cppflow_amd/gen_robots.py:emit_robot) ------------------------------------------
 std::string rtc_float(float v) {
+    if (v != v) return "__builtin_nanf(\"\")";  // (%a would print "nanf" / "inff", which is not a literal)
+    if (v == INFINITY) return "__builtin_huge_valf()";
+    if (v == -INFINITY) return "(-__builtin_huge_valf())";
     char buf[64];
     std::snprintf(buf, sizeof buf, "%af", (double)v);  // C99 hex float: exact
     return buf;
@@ -191,22 +203,33 @@ std::string rtc_cache_dir(const char* cache_dir) {
     return "/tmp/cppflow_amd-" + std::to_string((long)getuid());
 }
 
+// Parents with the usual 0755, the cache directory itself private to the user (0700): what is read back from it is loaded
+// into the GPU as code.
 void mkdir_p(const std::string& path) {
     std::string cur;
     for (size_t i = 0; i <= path.size(); ++i) {
         if (i == path.size() || path[i] == '/') {
-            if (!cur.empty()) (void)mkdir(cur.c_str(), 0755);
+            if (!cur.empty()) (void)mkdir(cur.c_str(), i == path.size() ? 0700 : 0755);
         }
         if (i < path.size()) cur += path[i];
     }
 }
 
-// cache file: "CPPFRTC1\n" + RTC_COUNT lowered names (one per line) + code object bytes
-bool rtc_cache_read(const std::string& file, std::vector<std::string>& names, std::string& code) {
+// Is `dir` ours alone?  (owned by this user, a directory, not writable by group or others.)  A cache in a directory another local
+// user could have created -- the /tmp fall-back when neither $CPPF_CACHE_DIR nor $HOME is set -- is neither read nor written.
+bool rtc_cache_dir_trusted(const std::string& dir) {
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
+// cache file: "CPPFRTC2\n" + fnv1a-64 of the code object (hex) + "\n" + RTC_COUNT lowered names (one per line) + code object bytes
+bool rtc_cache_read(const std::string& dir, const std::string& file, std::vector<std::string>& names, std::string& code) {
+    if (!rtc_cache_dir_trusted(dir)) return false;
     std::ifstream f(file, std::ios::binary);
     if (!f) return false;
-    std::string magic;
-    if (!std::getline(f, magic) || magic != "CPPFRTC1") return false;
+    std::string magic, sum;
+    if (!std::getline(f, magic) || magic != "CPPFRTC2" || !std::getline(f, sum)) return false;
     names.clear();
     for (int i = 0; i < RTC_COUNT; ++i) {
         std::string n;
@@ -216,16 +239,21 @@ bool rtc_cache_read(const std::string& file, std::vector<std::string>& names, st
     std::ostringstream rest;
     rest << f.rdbuf();
     code = rest.str();
-    return code.size() > 64;
+    char want[32];
+    std::snprintf(want, sizeof want, "%016llx", (unsigned long long)fnv1a(code));
+    return code.size() > 64 && sum == want;  // a truncated or altered file is recompiled, not loaded
 }
 
 void rtc_cache_write(const std::string& dir, const std::string& file, const std::vector<std::string>& names, const std::string& code) {
     mkdir_p(dir);
+    if (!rtc_cache_dir_trusted(dir)) return;  // an unusable cache only costs the next process a compile
     const std::string tmp = file + ".tmp." + std::to_string((long)getpid());
     {
         std::ofstream f(tmp, std::ios::binary);
-        if (!f) return;  // an unwritable cache only costs the next process a compile
-        f << "CPPFRTC1\n";
+        if (!f) return;
+        char sum[32];
+        std::snprintf(sum, sizeof sum, "%016llx", (unsigned long long)fnv1a(code));
+        f << "CPPFRTC2\n" << sum << "\n";
         for (const std::string& n : names) f << n << "\n";
         f.write(code.data(), (std::streamsize)code.size());
         if (!f) return;

@@ -312,7 +312,10 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
  * came from).  The caller supplies the workspace (device): work_qT [T*k*d] floats, work_costsT [T*k] floats (on return:
  * the cost table, time-major), work_memoT [T*k] int32.  For k <= 256 (the reference plans with k = 175) the whole recurrence runs in ONE
  * resident launch (one or four destinations per workgroup; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are their
- * own flags, no grid barrier), else one small launch per waypoint; no host synchronisation either way. */
+ * own flags, no grid barrier), else one small launch per waypoint; no host synchronisation either way.  The resident form
+ * needs its <= 64 workgroups on the device together; its waits are bounded, and if one expires (a CU-masked / partitioned device)
+ * the call still returns CPPF_OK -- it is asynchronous -- but best_idx[*] = -1 and best_path is NaN: repeat it with
+ * cppf_debug_set(robot, CPPF_TUNE_DP_PERSISTENT, 0) (cppflow_hip_debug.h), which issues one launch per waypoint. */
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
                    float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
                    void* stream);
