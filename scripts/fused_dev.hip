@@ -15,4 +15,4 @@ constexpr int kBlock = 256;
 #include "kernels_fused.h"
 }
 using namespace dev;
-template __global__ void dev::lm_fused_kernel<StaRobot<gen::Panda>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs);
+template __global__ void dev::lm_fused_kernel<StaRobot<gen::Panda>, 1>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs);
