@@ -72,9 +72,10 @@ __device__ __forceinline__ void jacobian_from_axes(const RB& rb, const float (&p
         if (!rb.pris(j)) {
             const float rx = pe[0] - og[j][0], ry = pe[1] - og[j][1], rz = pe[2] - og[j][2];
             J[0][j] = z0, J[1][j] = z1, J[2][j] = z2;
-            J[3][j] = CPPF_FMA(z1, rz, -(z2 * ry));
-            J[4][j] = CPPF_FMA(z2, rx, -(z0 * rz));
-            J[5][j] = CPPF_FMA(z0, ry, -(z1 * rx));
+            // (cmul / cfma: the axis of a specialised chain's first joints has literal 0 / +-1 components)
+            J[3][j] = cfma(rz, z1, -cmul(ry, z2));
+            J[4][j] = cfma(rx, z2, -cmul(rz, z0));
+            J[5][j] = cfma(ry, z0, -cmul(rx, z1));
         } else {
             J[0][j] = J[1][j] = J[2][j] = 0.f;
             J[3][j] = z0, J[4][j] = z1, J[5][j] = z2;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void lm_dual_solve_y(const float (&J)[6][D], const fl
         for (int i = j; i < 6; ++i) {
             float s = (i == j) ? lam : 0.f;
 #pragma unroll
-            for (int k = 0; k < D; ++k) s = CPPF_FMA(J[i][k], J[j][k], s);
+            for (int k = 0; k < D; ++k) s = cfma2(J[i][k], J[j][k], s);  // (literal zeros of a specialised chain's J drop out)
             if (i == j) dmax = fmaxf(dmax, s);  // A[j][j], before the elimination terms
 #pragma unroll
             for (int k = 0; k < j; ++k) s = CPPF_FMA(-L[i][k], L[j][k], s);
@@ -221,7 +222,7 @@ __device__ __forceinline__ void lm_dual_apply(const float (&J)[6][D], const floa
     for (int k = 0; k < D; ++k) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s = CPPF_FMA(J[i][k], y[i], s);
+        for (int i = 0; i < 6; ++i) s = cfma(y[i], J[i][k], s);
         delta[k] = s;
     }
 }

@@ -90,6 +90,12 @@ __device__ __forceinline__ float cfma(float x, float c, float acc) {
     return CPPF_FMA(x, c, acc);
 }
 
+// (a literal zero on either side: the products of two Jacobian entries)
+__device__ __forceinline__ float cfma2(float a, float b, float acc) {
+    if (__builtin_constant_p(a) && a == 0.f) return acc;
+    return cfma(a, b, acc);
+}
+
 // ---- robot accessors ------------------------------------------------------------------------------------------------------------
 // DynRobot<D>: constants come from the kernel-argument structs (scalar loads).  StaRobot<T>: constants are the
 // generated compile-time tables of robots_gen.h; obstacles and the joint-limit padding stay run-time (CollK) in both.

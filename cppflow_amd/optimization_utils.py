@@ -297,6 +297,28 @@ def filter_rows_from_r_J_differencing(robot, r: torch.Tensor, J: torch.Tensor, t
     return r[keep, :], J[keep, :]
 
 
+def get_jacobian_finite_differencing(robot, opt_params, x: torch.Tensor, target_path: torch.Tensor, eps: float = 0.01,
+                                     constraints=None) -> torch.Tensor:
+    """The Jacobian of the stacked residual by forward differences (cppflow/optimization_utils.py:771-799: the reference's debugging
+    aid for `LmResidualFns.get_r_and_J`, eps = 0.01 there too).  The reference perturbs one (row, column) entry per evaluation --
+    r.numel() x n d evaluations; a perturbed residual vector gives a whole column, so this takes n d + 1 evaluations and returns the
+    same matrix.  Only meaningful while the perturbation adds or drops no residual row (no collision pair changing sign, no
+    differencing row filtered): asserted."""
+    n, d = x.shape
+    _, r0 = LmResidualFns.get_r_and_J(opt_params, robot, x, target_path, constraints=constraints)
+    r0 = r0.get_r()
+    J = torch.zeros((r0.shape[0], n * d), device=x.device, dtype=x.dtype)
+    for j in range(n * d):
+        x_diff = x.clone()
+        t, k = divmod(j, d)
+        x_diff[t, k] += eps
+        _, r_new = LmResidualFns.get_r_and_J(opt_params, robot, x_diff, target_path, constraints=constraints)
+        r_new = r_new.get_r()
+        assert r_new.shape == r0.shape, "the perturbation changed the set of residual rows"
+        J[:, j] = (r_new[:, 0] - r0[:, 0]) / eps
+    return J
+
+
 def get_6d_pose_errors(robot, x: torch.Tensor, target_poses: torch.Tensor):
     """[n, 6, 1] pose errors [roll, pitch, yaw, x, y, z] (rad, m) and the current poses [n, 7].
 

@@ -168,10 +168,24 @@ def test_run_time_specialisation_compiles_without_a_gpu(lib, tmp_path):
     files = list(tmp_path.glob("robot_*.cppfrtc"))
     assert len(files) == 1 and files[0].stat().st_size > 50_000
     head = files[0].read_bytes()[:4096].split(b"\n")
-    assert head[0] == b"CPPFRTC1" and b"lm_fused_kernel" in head[1] and b"Custom" in head[1]
+    # magic, the checksum of the code object (16 hex digits), then the lowered kernel names
+    assert head[0] == b"CPPFRTC2" and len(head[1]) == 16 and int(head[1], 16) >= 0
+    assert b"lm_fused_kernel" in head[2] and b"Custom" in head[2]
     t0 = time.perf_counter()
     lib.cppf_debug_rtc_compile(ctypes.byref(desc), str(tmp_path).encode())
     assert time.perf_counter() - t0 < 0.5 * t_compile + 0.05  # served from the cache
+    # a damaged entry (one byte of the code object flipped) fails its checksum: it is compiled again and rewritten, never loaded
+    good = files[0].read_bytes()
+    bad = bytearray(good)
+    bad[-1000] ^= 0x55
+    files[0].write_bytes(bytes(bad))
+    t0 = time.perf_counter()
+    lib.cppf_debug_rtc_compile(ctypes.byref(desc), str(tmp_path).encode())
+    assert time.perf_counter() - t0 > 0.5 * t_compile  # (not served from the cache)
+    assert files[0].read_bytes() != bytes(bad)  # rewritten (hipRTC's output is not byte-reproducible, so not compared with `good`)
+    t0 = time.perf_counter()
+    lib.cppf_debug_rtc_compile(ctypes.byref(desc), str(tmp_path).encode())
+    assert time.perf_counter() - t0 < 0.5 * t_compile + 0.05  # and valid again
     # a different robot gets a different entry
     desc2 = _hip.chain_to_desc(canonicalize(H.random_chain_spec(7, seed=22)))
     lib.cppf_debug_rtc_compile(ctypes.byref(desc2), str(tmp_path).encode())
