@@ -877,6 +877,8 @@ def main():
     obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if (collide and args.config != "C3") else []
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
+    if os.environ.get("CPPF_BENCH_SPREAD_KB"):  # developer sweep of the residency claim of small launches (cppflow_hip_debug.h)
+        robot.debug_set("spread_kb", int(os.environ["CPPF_BENCH_SPREAD_KB"]))
     shape = {"auto": _hip.SHAPE_AUTO, "row": _hip.SHAPE_ROW, "quad": _hip.SHAPE_QUAD}[args.shape]
     solver = {"auto": _hip.SOLVER_AUTO, "f32": _hip.SOLVER_F32, "f64": _hip.SOLVER_F64}[args.solver]
 

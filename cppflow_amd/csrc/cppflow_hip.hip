@@ -103,8 +103,20 @@ namespace {
 constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
     /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
     /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
+    /* SPREAD_KB */ 42,
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
+
+// Dynamic LDS (bytes) a fused row-shape launch of n rows claims purely to bound how many of its workgroups share a compute unit
+// (CPPF_TUNE_SPREAD_KB; 0 = none): 12.5 KB static + 42 KB means two fit on a unit's 160 KB and a third does not.  Only launches
+// of at most 128 workgroups take it -- half a workgroup per compute unit, so the four launches the hardware keeps in flight
+// (profiles/r3_streams_sweep.txt) still all fit.  Measured on a 32 768-row shard, four launches in flight: 8.46 -> 7.8 us per
+// step (the dispatcher otherwise stacks the launches four deep on the units it tries first and leaves others idle); at 65 536
+// rows the same claim would hold two of the four launches back (10.1 -> 12.8 us), hence the bound.
+inline size_t fused_spread_lds(const cppf_robot* rb, size_t n) {
+    const int kb = tune(rb, CPPF_TUNE_SPREAD_KB);
+    return (kb > 0 && n <= (size_t)128 * kBlock) ? (size_t)kb * 1024 : 0;
+}
 }  // namespace
 
 #include "rtc_specialize.h"
@@ -716,11 +728,15 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                      oq.jlim_mask, summary_dst, stream);
         return CPPF_OK;
     }
-    const size_t lds = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
+    // Dynamic LDS: what the generic kernels stage their capsules in, or -- for a launch of at most two workgroups per compute
+    // unit -- a claim sized so that only two workgroups FIT on one (fused_spread_lds): several such launches in flight then
+    // spread over the whole chip instead of stacking four deep on the compute units the dispatcher tries first.
+    const size_t lds_need = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
+    const size_t lds = std::max(lds_need, fused_spread_lds(robot, n));
     if (use_rtc(robot)) {
         void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)out};
         const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
-        if (int rc = rtc_launch(robot, which, grid_for(n), 0, st, args)) return rc;
+        if (int rc = rtc_launch(robot, which, grid_for(n), fused_spread_lds(robot, n), st, args)) return rc;
     } else if (coll && (out->min_self || out->min_env)) {
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
@@ -735,7 +751,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
 #undef CPPF_BODY
     } else {
 #define CPPF_BODY                                                                                               \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), 0, st, robot->chain, robot->coll, \
+    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), fused_spread_lds(robot, n), st, robot->chain, robot->coll, \
                        prm, x_in, target, *out)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY

@@ -42,7 +42,11 @@ extern "C" {
 /* non-zero: J J^T of the four-lanes-per-row shape by v_mfma_f32_4x4x1_16b_f32 in the robot-specialised instantiations (the
  * measured comparison of DESIGN.md section 4.2).  Default 0. */
 #define CPPF_TUNE_QUAD_MFMA 7
-#define CPPF_TUNE_COUNT 8
+/* KB of dynamic LDS a row-shape fused launch of at most 128 workgroups claims for nothing but residency control: with 42 (the
+ * default) only two of its workgroups fit on one compute unit (12.5 KB static + 42 KB, 160 KB per unit), so that four such launches
+ * in flight spread over the chip instead of stacking on the units the dispatcher fills first.  0 = no claim. */
+#define CPPF_TUNE_SPREAD_KB 8
+#define CPPF_TUNE_COUNT 9
 
 int cppf_debug_set(cppf_robot* robot, int key, int value);
 int cppf_debug_get(const cppf_robot* robot, int key, int* value);
