@@ -302,7 +302,8 @@ def get_jacobian_finite_differencing(robot, opt_params, x: torch.Tensor, target_
     """The Jacobian of the stacked residual by forward differences (cppflow/optimization_utils.py:771-799: the reference's debugging
     aid for `LmResidualFns.get_r_and_J`, eps = 0.01 there too).  The reference perturbs one (row, column) entry per evaluation --
     r.numel() x n d evaluations; a perturbed residual vector gives a whole column, so this takes n d + 1 evaluations and returns the
-    same matrix.  Only meaningful while the perturbation adds or drops no residual row (no collision pair changing sign, no
+    same matrix.  What comes out is dr/dx, which is MINUS the J of `get_r_and_J`: every residual there is  desired - current  and J
+    the Jacobian of `current` (hence x + solve(J^T J + lambda I, J^T r), cppflow/optimization.py:95-113).  Only meaningful while the perturbation adds or drops no residual row (no collision pair changing sign, no
     differencing row filtered): asserted."""
     n, d = x.shape
     _, r0 = LmResidualFns.get_r_and_J(opt_params, robot, x, target_path, constraints=constraints)
