@@ -907,6 +907,10 @@ def main():
         return x_all, tgt, desc
 
     def barrier():
+        # (drain this rank's launch streams BEFORE the group's barrier: its all-reduce belongs to torch.distributed's communicator,
+        # the exchange steps still in flight to the C-ABI one, and kernels of two communicators must not wait for each other in a
+        # different order on different ranks)
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
