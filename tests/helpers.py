@@ -129,6 +129,35 @@ FK_PINS = {
 }
 
 
+# ---- hand-derived Jacobian pins at the zero pose ----------------------------------------------------------------------------------
+# Same derivation on paper: at q = 0 every joint axis is a signed world axis and every joint origin a sum of link offsets, so the
+# geometric Jacobian column of a revolute joint is [axis; axis x (p_ee - origin)] and of a prismatic one [0; axis]  (rows 0:3 angular,
+# 3:6 linear, world frame: SURVEY.md 8a a7).  Panda: axes z, y, z, -y, z, -y, -z at origins (0,0,.333), (0,0,.333), (0,0,.649),
+# (.0825,0,.649), (0,0,1.033), (0,0,1.033), (.088,0,1.033), p_ee = (.088,0,.926).  Fetch: torso prismatic z, then z, y, x, y, x, y, x
+# at x = .03265, .14965, .36865, .50165, .69865, .82315, .96165 (z = .72601 for the pan joint, .78601 beyond), p_ee = (1.1281,0,.78601).
+J_PINS = {
+    "panda": np.array([
+        # j1      j2      j3      j4       j5      j6      j7
+        [0.0,     0.0,    0.0,    0.0,     0.0,    0.0,    0.0],     # wx
+        [0.0,     1.0,    0.0,   -1.0,     0.0,   -1.0,    0.0],     # wy
+        [1.0,     0.0,    1.0,    0.0,     1.0,    0.0,   -1.0],     # wz
+        [0.0,     0.593,  0.0,   -0.277,   0.0,    0.107,  0.0],     # vx
+        [0.088,   0.0,    0.088,  0.0,     0.088,  0.0,    0.0],     # vy
+        [0.0,    -0.088,  0.0,    0.0055,  0.0,    0.088,  0.0],     # vz
+    ]),
+    "fetch": np.array([
+        # torso   pan      lift      uroll  elbow     froll  wflex     wroll
+        [0.0,     0.0,     0.0,      1.0,   0.0,      1.0,   0.0,      1.0],
+        [0.0,     0.0,     1.0,      0.0,   1.0,      0.0,   1.0,      0.0],
+        [0.0,     1.0,     0.0,      0.0,   0.0,      0.0,   0.0,      0.0],
+        [0.0,     0.0,     0.0,      0.0,   0.0,      0.0,   0.0,      0.0],
+        [0.0,     1.09545, 0.0,      0.0,   0.0,      0.0,   0.0,      0.0],
+        [1.0,     0.0,    -0.97845,  0.0,  -0.62645,  0.0,  -0.30495,  0.0],
+    ]),
+}
+J_PINS["fetch_arm"] = J_PINS["fetch"][:, 1:].copy()
+
+
 def fk_pin_arrays(name):
     q = np.array([p[0] for p in FK_PINS[name]], dtype=np.float64)
     pose = np.array([p[1] for p in FK_PINS[name]], dtype=np.float64)

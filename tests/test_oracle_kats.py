@@ -305,6 +305,12 @@ def test_forward_kinematics_equals_hand_derived_values_from_the_urdf_constants(n
     assert H.pose_close(H.oracle32(name).fk(H.f32(q)), pose, 2e-6, 2e-6)
     rb = ref_torch.TorchRobot(ROBOT_SPECS[name](), device="cpu", dtype=torch.float64)
     assert H.pose_close(rb.forward_kinematics(torch.tensor(q)).numpy(), pose, 1e-12, 1e-12)
+    # the zero-pose Jacobian, derived on paper the same way (axis; axis x lever arm): convention and values
+    Jz = H.J_PINS[name]
+    q0 = np.zeros((1, Jz.shape[1]))
+    assert np.abs(H.oracle64(name).jacobian(q0)[0] - Jz).max() < 1e-7
+    assert np.abs(H.oracle32(name).jacobian(H.f32(q0))[0] - Jz).max() < 2e-6
+    assert np.abs(rb.jacobian(torch.tensor(q0))[0].numpy() - Jz).max() < 1e-12
     if name == "fetch":  # the frame the reference's Fetch problems are offset in: torso_lift_link at q = 0, unrotated
         torso = H.oracle64(name).link_frames(np.zeros((1, 8)))[0, 0]  # [R row-major (9), t (3)] of the first moving link
         assert np.allclose(torso[9:], [-0.086875, 0.0, 0.37743], atol=1e-7) and np.allclose(torso[:9], np.eye(3).ravel(), atol=1e-12)
