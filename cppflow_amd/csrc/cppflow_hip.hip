@@ -148,7 +148,7 @@ CapsuleCentred capsule_centred(const cppf_robot_desc& d, int cap) {
     const double h0 = r.h[0], h1 = r.h[1], h2 = r.h[2];
     const double a = (h0 * h0 + h1 * h1) + h2 * h2;
     r.a = (float)a;
-    r.ia = (float)(1.0 / a);
+    r.ia = a >= 0x1p-100 ? (float)(1.0 / a) : 0.f;  // a zero-length capsule is a sphere: its parameter stays 0 (as rcp_rn would have it)
     r.half_length = std::sqrt(a);
     return r;
 }
@@ -342,7 +342,8 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
             const float dd = desc->cap_p1[c][k] - desc->cap_p0[c][k];
             len2 += dd * dd;
         }
-        CPPF_REQUIRE(len2 > 1e-12f, "degenerate capsule (p0 == p1)");
+        // p0 == p1 exactly is a SPHERE (its 1 / |h|^2 is 0, capsule_centred); a segment shorter than a micrometre is a mistake
+        CPPF_REQUIRE(len2 == 0.f || len2 > 1e-12f, "degenerate capsule (|p1 - p0| < 1e-6 but not 0; use p0 == p1 for a sphere)");
         CPPF_REQUIRE(desc->cap_r[c] >= 0.f, "negative capsule radius");
     }
     for (int p = 0; p < desc->n_pairs; ++p) {

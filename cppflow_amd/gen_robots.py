@@ -64,7 +64,7 @@ def cull_threshold(reach: float) -> np.float32:
 
 def capsule_centred(cap_p0, cap_p1):
     """(centre, half-axis, |h|^2, 1 / |h|^2) of every capsule as the kernels use them: double arithmetic on the fp32 end points,
-    each rounded to fp32 once -- c = 0.5 (p0 + p1), h = 0.5 (p1 - p0), a = (h0 h0 + h1 h1) + h2 h2 over the ROUNDED h, 1 / a.
+    each rounded to fp32 once -- c = 0.5 (p0 + p1), h = 0.5 (p1 - p0), a = (h0 h0 + h1 h1) + h2 h2 over the ROUNDED h, 1 / a (0 when a < 2^-100).
     The same four lines are in csrc/cppflow_hip.hip (capsule_centred) and oracle/lmik_oracle.c (orc_robot_create)."""
     p0 = np.asarray(cap_p0, dtype=np.float32).astype(np.float64).reshape(-1, 3)
     p1 = np.asarray(cap_p1, dtype=np.float32).astype(np.float64).reshape(-1, 3)
@@ -72,8 +72,7 @@ def capsule_centred(cap_p0, cap_p1):
     h = (0.5 * (p1 - p0)).astype(np.float32)
     hd = h.astype(np.float64)
     a = (hd[:, 0] * hd[:, 0] + hd[:, 1] * hd[:, 1]) + hd[:, 2] * hd[:, 2]
-    with np.errstate(divide="ignore"):
-        ia = 1.0 / a
+    ia = np.where(a >= 2.0**-100, 1.0 / np.maximum(a, 2.0**-100), 0.0)  # a zero-length capsule is a sphere: its parameter stays 0
     return c, h, a.astype(np.float32), ia.astype(np.float32), np.sqrt(a)
 
 

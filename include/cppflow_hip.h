@@ -64,8 +64,8 @@ typedef struct cppf_robot_desc {
     float hi[CPPF_MAX_DOF];
     int32_t n_capsules;
     int32_t cap_link[CPPF_MAX_CAPSULES]; /* moving link the capsule rides on, -1 = base; must be non-decreasing */
-    float cap_p0[CPPF_MAX_CAPSULES][3];
-    float cap_p1[CPPF_MAX_CAPSULES][3]; /* |p1 - p0| must be > 0 */
+    float cap_p0[CPPF_MAX_CAPSULES][3]; /* axis end points in the link frame; p0 == p1 exactly makes the capsule a sphere */
+    float cap_p1[CPPF_MAX_CAPSULES][3]; /* |p1 - p0| = 0 (sphere) or > 1e-6 */
     float cap_r[CPPF_MAX_CAPSULES];
     int32_t n_pairs;
     int32_t pairs[CPPF_MAX_PAIRS][2]; /* capsule index pairs checked by self_collision_distances */

@@ -118,7 +118,7 @@ void* orc_robot_create(int ndof, const double* F, const double* Fee, const int* 
         }
         rb->cap_r[c] = (REAL)cap_r[c];
         /* centre c = 0.5 (p0 + p1), half-axis h = 0.5 (p1 - p0), a = |h|^2, 1 / a: double arithmetic on the (fp32-valued) end
-         * points, each rounded to fp32 ONCE, a over the rounded h summed (h0 h0 + h1 h1) + h2 h2 -- the same lines as
+         * points, each rounded to fp32 ONCE, a over the rounded h summed (h0 h0 + h1 h1) + h2 h2, 1 / a (0 for a < 2^-100) -- the same lines as
          * cppflow_amd/gen_robots.py (capsule_centred) and csrc/cppflow_hip.hip (capsule_centred), so that all three hold the
          * same bits; the fp64 build keeps the fp32-valued c and h (it is the ground truth OF THAT capsule) with a, 1 / a unrounded. */
         float hf[3];
@@ -130,7 +130,7 @@ void* orc_robot_create(int ndof, const double* F, const double* Fee, const int* 
         }
         const double a = ((double)hf[0] * (double)hf[0] + (double)hf[1] * (double)hf[1]) + (double)hf[2] * (double)hf[2];
         rb->cap_a[c] = (REAL)a; /* fp32 build: rounded once, the kernels' constants; fp64 build: the exact |h|^2 */
-        rb->cap_ia[c] = (REAL)(1.0 / a);
+        rb->cap_ia[c] = a >= 0x1p-100 ? (REAL)(1.0 / a) : (REAL)0; /* a zero-length capsule is a sphere: its parameter stays 0 (rcp_rn) */
     }
     rb->npairs = npairs;
     for (int p = 0; p < npairs; ++p) {

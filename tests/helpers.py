@@ -169,3 +169,43 @@ def pose_close(got, want, tol_p, tol_q):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     dq = np.minimum(np.abs(got[:, 3:] - want[:, 3:]).max(axis=1), np.abs(got[:, 3:] + want[:, 3:]).max(axis=1))
     return np.abs(got[:, :3] - want[:, :3]).max() <= tol_p and dq.max() <= tol_q
+
+
+# ---- closed-form cases of the capsule distance functions ---------------------------------------------------------------------------
+# (end points exactly representable in fp32; radius 0, so the "distance" the APIs return is the distance between the axis segments)
+SEGMENT_KATS = [
+    (((0, 0, 0), (1, 0, 0)), ((0, 1, 0), (1, 1, 0)), 1.0),            # parallel, overlapping ranges
+    (((0, 0, 0), (1, 0, 0)), ((2, 1, 0), (3, 1, 0)), np.sqrt(2.0)),    # parallel, disjoint ranges: end point to end point
+    (((-1, 0, 0), (1, 0, 0)), ((0, -1, 0.5), (0, 1, 0.5)), 0.5),      # skew, crossing in projection
+    (((-1, 0, 0), (1, 0, 0)), ((0, -1, 0), (0, 1, 0)), 0.0),           # intersecting
+    (((0, 0, 0), (1, 0, 0)), ((2, 0, 0), (4, 0, 0)), 1.0),             # collinear, disjoint
+    (((0, 0, 0), (1, 0, 0)), ((0.5, 0.25, 0), (0.5, 2, 0)), 0.25),     # T shape: end point to interior
+    (((0.375, 0.5, 0), (0.375, 0.5, 0)), ((0, 0, 0), (0, 0, 0)), 0.625),  # two spheres (zero-length segments)
+    (((0, 0, 2), (0, 0, 2)), ((-1, 0, 0), (1, 0, 0)), 2.0),            # sphere to the interior of a segment
+]
+BOX_KATS = [  # against the unit box [0, 1]^3
+    (((2, 0.5, 0.5), (3, 0.5, 0.5)), 1.0),               # along an axis, off a face
+    (((2, 2, 0.5), (3, 3, 0.5)), np.sqrt(2.0)),          # off an edge: end point to the edge
+    (((2, 2, 2), (2, 2, 2)), np.sqrt(3.0)),              # a sphere off a corner
+    (((-1, 2, 0.5), (2, -1, 0.5)), 0.0),                 # passes through the box
+    (((0.5, 0.5, 0.5), (0.625, 0.5, 0.5)), 0.0),         # inside
+    (((-1, 1.5, 0.5), (2, 1.5, 0.5)), 0.5),              # parallel to a face, overhanging both sides
+    (((1.5, 1.5, -1), (1.5, 1.5, 2)), np.sqrt(0.5)),     # parallel to an edge
+    (((2, 0, 0.5), (0, 2, 0.5)), 0.0),                   # grazes the edge x = y = 1 exactly
+]
+
+
+def two_capsule_spec(c0, c1):
+    """three coincident revolute joints about z, a capsule c0 on the base and c1 on the last link: at q = 0 both sit where given"""
+    from cppflow_amd.robot_model import CapsuleSpec, JointSpec, RobotSpec
+
+    joints = [JointSpec(f"j{i}", f"l{i}", (0, 0, 0), (0, 0, 0), (0, 0, 1), "revolute", (-1.0, 1.0)) for i in range(3)]
+    joints.append(JointSpec("tool", "tool", (0, 0, 0.125), (0, 0, 0), jtype="fixed"))
+    caps = [CapsuleSpec("base", c0[0], c0[1], 0.0), CapsuleSpec("l2", c1[0], c1[1], 0.0)]
+    return RobotSpec("kat", "two capsules", "base", joints, caps, collision_pairs=[(0, 1)])
+
+
+def two_capsule_chain(c0, c1):
+    from cppflow_amd.robot_model import canonicalize
+
+    return canonicalize(two_capsule_spec(c0, c1))

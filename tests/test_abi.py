@@ -112,7 +112,8 @@ def test_invalid_descriptions_are_rejected_without_a_gpu(lib):
     assert lib.cppf_robot_create(ctypes.byref(desc), 0, ctypes.byref(out)) == _hip.CPPF_ERR_INVALID
     assert b"ndof" in lib.cppf_last_error()
     desc.ndof = 7
-    desc.cap_p1[3][0], desc.cap_p1[3][1], desc.cap_p1[3][2] = desc.cap_p0[3][0], desc.cap_p0[3][1], desc.cap_p0[3][2]
+    # a capsule shorter than a micrometre but not of length 0 is a mistake (p0 == p1 exactly is a sphere and accepted)
+    desc.cap_p1[3][0], desc.cap_p1[3][1], desc.cap_p1[3][2] = desc.cap_p0[3][0] + 3e-7, desc.cap_p0[3][1], desc.cap_p0[3][2]
     assert lib.cppf_robot_create(ctypes.byref(desc), 0, ctypes.byref(out)) == _hip.CPPF_ERR_INVALID
     assert b"degenerate" in lib.cppf_last_error()
     with pytest.raises(AssertionError):

@@ -390,3 +390,42 @@ def test_finite_difference_jacobian_of_the_stacked_residual_agrees_with_the_anal
     assert 1e-4 < e_rot < 2e-2
     assert np.abs(J_fd[:n_pose] + J[:n_pose]).max() < 3.5 * 2.0 * eps + 0.35 * 2.0 * e_rot + 5e-4
     assert np.abs(J[:n_pose]).max() > 0.3  # (the comparison is not vacuous)
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+def test_capsule_distance_known_answers_on_the_device(specialize):
+    """tests/helpers.py:SEGMENT_KATS / BOX_KATS (closed-form segment-segment and segment-box distances, zero-length capsules =
+    spheres included) through cppf_self_collision_distances / cppf_env_collision_distances and the masks of the fused launch, with
+    the generic kernels and with the run-time-specialised ones."""
+    from cppflow_amd.robots import Robot
+
+    q0 = dev(np.zeros((64, 3)))
+    for c0, c1, want in H.SEGMENT_KATS:
+        rb = Robot(H.two_capsule_spec(c0, c1), specialize=specialize)
+        got = host(rb.self_collision_distances(q0))
+        assert got.shape == (64, 1) and np.abs(got - want).max() < 1e-6, (c0, c1, got[0], want)
+        m = rb.collision_masks(q0.reshape(1, 64, 3), want_min_dists=True)
+        assert np.abs(host(m["min_self"]) - want).max() < 1e-6 and not m["self_mask"].any()
+    # distance gradients with spheres in play (sphere / sphere, sphere / segment, segment / sphere; off the joint axis so that the
+    # distance moves): the device's analytic d(distance)/dq against the oracle's (which equals central differences to 2e-10)
+    from oracle.oracle import Oracle
+
+    p = (0.5, 0.25, 0.125)
+    grad_cases = [(((1.5, 0, 0.5), (1.5, 0, 0.5)), (p, p)), (((1.5, -1, 0.5), (1.5, 1, 0.5)), (p, p)),
+                  (((1.5, 0, 0.5), (1.5, 0, 0.5)), ((0.25, 0, 0), (0.75, 0.5, 0.25)))]
+    qs = np.concatenate([np.zeros((1, 3)), H.f32(0.3 * np.random.RandomState(2).randn(63, 3))])
+    for c0, c1 in grad_cases:
+        rb = Robot(H.two_capsule_spec(c0, c1), specialize=specialize)
+        o = Oracle(H.two_capsule_chain(c0, c1), f32=False)
+        Jd, dist = rb.self_collision_distances_jacobian(dev(qs), return_distances=True)
+        want_d, want_g = o.self_dists_grads(qs)
+        assert np.isfinite(host(Jd)).all() and np.abs(host(dist) - want_d).max() < 1e-6
+        assert np.abs(want_g).max() > 0.3 and np.abs(host(Jd) - want_g).max() < 1e-5, np.abs(host(Jd) - want_g).max()
+    unit = H.cuboid_obstacle(0.5, 0.5, 0.5, 1.0, 1.0, 1.0)
+    for c1, want in H.BOX_KATS:
+        rb = Robot(H.two_capsule_spec(((0, 0, 5), (0, 0, 5)), c1), specialize=specialize)
+        got = host(rb.env_collision_distances(q0, unit[0], unit[1]))
+        assert got.shape == (64, 2) and np.abs(got[:, 1] - want).max() < 1e-6, (c1, got[0], want)
+        rb.set_obstacles([unit[0]], [unit[1]])
+        m = rb.collision_masks(q0.reshape(1, 64, 3), want_min_dists=True)
+        assert np.abs(host(m["min_env"]) - want).max() < 1e-6, (c1, host(m["min_env"])[0], want)

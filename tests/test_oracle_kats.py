@@ -243,6 +243,50 @@ def test_segment_box_distance_against_brute_force():
     del rng
 
 
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_segment_segment_distance_against_brute_force(name):
+    """The capsule-capsule definition (exact distance between the two axis segments, minus the radii) against sampling: 4001
+    points along one segment, each with its exact nearest point on the other (a point-segment distance is one clamp).  Sampling
+    can only overestimate, and by O(step^2)."""
+    o, ch = H.oracle64(name), H.chain(name)
+    q = H.random_configs(name, 48, seed=12)
+    ends = o.capsule_endpoints(q)  # [n, L, 6]
+    d = o.self_dists(q) + (ch.cap_r[ch.pairs[:, 0]] + ch.cap_r[ch.pairs[:, 1]])[None]
+    A0, A1 = ends[:, ch.pairs[:, 0], :3], ends[:, ch.pairs[:, 0], 3:]  # [n, P, 3]
+    B0, B1 = ends[:, ch.pairs[:, 1], :3], ends[:, ch.pairs[:, 1], 3:]
+    t = np.linspace(0, 1, 4001)[None, None, :, None]
+    pts = A0[:, :, None, :] * (1 - t) + A1[:, :, None, :] * t  # [n, P, 4001, 3]
+    u = (B1 - B0)[:, :, None, :]
+    uu = np.maximum((u * u).sum(-1), 1e-300)
+    s = np.clip(((pts - B0[:, :, None, :]) * u).sum(-1) / uu, 0.0, 1.0)
+    brute = np.linalg.norm(pts - (B0[:, :, None, :] + s[..., None] * u), axis=-1).min(axis=2)
+    assert (d <= brute + 1e-12).all()
+    np.testing.assert_allclose(d, brute, atol=2e-6)
+    # the canonical fp32 build computes the same distances in the operation order the kernels use
+    d32 = H.oracle32(name).self_dists(H.f32(q)) + (ch.cap_r[ch.pairs[:, 0]] + ch.cap_r[ch.pairs[:, 1]])[None]
+    np.testing.assert_allclose(d32, brute, atol=5e-6)
+
+
+def test_segment_distance_known_answers():
+    """Closed-form cases of the two distance functions (tests/helpers.py:SEGMENT_KATS, BOX_KATS) through a two-capsule robot:
+    parallel, crossing, collinear-disjoint, T-shaped and degenerate (zero-length = sphere) segments; a segment outside, touching,
+    and inside a box.  (A zero-length capsule used to give NaN: 1 / |h|^2 is now 0 for it, as rcp_rn has it.)"""
+    from oracle.oracle import Oracle
+
+    for c0, c1, want in H.SEGMENT_KATS:
+        ch = H.two_capsule_chain(c0, c1)
+        assert ch.n_pairs == 1, ch.pairs
+        for orc, tol in ((Oracle(ch, f32=False), 1e-12), (Oracle(ch, f32=True), 1e-6)):
+            got = orc.self_dists(np.zeros((1, 3)))[0, 0]
+            assert abs(got - want) < tol, (c0, c1, got, want)
+    lo, hi = np.zeros(3), np.ones(3)  # the unit box
+    for c1, want in H.BOX_KATS:
+        ch = H.two_capsule_chain(((0, 0, 5), (0, 0, 5)), c1)
+        for orc, tol in ((Oracle(ch, f32=False), 1e-12), (Oracle(ch, f32=True), 1e-6)):
+            got = orc.env_dists(np.zeros((1, 3)), lo, hi)[0, 1]
+            assert abs(got - want) < tol, (c1, got, want)
+
+
 # ---- coupled ("full") LM step ---------------------------------------------------------------------------------------------
 
 
