@@ -429,3 +429,48 @@ def test_capsule_distance_known_answers_on_the_device(specialize):
         rb.set_obstacles([unit[0]], [unit[1]])
         m = rb.collision_masks(q0.reshape(1, 64, 3), want_min_dists=True)
         assert np.abs(host(m["min_env"]) - want).max() < 1e-6, (c1, host(m["min_env"])[0], want)
+
+
+def test_launches_past_four_gigabytes_of_rows_address_every_row():
+    """Maximum sizes: 2^27 + 2^24 + 2^23 rows of a 7-joint robot are 4.46 GB of `x` -- byte offsets beyond 32 bits in every per-row array.
+    The input is one 65 536-row block tiled, so every block of the result must equal the result of that block alone, bit for bit
+    (fused launch with the collision stage and the per-seed summary, FK, and the standalone collision launch)."""
+    from cppflow_amd.robots import get_robot
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2**30:
+        pytest.skip("needs 24 GB of free device memory")
+    rb = get_robot("panda")
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    W, blk = 256, 65536
+    reps = (2**27 + 2**24 + 2**23) // blk  # 2432 blocks = 159 383 552 rows, x = 4.46 GB
+    n = reps * blk
+    q_star = H.random_configs("panda", W, seed=4)
+    target = dev(H.oracle64("panda").fk(q_star))
+    ch = H.chain("panda")
+    x_blk = dev(np.clip(np.tile(q_star, (blk // W, 1)) + 0.1 * np.random.RandomState(0).randn(blk, 7), ch.lo, ch.hi))
+    small = rb.lm_pose_steps(x_blk, target, n_steps=2, want_errors=True, **LM,
+                             packed_out=torch.empty(rb.PACKED_BYTES_PER_ROW * blk, dtype=torch.uint8, device=DEV),
+                             summary_out=torch.empty((blk // W, 8), device=DEV))
+    x_big = x_blk.repeat(reps, 1)
+    assert x_big.shape == (n, 7) and x_big.numel() * 4 > 2**32
+    pk = torch.empty(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=DEV)
+    sm = torch.empty((n // W, 8), device=DEV)
+    big = rb.lm_pose_steps(x_big, target, n_steps=2, want_errors=True, **LM, packed_out=pk, summary_out=sm)
+    torch.cuda.synchronize()
+    xs, xb = small["x"], big["x"].view(reps, blk, 7)
+    assert torch.equal(xb, xs[None].expand_as(xb))
+    for k in ("pos_err_m", "rot_err_rad", "ext_cost", "self_mask", "env_mask", "jlim_mask"):
+        assert torch.equal(big[k].view(reps, -1), small[k].view(1, -1).expand(reps, -1)), k
+    assert torch.equal(sm.view(reps, -1), small["seed_summary"].view(1, -1).expand(reps, -1))
+    del big, pk, sm
+    poses = rb.forward_kinematics(x_big)
+    assert torch.equal(poses.view(reps, blk, 7), rb.forward_kinematics(x_blk)[None].expand(reps, blk, 7))
+    del poses
+    m_big = rb.collision_masks(x_big.view(n // W, W, 7))
+    m_small = rb.collision_masks(x_blk.view(blk // W, W, 7))
+    for k in ("self_mask", "env_mask", "jlim_mask", "ext_cost"):
+        assert torch.equal(m_big[k].reshape(reps, -1), m_small[k].reshape(1, -1).expand(reps, -1)), k
+    rb.set_obstacles([], [])
