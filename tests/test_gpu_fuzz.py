@@ -1,5 +1,5 @@
-"""Shape / value fuzz of the two neighbour stages against the oracle (pytest -m gpu): the sweeps live in scripts/fuzz_dp.py and
-scripts/fuzz_coupled.py so that they can be run and extended by hand; here they must report no disagreement."""
+"""Shape / value fuzz of the fused launch and its two neighbour stages against the oracle (pytest -m gpu): the sweeps live in scripts/fuzz_dp.py,
+scripts/fuzz_coupled.py and scripts/fuzz_lm.py so that they can be run and extended by hand; here they must report no disagreement."""
 import os
 import runpy
 
@@ -9,12 +9,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script", ["fuzz_dp.py", "fuzz_coupled.py"])
+@pytest.mark.parametrize("script", ["fuzz_dp.py", "fuzz_coupled.py", "fuzz_lm.py"])
 def test_fuzz_sweep_reports_no_disagreement(script, capsys):
     """fuzz_dp: cppf_dp_search in its table / resident / per-waypoint forms over k = 1 .. 300, T = 1 .. 257 with ties, +inf columns,
     1e33 costs and identical candidates -- cost table, argmins and path bit-identical to the oracle (920 comparisons).
     fuzz_coupled: cppf_lm_full_step in its three elimination orders over T = 1 .. 65, S = 1 .. 3, 0 .. 4 virtual configurations,
-    with and without obstacles, three robots (1134 comparisons)."""
+    with and without obstacles, three robots (1134 comparisons).
+    fuzz_lm: the fused launch over four robots x eleven (S, W) shapes (W = 1 .. 300, ragged and not) x K in {1, 3, 10} x kernel
+    shape x solver: x against the oracle, per-row outputs at the launch's own x (masks bit-exact), the per-seed summary against the
+    separate reduction, the two kernel shapes against each other (792 launches)."""
     with pytest.raises(SystemExit) as e:
         runpy.run_path(os.path.join(ROOT, "scripts", script), run_name="__main__")
     out = capsys.readouterr().out
