@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the parallel-in-time elimination's forms (cppf_debug_set_pcr_lds: 0 workspace, 1 LDS, 2 LDS + split)."""
+"""Same-process A/B of the parallel-in-time elimination's forms (CPPF_TUNE_PCR_LDS: 0 workspace, 1 LDS, 2 LDS + split)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

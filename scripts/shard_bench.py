@@ -17,7 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="row,quad")
 ap.add_argument("--lib", default=None)
 ap.add_argument("--robot", default="panda")
-ap.add_argument("--mfma", type=int, default=0, help="quad shape: J J^T by v_mfma_f32_4x4x1 (cppf_debug_set_quad_mfma)")
+ap.add_argument("--mfma", type=int, default=0, help="quad shape: J J^T by v_mfma_f32_4x4x1 (CPPF_TUNE_QUAD_MFMA)")
 ap.add_argument("--sizes", default="128,256,512,1024", help="seeds (x 256 waypoints) of the collision-fused cases")
 args = ap.parse_args()
 if args.lib:
