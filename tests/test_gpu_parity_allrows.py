@@ -59,12 +59,33 @@ def _one_step_case(name, source):
         z = np.load(os.path.join(GOLDEN, f"lm_golden_{name}.npz"))
         x0, target = H.f32(z["x0"]), H.f32(z["target"])
         return x0, target, int(z["S"])
+    if source == "special":
+        # the corners: starts at / next to a kinematic singularity (the zero pose and the stretched arm), on the joint limits,
+        # exactly on the solution (zero residual), and far from it (a target taken from an unrelated configuration)
+        ch = H.chain(name)
+        rng = np.random.RandomState(11)
+        W, d = 64, ch.ndof
+        q_star = rng.uniform(ch.lo, ch.hi, size=(W, d))
+        target = H.f32(H.oracle64(name).fk(H.f32(q_star)))
+        mid = np.clip(np.zeros(d), ch.lo, ch.hi)
+        blocks = [
+            np.tile(mid, (W, 1)) + 1e-3 * rng.randn(W, d),                       # the zero pose (clamped into the limits)
+            np.tile(mid, (W, 1)) + 1e-6 * rng.randn(W, d),                       # ... to within a micro-radian
+            np.tile(ch.lo, (W, 1)) + 1e-4 * np.abs(rng.randn(W, d)),             # on the lower limits
+            np.tile(ch.hi, (W, 1)) - 1e-4 * np.abs(rng.randn(W, d)),             # on the upper limits
+            q_star.copy(),                                                        # exactly on the solution
+            q_star + 1e-6 * rng.randn(W, d),                                      # a micro-radian off it
+            rng.uniform(ch.lo, ch.hi, size=(W, d)),                              # far: unrelated configurations
+            q_star + 0.1 * rng.randn(W, d),                                       # the usual seeds
+        ]
+        x0 = H.f32(np.clip(np.concatenate(blocks), ch.lo, ch.hi))
+        return x0, target, len(blocks)
     S, W = 64, 64
     x0, target = H.lm_problem(name, S, W, seed=3)
     return x0, target, S
 
 
-@pytest.mark.parametrize("source", ["seeded", "golden"])
+@pytest.mark.parametrize("source", ["seeded", "golden", "special"])
 @pytest.mark.parametrize("name", ROBOTS)
 def test_one_step_task_space_parity_on_all_rows(robots, name, source):
     from cppflow_amd import _hip
@@ -89,12 +110,21 @@ def test_one_step_task_space_parity_on_all_rows(robots, name, source):
     # ---- fp64 solve: every row, both shapes ----
     step = np.abs(x64 - x0).max(axis=1)
     calm = step < 1.0
-    assert calm.mean() > 0.9
+    assert calm.mean() > (0.3 if source == "special" else 0.9)
     small = step < 0.1
+    # At a singular start with a far target (source "special": the zero pose of Fetch / the 12-joint chain, sigma_min 1e-8 .. 1e-4,
+    # |e_s| ~ 5) the step's filter factors sigma^2 / (sigma^2 + lambda) move with the LAST BITS of the fp32 Jacobian itself: a
+    # relative change 1e-7 sigma_max / sigma of a singular value near sqrt(lambda) = 1e-3 is 1e-4 .. 1e-3 of |e_s| in task space,
+    # whatever solves the system (measured 5e-4 .. 1.3e-3 there with the fp64 solve; the reference-order fp32 arithmetic is off by
+    # 0.5 .. 12 on the same rows).  The bar for those rows is that perturbation bound; everywhere else it is 2e-5 as before.
+    e_norm = np.abs(es).reshape(len(x0), -1).max(axis=1)
+    bar64 = np.full(len(x0), 2e-5)
+    if source == "special":
+        bar64 = 2e-5 + 2.5e-7 * smax * e_norm / np.maximum(smin, 1e-3)
     for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
         x = xs[(_hip.SOLVER_F64, shape)]
         ts = _task_space(Js, x - x64)
-        assert ts.max() <= 2e-5, (name, source, shape, ts.max())
+        assert (ts <= bar64).all(), (name, source, shape, ts.max(), np.max(ts / bar64))
         pe, re = o64.pose_metrics_exact(x, tgt)
         # pose error after ONE step: the step itself is nonlinear in x, so a joint-space difference d in a near-null direction of
         # J(x0) moves the pose at x0 + delta by |J(x0 + delta) - J(x0)| d ~ |delta| d: the bar is 1e-5 + 2 |delta| |d|; rows whose
@@ -116,6 +146,8 @@ def test_one_step_task_space_parity_on_all_rows(robots, name, source):
             assert np.quantile(ts, 0.5) <= 2.0 * max(np.quantile(ts32, 0.5), 2e-7)
             assert np.quantile(ts, 0.9) <= 2.0 * max(np.quantile(ts32, 0.9), 5e-7)
         assert ts[well].max() <= 1e-4, (name, source, shape, ts[well].max())
+        if source == "special":  # row by row: the gated solve meets the fp64 solve's bar (x5: the gate's tolerance is 1e-5)
+            assert (ts <= 5.0 * bar64).all(), (name, shape, np.max(ts / bar64))
         pe, re = o64.pose_metrics_exact(x, tgt)
         ok = well & calm
         assert np.abs(pe - pe64)[ok].max() <= 2e-4 and np.abs(re - re64)[ok].max() <= 5e-4
@@ -124,8 +156,10 @@ def test_one_step_task_space_parity_on_all_rows(robots, name, source):
     # ---- fp32 without the gate: the well-conditioned rows ----
     for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
         ts = _task_space(Js, xs[(_hip.SOLVER_F32, shape)] - x64)
-        assert ts[well].max() <= 1e-4 and np.median(ts) <= 1e-6, (name, source, shape)
-    del smax
+        if source == "special":  # (the ungated fp32 error is eps cond^2 |e_s|: far targets have |e_s| ~ 5 -- why the gate exists)
+            assert (ts[well] <= 1e-4 + 1e-6 * (smax[well] / smin[well]) ** 2 * e_norm[well]).all(), (name, source, shape)
+        else:
+            assert ts[well].max() <= 1e-4 and np.median(ts) <= 1e-6, (name, source, shape)
 
 
 @pytest.mark.parametrize("name", ROBOTS)
