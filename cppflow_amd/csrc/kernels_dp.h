@@ -51,13 +51,13 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
         const float c = cost_prev[a];
 #pragma unroll
         for (int i = 0; i < kDpBPB; ++i) {
-            float m = 0.f;
+            float dq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                float dq = qb[i][j] - qa[j];
-                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-                m = fmaxf(m, fabsf(wrap_pi(dq)));
+                dq[j] = qb[i][j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
             }
+            const float m = max_wrapped_change<D>(dq);
             const float v = fmaxf(m, c) + eb[i];  // search.py:157-158
             if (v < best[i]) {
                 best[i] = v;
@@ -195,14 +195,13 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
             m[s] = 0.f;
             if (s < A) {  // wave-uniform
                 const int a = min(lane + 64 * s, k - 1);
-                float mm = 0.f;
+                float dq[D];
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
-                    float dq = qb[j] - q_prev[(size_t)a * D + j];
-                    if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-                    mm = fmaxf(mm, fabsf(wrap_pi(dq)));
+                    dq[j] = qb[j] - q_prev[(size_t)a * D + j];
+                    if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
                 }
-                m[s] = mm;
+                m[s] = max_wrapped_change<D>(dq);
             }
         }
         // ---- dependent: wait for exactly the costs this lane reads; sources ascend per lane, so `<` keeps the first minimum ----
@@ -255,14 +254,13 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
         for (int u = 0; u < 2; ++u) {
             const int b = min(b0 + 2 * h + u, k - 1);
             eb[u] = ext[(size_t)b * T + t];
-            float mm = 0.f;
+            float dq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                float dq = q_cur[(size_t)b * D + j] - qa[j];
-                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-                mm = fmaxf(mm, fabsf(wrap_pi(dq)));
+                dq[j] = q_cur[(size_t)b * D + j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
             }
-            m[u] = mm;
+            m[u] = max_wrapped_change<D>(dq);
         }
         // ---- dependent: wait for exactly the cost this lane reads ----
         unsigned long long (*img)[256] = keys[t & 1];
@@ -337,13 +335,13 @@ __global__ __launch_bounds__(256) void dp_table_kernel(const float* __restrict__
         float m = INFINITY;  // row padding: a destination that does not exist
         if (b < k) {
             const float* qa = qT + ((size_t)(t - 1) * k + a) * D;
-            m = 0.f;
+            float dq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                float dq = qb[j] - qa[j];
-                if ((pris_mask >> j) & 1u) dq *= pscale;  // search.py:119-121
-                m = fmaxf(m, fabsf(wrap_pi(dq)));
+                dq[j] = qb[j] - qa[j];
+                if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
             }
+            m = max_wrapped_change<D>(dq);
         }
         table[((size_t)(t - 1) * k + a) * kp + b] = dp_okey(m);
     }
@@ -530,14 +528,13 @@ __global__ __launch_bounds__(256) void mjacs_kernel(const float* __restrict__ q,
     const int j = (int)(ij % k), i = (int)(ij / k);
     const float* qi = q + ((size_t)i * T + t + 1) * D;
     const float* qj = q + ((size_t)j * T + t) * D;
-    float m = 0.f;
+    float dq[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        float dq = qi[c] - qj[c];
-        if ((pris_mask >> c) & 1u) dq *= pscale;
-        m = fmaxf(m, fabsf(wrap_pi(dq)));
+        dq[c] = qi[c] - qj[c];
+        if ((pris_mask >> c) & 1u) dq[c] *= pscale;
     }
-    out[idx] = m;
+    out[idx] = max_wrapped_change<D>(dq);
 }
 
 // argmin over the final costs (first minimal index), walk the memo table back, gather the path

@@ -33,16 +33,18 @@ __global__ __launch_bounds__(64) void plan_metrics_kernel(const ChainK ch, const
         if (self_mask) sm[5] += (float)self_mask[row];
         if (env_mask) sm[6] += (float)env_mask[row];
         if (w + 1 < W) {
-            float qn[D];
+            float qn[D], dq[D], wr[D];
             load_x<D>(x, row + 1, qn);
 #pragma unroll
+            for (int j = 0; j < D; ++j) dq[j] = wr[j] = qn[j] - q[j];
+            wrap_pi_all<D>(wr);
+#pragma unroll
             for (int j = 0; j < D; ++j) {
-                const float dq = qn[j] - q[j];
                 if (rb.pris(j)) {
-                    const float a = fabsf(dq);
+                    const float a = fabsf(dq[j]);
                     mx[3] = fmaxf(mx[3], nan_to_inf(100.f * a)), sm[3] += a;
                 } else {
-                    const float a = fabsf(wrap_pi(dq));
+                    const float a = fabsf(wr[j]);
                     mx[2] = fmaxf(mx[2], nan_to_inf(rad2deg * a)), sm[2] += a;
                 }
             }
@@ -103,13 +105,16 @@ __global__ __launch_bounds__(64) void seed_summary_kernel(const ChainK ch, int S
             float q[D], qn[D];
             load_x<D>(x, row, q);
             load_x<D>(x, row + 1, qn);
+            float dq[D], wr[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) dq[j] = wr[j] = qn[j] - q[j];
+            wrap_pi_all<D>(wr);
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const float dq = qn[j] - q[j];
                 if ((ch.pris_mask >> j) & 1u)
-                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq)));
+                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq[j])));
                 else
-                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wrap_pi(dq))));
+                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wr[j])));
             }
         }
     }

@@ -64,13 +64,18 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
     const bool has_next = active && !(lane == 63 && seed_ends_here);
     const int nw = wave + 1 < kBlock / 64 ? wave + 1 : wave;
     float mrev = 0.f, mpri = 0.f;
+    float dq[D], wr[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         float qn = dpp_or_zero<0x130>(q[j]);  // wave_shl:1 -- lane i reads lane i + 1
         qn = (lane == 63) ? s_q[nw][j] : qn;  // (stale but unused when wps == 1: has_next is false there)
-        const float dq = qn - q[j];
+        dq[j] = wr[j] = qn - q[j];
+    }
+    wrap_pi_all<D>(wr);  // (one rare branch for the row instead of one per joint)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
         const bool pr = rb.pris(j);
-        const float a = nan_to_inf(pr ? fabsf(100.f * dq) : fabsf(rad2deg * wrap_pi(dq)));
+        const float a = nan_to_inf(pr ? fabsf(100.f * dq[j]) : fabsf(rad2deg * wr[j]));
         mpri = fmaxf(mpri, pr ? a : 0.f);
         mrev = fmaxf(mrev, pr ? 0.f : a);
     }
@@ -498,15 +503,17 @@ __global__ __launch_bounds__(64) void seed_validity_kernel(const ChainK ch, cons
         mp = fmaxf(mp, nan_to_inf(100.f * pe));
         mr = fmaxf(mr, nan_to_inf(rad2deg * re));
         if (w + 1 < W) {
-            float qn[D];
+            float qn[D], dq[D], wr[D];
             load_x<D>(x, row + 1, qn);
 #pragma unroll
+            for (int j = 0; j < D; ++j) dq[j] = wr[j] = qn[j] - q[j];
+            wrap_pi_all<D>(wr);
+#pragma unroll
             for (int j = 0; j < D; ++j) {
-                const float dq = qn[j] - q[j];
                 if (rb.pris(j))
-                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq)));
+                    mpri = fmaxf(mpri, nan_to_inf(fabsf(100.f * dq[j])));
                 else
-                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wrap_pi(dq))));
+                    mrev = fmaxf(mrev, nan_to_inf(fabsf(rad2deg * wr[j])));
             }
         }
     }

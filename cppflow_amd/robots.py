@@ -586,8 +586,8 @@ class Robot:
                   return_memo: bool = False):
         """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191.
         `method`: "table" (k <= 256: transition table + the recurrence on one compute unit, cppf_dp_search_tabled), "resident"
-        (cppf_dp_search: resident workgroups handing the cost row on, or one launch per waypoint beyond k = 256), "auto" = table
-        up to k = 192 (where it is the faster one).  Bit-identical results."""
+        (cppf_dp_search: resident workgroups handing the cost row on, or one launch per waypoint beyond k = 256), "auto" = whichever
+        is faster at this k (table up to 128 candidates, 192 for chains of more than 8 joints).  Bit-identical results."""
         assert method in ("auto", "table", "resident"), method
         q = _require_device_tensor(q, "q")
         ext_cost = _require_device_tensor(ext_cost, "q_costs_external")
@@ -602,9 +602,12 @@ class Robot:
         best_idx = torch.empty(T, dtype=torch.int32, device=dev)
         n_table = ctypes.c_size_t(0)
         _hip.check(_hip.lib().cppf_dp_table_floats(k, T, ctypes.byref(n_table)))
-        # measured (scripts/dp_bench.py): the table form wins up to k = 192 (two register sets of table rows in flight); at
-        # k = 256 one compute unit's ~100 GB/s of table streaming is slower than the hand-offs of the resident form
-        tabled = method == "table" or (method == "auto" and k <= 192 and 2 <= T <= 65536 and n_table.value * 4 <= (1 << 30))
+        # measured (scripts/dp_bench.py, profiles/r3_dp_bench.txt): the table form wins up to k = 128 (k = 64: 168 vs 321 us, 128: 365
+        # vs 442); from 129 candidates on its rows take the 192-wide register sets (~540 us at T = 256 whatever k) and the resident
+        # hand-off form is ahead (k = 175: 491 vs 537 us, 256: 493 vs 812) -- unless the chain has more than 8 joints, whose
+        # per-pair arithmetic in front of every hand-off keeps the table form ahead up to k = 192 (12 joints: 551 vs 618 us)
+        k_table = 128 if d <= 8 else 192
+        tabled = method == "table" or (method == "auto" and k <= k_table and 2 <= T <= 65536 and n_table.value * 4 <= (1 << 30))
         if tabled:
             table = torch.empty(max(n_table.value, 1), dtype=torch.float32, device=dev)
             _hip.check(

@@ -67,8 +67,8 @@ def dp_search(
             + K_COLLISION_COST * self_collision_violations.to(q.device, torch.float32)
         )
     best_path, best_idx, _ = robot.dp_search(q, q_costs.contiguous())
-    if k > 192 and k <= 256 and int(best_idx[0].item()) < 0:
-        # the single resident launch (only used in this range of k) could not hand its cost rows from workgroup to workgroup
+    if k <= 256 and int(best_idx[0].item()) < 0:
+        # the single resident launch (k <= 256 where the table form is not the faster one) could not hand its cost rows from workgroup to workgroup
         # (include/cppflow_hip.h, cppf_dp_search): one launch per waypoint instead
         robot.debug_set("dp_persistent", 0)
         try:
