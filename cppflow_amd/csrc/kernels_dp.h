@@ -242,26 +242,40 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
     const int b0 = blockIdx.x * BP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = tid >> 8, a = tid & 255;  // k <= 256: one source per lane
     const int asrc = min(a, k - 1);
-    for (int t = 1; t < T; ++t) {
+    // The operands of a step (this lane's source configuration at t - 1, its two destinations' at t, their external costs) depend
+    // on nothing: they are loaded ONE STEP AHEAD, behind the arithmetic of the current step and in front of its wait, so that their
+    // latency lies under the hand-off instead of in front of the next one (k = 175, T = 256: 491 -> measured in DESIGN.md 8.1).
+    float qa[D], qb[2][D], eb[2];
+    auto load_operands = [&](int t, float (&qa_)[D], float (&qb_)[2][D], float (&eb_)[2]) {
         const float* q_prev = qT + (size_t)(t - 1) * k * D;
         const float* q_cur = qT + (size_t)t * k * D;
-        const float* cost_prev = costsT + (size_t)(t - 1) * k;
-        // ---- independent of the costs ----
-        float qa[D], m[2], eb[2];
 #pragma unroll
-        for (int j = 0; j < D; ++j) qa[j] = q_prev[(size_t)asrc * D + j];
+        for (int j = 0; j < D; ++j) qa_[j] = q_prev[(size_t)asrc * D + j];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int b = min(b0 + 2 * h + u, k - 1);
-            eb[u] = ext[(size_t)b * T + t];
+            eb_[u] = ext[(size_t)b * T + t];
+#pragma unroll
+            for (int j = 0; j < D; ++j) qb_[u][j] = q_cur[(size_t)b * D + j];
+        }
+    };
+    if (T > 1) load_operands(1, qa, qb, eb);
+    for (int t = 1; t < T; ++t) {
+        const float* cost_prev = costsT + (size_t)(t - 1) * k;
+        // ---- independent of the costs ----
+        float m[2], e_now[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            e_now[u] = eb[u];
             float dq[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                dq[j] = q_cur[(size_t)b * D + j] - qa[j];
+                dq[j] = qb[u][j] - qa[j];
                 if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
             }
             m[u] = max_wrapped_change<D>(dq);
         }
+        if (t + 1 < T) load_operands(t + 1, qa, qb, eb);  // (in flight during the wait below)
         // ---- dependent: wait for exactly the cost this lane reads ----
         unsigned long long (*img)[256] = keys[t & 1];
         {
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
             if (a < k) c = dp_wait_cost(cost_prev + a, memoT);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float v = fmaxf(m[u], c) + eb[u];  // search.py:157-158
+                const float v = fmaxf(m[u], c) + e_now[u];  // search.py:157-158
                 // lanes beyond k carry (+inf, 0), like the idle lanes of the per-waypoint kernel
                 img[2 * h + u][a] = a < k ? dp_key(v < INFINITY ? v : INFINITY, v < INFINITY ? a : 0) : dp_key(INFINITY, 0);
             }
