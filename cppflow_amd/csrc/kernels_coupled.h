@@ -207,6 +207,18 @@ __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm,
         const bool has_next = t + 1 < T, has_prev = t > 0;
         const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
         const float beta = prm.a_vq * prm.a_diff, beta2 = beta * beta;
+        // the wrapped joint changes to the successor / from the predecessor / from the virtual configuration, each set through
+        // wrap_pi_all (one rare branch per set instead of one per joint)
+        float wn[D], wp[D], wv[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            wn[j] = has_next ? x[(row + 1) * D + j] - q[j] : 0.f;
+            wp[j] = has_prev ? q[j] - x[(row - 1) * D + j] : 0.f;
+            wv[j] = (vq && xv) ? q[j] - xv[row * D + j] : 0.f;
+        }
+        wrap_pi_all<D>(wn);
+        wrap_pi_all<D>(wp);
+        wrap_pi_all<D>(wv);
         int k = 0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -214,9 +226,9 @@ __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm,
             const float a2 = a * a;
             M[k] += ((has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f)) * a2 + (vq ? beta2 : 0.f) + prm.lm_lambda;
             k += D - j;
-            if (has_next) m[j] = CPPF_FMA(a2, wrap_pi(x[(row + 1) * D + j] - q[j]), m[j]);
-            if (has_prev) m[j] = CPPF_FMA(-a2, wrap_pi(q[j] - x[(row - 1) * D + j]), m[j]);
-            if (vq && xv) m[j] = CPPF_FMA(-beta2, wrap_pi(q[j] - xv[row * D + j]), m[j]);
+            if (has_next) m[j] = CPPF_FMA(a2, wn[j], m[j]);
+            if (has_prev) m[j] = CPPF_FMA(-a2, wp[j], m[j]);
+            if (vq && xv) m[j] = CPPF_FMA(-beta2, wv[j], m[j]);
         }
     }
     float* o = blocks + row * (NT + D);
@@ -496,18 +508,31 @@ __global__ __launch_bounds__(64) void full_solve_kernel(const ChainK ch, const F
             if (has_next) load_x<D>(x, base + t + 1, xn);
             const float cnt = (has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f);
             const bool vq = prm.use_vq && (t < prm.n_vq || t >= T - prm.n_vq);
+            float wn[D], wp[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                wn[j] = has_next ? xn[j] - xc[j] : 0.f;
+                wp[j] = has_prev ? xc[j] - xp[j] : 0.f;
+            }
+            wrap_pi_all<D>(wn);
+            wrap_pi_all<D>(wp);
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 A[j][j] += cnt * a2[j] + (vq ? beta2 : 0.f) + prm.lm_lambda;
                 // J^T r of the differencing rows: +a^2 w_t at (t,j), -a^2 w_{t-1} at (t,j)   (w = wrapped joint change)
-                if (has_next) b[j] = CPPF_FMA(a2[j], wrap_pi(xn[j] - xc[j]), b[j]);
-                if (has_prev) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xp[j]), b[j]);
+                if (has_next) b[j] = CPPF_FMA(a2[j], wn[j], b[j]);
+                if (has_prev) b[j] = CPPF_FMA(-a2[j], wp[j], b[j]);
             }
             if (vq) {  // r = beta * wrap(x - x_virtual), J = -beta I  (optimization_utils.py:430-484)
                 float v[D];
-                if (xv) load_x<D>(xv, base + t, v);
+                if (xv) {
+                    load_x<D>(xv, base + t, v);
 #pragma unroll
-                for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? wrap_pi(xc[j] - v[j]) : 0.f, b[j]);
+                    for (int j = 0; j < D; ++j) v[j] = xc[j] - v[j];
+                    wrap_pi_all<D>(v);
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xv ? v[j] : 0.f, b[j]);
             }
         }
         if (has_prev) {
@@ -1075,17 +1100,26 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         if (has_next) {
             load_x<D>(x, base + t + 1, xo);
 #pragma unroll
-            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(a2[j], wrap_pi(xo[j] - xc[j]), b[j]);
+            for (int j = 0; j < D; ++j) xo[j] = xo[j] - xc[j];
+            wrap_pi_all<D>(xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(a2[j], xo[j], b[j]);
         }
         if (has_prev) {
             load_x<D>(x, base + t - 1, xo);
 #pragma unroll
-            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-a2[j], wrap_pi(xc[j] - xo[j]), b[j]);
+            for (int j = 0; j < D; ++j) xo[j] = xc[j] - xo[j];
+            wrap_pi_all<D>(xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-a2[j], xo[j], b[j]);
         }
         if (vq && xv) {
             load_x<D>(xv, base + t, xo);
 #pragma unroll
-            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, wrap_pi(xc[j] - xo[j]), b[j]);
+            for (int j = 0; j < D; ++j) xo[j] = xc[j] - xo[j];
+            wrap_pi_all<D>(xo);
+#pragma unroll
+            for (int j = 0; j < D; ++j) b[j] = CPPF_FMA(-beta2, xo[j], b[j]);
         }
         {
             int k = 0, kd = 0;
