@@ -1161,7 +1161,7 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
                            best_path);
         return check_launch(robot);
     }
-    const int bpb = k >= 2048 ? 4 : (k >= 512 ? 2 : 1);
+    const int bpb = k >= 4096 ? 4 : (k >= 2048 ? 2 : 1);
     const unsigned blocks = (unsigned)((k + bpb - 1) / bpb);
     for (int t = 1; t < T; ++t) {
         const float* qp = work_qT + (size_t)(t - 1) * k * d;

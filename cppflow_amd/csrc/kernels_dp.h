@@ -24,14 +24,42 @@ __global__ __launch_bounds__(256) void dp_transpose_kernel(const float* __restri
     }
 }
 
+// order-preserving bits of a float (every non-NaN value; a NaN sorts above +inf, where the scalar rule `v < best` also leaves it)
+__device__ __forceinline__ unsigned long long dp_key(float v, int a) {
+    uint32_t b = __float_as_uint(v);
+    b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((unsigned long long)b << 32) | (uint32_t)a;
+}
+__device__ __forceinline__ float dp_key_value(unsigned long long key) {
+    uint32_t b = (uint32_t)(key >> 32);
+    b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(b);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dp_dpp_min(unsigned long long x) {  // lanes without a source lane keep their own value
+    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)(x >> 32);
+    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < x ? o : x;
+}
+__device__ __forceinline__ unsigned long long dp_wave_min_to_lane63(unsigned long long x) {
+    x = dp_dpp_min<0x111>(x);  // row_shr:1
+    x = dp_dpp_min<0x112>(x);  // row_shr:2
+    x = dp_dpp_min<0x114>(x);  // row_shr:4
+    x = dp_dpp_min<0x118>(x);  // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
+    x = dp_dpp_min<0x142>(x);  // row_bcast:15 -> lanes 31 / 63 hold rows 0-1 / 2-3
+    x = dp_dpp_min<0x143>(x);  // row_bcast:31 -> lane 63 holds the wavefront's minimum
+    return x;
+}
+
 // BPB = destination candidates per workgroup: fewer for small k so that a step still fills the chip with workgroups
 template <int D, int kDpBPB>
 __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ q_prev, const float* __restrict__ q_cur,
                                                       const float* __restrict__ cost_prev, const float* __restrict__ ext,
                                                       int k, int T, int t, uint32_t pris_mask, float pscale,
                                                       float* __restrict__ cost_cur, int32_t* __restrict__ memo_cur) {
-    __shared__ float red_v[kDpBPB][4];
-    __shared__ int red_a[kDpBPB][4];
+    __shared__ unsigned long long red[kDpBPB][4];
     const int b0 = blockIdx.x * kDpBPB;
     float qb[kDpBPB][D], eb[kDpBPB], best[kDpBPB];
     int arg[kDpBPB];
@@ -65,43 +93,23 @@ __global__ __launch_bounds__(256) void dp_step_kernel(const float* __restrict__ 
             }
         }
     }
-    // lexicographic (value, index) min: first minimal index, over the wave then over the 4 waves
+    // lexicographic (value, index) minimum = first minimal index: ONE 64-bit unsigned minimum on (order key of the value, index),
+    // over the wavefront by DPP (no LDS traffic), then over the 4 wavefronts
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < kDpBPB; ++i) {
-        float v = best[i];
-        int a = arg[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(v, off, 64);
-            const int oa = __shfl_xor(a, off, 64);
-            if (ov < v || (ov == v && oa < a)) {
-                v = ov;
-                a = oa;
-            }
-        }
-        if (lane == 0) {
-            red_v[i][wave] = v;
-            red_a[i][wave] = a;
-        }
+        const unsigned long long key = dp_wave_min_to_lane63(dp_key(best[i], arg[i]));
+        if (lane == 63) red[i][wave] = key;
     }
     __syncthreads();
     if (threadIdx.x < kDpBPB) {
         const int i = threadIdx.x;
-        float v = red_v[i][0];
-        int a = red_a[i][0];
+        unsigned long long key = red[i][0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float ov = red_v[i][w];
-            const int oa = red_a[i][w];
-            if (ov < v || (ov == v && oa < a)) {
-                v = ov;
-                a = oa;
-            }
-        }
+        for (int w = 1; w < 4; ++w) key = red[i][w] < key ? red[i][w] : key;
         if (b0 + i < k) {
-            cost_cur[b0 + i] = v;
-            memo_cur[b0 + i] = a;
+            cost_cur[b0 + i] = dp_key_value(key);
+            memo_cur[b0 + i] = (int32_t)(uint32_t)key;
         }
     }
 }
@@ -141,35 +149,6 @@ __device__ __forceinline__ void dp_publish_cost(float* p, float v) {
     uint32_t bits = __float_as_uint(v);
     bits = bits == kDpSentinel ? kDpQuietNan : bits;
     __hip_atomic_store(reinterpret_cast<uint32_t*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// order-preserving bits of a float (every non-NaN value; a NaN sorts above +inf, where the scalar rule `v < best` also leaves it)
-__device__ __forceinline__ unsigned long long dp_key(float v, int a) {
-    uint32_t b = __float_as_uint(v);
-    b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u;
-    return ((unsigned long long)b << 32) | (uint32_t)a;
-}
-__device__ __forceinline__ float dp_key_value(unsigned long long key) {
-    uint32_t b = (uint32_t)(key >> 32);
-    b ^= (b >> 31) ? 0x80000000u : 0xFFFFFFFFu;
-    return __uint_as_float(b);
-}
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dp_dpp_min(unsigned long long x) {  // lanes without a source lane keep their own value
-    const int lo = (int)(uint32_t)x, hi = (int)(uint32_t)(x >> 32);
-    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    return o < x ? o : x;
-}
-__device__ __forceinline__ unsigned long long dp_wave_min_to_lane63(unsigned long long x) {
-    x = dp_dpp_min<0x111>(x);  // row_shr:1
-    x = dp_dpp_min<0x112>(x);  // row_shr:2
-    x = dp_dpp_min<0x114>(x);  // row_shr:4
-    x = dp_dpp_min<0x118>(x);  // row_shr:8   -> lane 15 of each row of 16 holds the row's minimum
-    x = dp_dpp_min<0x142>(x);  // row_bcast:15 -> lanes 31 / 63 hold rows 0-1 / 2-3
-    x = dp_dpp_min<0x143>(x);  // row_bcast:31 -> lane 63 holds the wavefront's minimum
-    return x;
 }
 
 // One wavefront per destination b (grid = k single-wave workgroups): lane l handles sources l, l+64, ..., so a step needs neither
