@@ -193,13 +193,16 @@ __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm,
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             float wn = 0.f, rn = 0.f, wp = 0.f, rp = 0.f;
-            if (prm.use_diff && has_next) diff_row_options(prm, rb.pris(j), wrap_pi(x[(row + 1) * D + j] - q[j]), wn, rn);
-            if (prm.use_diff && has_prev) diff_row_options(prm, rb.pris(j), wrap_pi(q[j] - x[(row - 1) * D + j]), wp, rp);
+            float w3[3] = {(prm.use_diff && has_next) ? x[(row + 1) * D + j] - q[j] : 0.f,
+                           (prm.use_diff && has_prev) ? q[j] - x[(row - 1) * D + j] : 0.f, (vq && xv) ? q[j] - xv[row * D + j] : 0.f};
+            wrap_pi_all<3>(w3);
+            if (prm.use_diff && has_next) diff_row_options(prm, rb.pris(j), w3[0], wn, rn);
+            if (prm.use_diff && has_prev) diff_row_options(prm, rb.pris(j), w3[1], wp, rp);
             M[k] += wn + wp + (vq ? beta2 : 0.f) + prm.lm_lambda;
             k += D - j;
             m[j] = CPPF_FMA(wn, rn, m[j]);
             m[j] = CPPF_FMA(-wp, rp, m[j]);
-            if (vq && xv) m[j] = CPPF_FMA(-beta2, wrap_pi(q[j] - xv[row * D + j]), m[j]);
+            if (vq && xv) m[j] = CPPF_FMA(-beta2, w3[2], m[j]);
             w2next[row * D + j] = wn;
         }
     } else if (prm.fold) {
@@ -666,9 +669,11 @@ __global__ __launch_bounds__(64) void full_solve_wave_kernel(const ChainK ch, co
         if (in && i == j) A += ((has_next ? 1.f : 0.f) + (has_prev ? 1.f : 0.f)) * a2j + (vq ? beta2 : 0.f) + prm.lm_lambda;
         float b = colv ? bj : 0.f;
         if (colv) {
-            if (has_next) b = CPPF_FMA(a2j, wrap_pi(xn - xc), b);
-            if (has_prev) b = CPPF_FMA(-a2j, wrap_pi(xc - xp), b);
-            if (vq && xv) b = CPPF_FMA(-beta2, wrap_pi(xc - vj), b);
+            float w3[3] = {has_next ? xn - xc : 0.f, has_prev ? xc - xp : 0.f, (vq && xv) ? xc - vj : 0.f};
+            wrap_pi_all<3>(w3);  // (straight-line; this sits on the critical path of every elimination step)
+            if (has_next) b = CPPF_FMA(a2j, w3[0], b);
+            if (has_prev) b = CPPF_FMA(-a2j, w3[1], b);
+            if (vq && xv) b = CPPF_FMA(-beta2, w3[2], b);
         }
         float ycol = b;
         if (has_prev) {
