@@ -7,6 +7,7 @@ from dataclasses import dataclass, field
 from time import time
 from typing import List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from cppflow_amd.config import (
@@ -211,11 +212,17 @@ class Plan:
     def validity_flags(self) -> dict:
         """Every term of the verdict by name (what `is_valid_(verbose=True)` and `__str__` of the reference print)."""
         c = self.constraints
+
+        def below(value, threshold) -> bool:
+            # fp32 against fp32, as `tensor.max() < python_float` compares in torch (cppflow/evaluation_utils.py:41-42, 56-59): a
+            # maximum equal to the fp32 value of the threshold is not below it
+            return bool(np.float32(value) < np.float32(threshold))
+
         return {
-            "mjac_deg": self.mjac_deg < c.max_allowed_mjac_deg,
-            "mjac_cm": self.mjac_cm < c.max_allowed_mjac_cm,
-            "max_positional_error": self.max_positional_error_cm < c.max_allowed_position_error_cm,
-            "max_rotational_error": self.max_rotational_error_deg < c.max_allowed_rotation_error_deg,
+            "mjac_deg": below(self.mjac_deg, c.max_allowed_mjac_deg),
+            "mjac_cm": below(self.mjac_cm, c.max_allowed_mjac_cm),
+            "max_positional_error": below(self.max_positional_error_cm, c.max_allowed_position_error_cm),
+            "max_rotational_error": below(self.max_rotational_error_deg, c.max_allowed_rotation_error_deg),
             "joint_limits": not self.joint_limits_violated,
             "self_collisions": int(self.self_colliding_per_ts.sum()) == 0,
             "env_collisions": int(self.env_colliding_per_ts.sum()) == 0,

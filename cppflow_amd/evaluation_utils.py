@@ -115,11 +115,10 @@ def errors_are_below_threshold(
 
 def seed_metrics_are_below_threshold(constraints, seed_metrics_row) -> Tuple[bool, Tuple[bool, bool, bool, bool]]:
     """Same decision from one row of `Robot.seed_validity` ([max pos cm, max rot deg, mjac deg, mjac cm])."""
-    p, r, mrev, mpri = (float(v) for v in seed_metrics_row)
-    flags = (
-        p < constraints.max_allowed_position_error_cm,
-        r < constraints.max_allowed_rotation_error_deg,
-        mrev < constraints.max_allowed_mjac_deg,
-        mpri < constraints.max_allowed_mjac_cm,
-    )
+    # fp32 against fp32, as `tensor.max() < python_float` compares in torch (the scalar takes the tensor's dtype) and as the device's
+    # seed selection does: a maximum equal to the fp32 value of the threshold is NOT below it
+    row = torch.as_tensor([float(v) for v in seed_metrics_row], dtype=torch.float32)
+    thr = torch.tensor([constraints.max_allowed_position_error_cm, constraints.max_allowed_rotation_error_deg,
+                        constraints.max_allowed_mjac_deg, constraints.max_allowed_mjac_cm], dtype=torch.float32)  # fmt: skip
+    flags = tuple(bool(v) for v in (row < thr))
     return all(flags), flags

@@ -131,3 +131,40 @@ def test_argument_contract(monkeypatch):
         opt.run_lm_alternating_loss(p, st, ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, False, None, 5, None, 0.3)
     with pytest.raises(AssertionError):
         opt.run_lm_alternating_loss(p, st, ALT_LOSS_V2_1_DIFF, ALT_LOSS_V2_1_POSE, False, None, 5, 6, 0.3)
+
+
+def test_x_is_valid_picks_the_first_seed_that_passes_everything_and_reports_the_last_examined_flags():
+    """x_is_valid over per-seed maxima (cppflow/optimization_utils.py:836-923, thresholds strict `<` as evaluation_utils.py:29-75):
+    seeds are examined in order; a seed failing a threshold is skipped BEFORE its collisions are looked at (their flags keep the
+    value of the previous seed that got that far, None at first); the first seed passing thresholds and both collision checks is
+    returned with its index; with none, the flags of the last seed examined come back."""
+    from cppflow_amd.data_types import Constraints
+    from cppflow_amd.optimization_utils import x_is_valid
+
+    W, d = 3, 2
+    problem = types.SimpleNamespace(n_timesteps=W)
+    c = Constraints(max_allowed_position_error_cm=0.01, max_allowed_rotation_error_deg=0.1, max_allowed_mjac_deg=3.0,
+                    max_allowed_mjac_cm=2.0)  # fmt: skip
+
+    def metrics(rows):  # (pos cm, rot deg, mjac deg, mjac cm, n_self, n_env)
+        m = torch.zeros((len(rows), 16))
+        for i, (p, r, a, b, ns, ne) in enumerate(rows):
+            m[i, 0], m[i, 2], m[i, 4], m[i, 5], m[i, 9], m[i, 10] = p, r, a, b, ns, ne
+        return m
+
+    ok = (0.005, 0.05, 1.0, 0.0, 0, 0)
+    x = torch.arange(4 * W * d, dtype=torch.float32).reshape(4 * W, d)
+    # seed 0 fails the position threshold (exactly AT the threshold is not below it), 1 collides with itself, 2 with the environment, 3 passes
+    m = metrics([(0.01, 0.05, 1.0, 0.0, 0, 0), (0.005, 0.05, 1.0, 0.0, 2, 0), (0.005, 0.05, 1.0, 0.0, 0, 1), ok])
+    xs, i, flags = x_is_valid(problem, c, None, x, 4, seed_metrics=m)
+    assert i == 3 and torch.equal(xs, x[3 * W :]) and flags == (True, True, True, True, False, False)
+    # nobody passes: the flags are those of the LAST seed examined; its collisions were never looked at, so the collision flags
+    # still hold what the last seed that got that far left there
+    m = metrics([(0.005, 0.05, 1.0, 0.0, 1, 0), (0.005, 0.2, 5.0, 0.0, 0, 0)])
+    xs, i, flags = x_is_valid(problem, c, None, x[: 2 * W], 2, seed_metrics=m)
+    assert xs is None and i is None and flags == (True, False, False, True, True, None)
+    m = metrics([(0.5, 0.05, 1.0, 3.0, 0, 0)])
+    xs, i, flags = x_is_valid(problem, c, None, x[:W], 1, seed_metrics=m)
+    assert xs is None and flags == (False, True, True, False, None, None)
+    with pytest.raises(AssertionError):
+        x_is_valid(problem, c, None, x[:W], 2, seed_metrics=m)
