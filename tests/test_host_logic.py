@@ -338,3 +338,17 @@ def test_target_path_length_known_answers():
                       [0.1, 0, 0, 0.9914449, 0, 0, 0.1305262], [0.2, 0, 0, 0.9063078, 0, 0, 0.4226183]])  # fmt: skip
     assert moving.path_length_cumultive_positional_change_cm == pytest.approx(20.0, abs=1e-5)
     assert moving.path_length_cumulative_rotational_change_deg == pytest.approx(50.0, abs=5e-4)
+
+
+def test_mjac_consistency_property_of_the_reference():
+    """tests/evaluation_utils_test.py:12-15 of the reference: the three joint-change measures agree with each other."""
+    import torch
+
+    from cppflow_amd.evaluation_utils import angular_changes, calculate_mjac_deg, calculate_per_timestep_mjac_deg
+
+    torch.manual_seed(0)
+    for _ in range(5):
+        qpath = 3.0 * torch.randn((10, 3))
+        assert abs(calculate_mjac_deg(qpath) - float(calculate_per_timestep_mjac_deg(qpath).max())) < 1e-5
+        assert abs(calculate_mjac_deg(qpath) - float(torch.rad2deg(angular_changes(qpath).abs().max()))) < 1e-5
+        assert float(angular_changes(qpath).abs().max()) <= 3.14159275
