@@ -158,6 +158,16 @@ J_PINS = {
 J_PINS["fetch_arm"] = J_PINS["fetch"][:, 1:].copy()
 
 
+# ---- the one forward-kinematics datum of the reference tree ------------------------------------------------------------------------
+# tests/planners_test.py:299-309 of the reference: a (commented-out) Panda configuration q0 next to the assertion that
+# robot.forward_kinematics(q0) equals the first pose of its target path to atol = 1e-3 -- pose [0.45, 0, 0, 1, 0, 0, 0] + the
+# panda__1cube offset [0, 0.5421984559194368, 0.7885155964931997] (`:282-298`).  jrl's Panda (`panda_link0 -> panda_hand`,
+# ros2/ros2_publisher.py:60-61) evaluated at an arbitrary seven-joint configuration: the only number in the reference that
+# depends on every link offset, every axis and the hand frame of the model at once.
+REFERENCE_PANDA_Q0 = [1.267967, 0.711829, -0.811080, -0.810924, -2.637594, 1.767759, 0.083284]
+REFERENCE_PANDA_POSE = [0.45, 0.5421984559194368, 0.7885155964931997, 1.0, 0.0, 0.0, 0.0]
+
+
 def fk_pin_arrays(name):
     q = np.array([p[0] for p in FK_PINS[name]], dtype=np.float64)
     pose = np.array([p[1] for p in FK_PINS[name]], dtype=np.float64)

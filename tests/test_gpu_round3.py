@@ -217,6 +217,9 @@ def test_gpu_forward_kinematics_equals_hand_derived_values(name):
     assert H.pose_close(got, pose, 2e-6, 2e-6), (got, pose)
     J = host(rb.jacobian(dev(q)))
     assert np.abs(J - H.oracle64(name).jacobian(H.f32(q))).max() < 1e-5
+    if name == "panda":  # the one FK datum of the reference tree (tests/planners_test.py:299-309), at the reference's own atol
+        got = host(rb.forward_kinematics(dev([H.REFERENCE_PANDA_Q0])))
+        assert H.pose_close(got, np.array([H.REFERENCE_PANDA_POSE]), 1e-3, 1e-3), got
     # and the zero-pose Jacobian against the values derived on paper (tests/helpers.py:J_PINS)
     Jz = H.J_PINS[name]
     assert np.abs(host(rb.jacobian(dev(np.zeros((1, Jz.shape[1])))))[0] - Jz).max() < 2e-6

@@ -360,6 +360,23 @@ def test_forward_kinematics_equals_hand_derived_values_from_the_urdf_constants(n
         assert np.allclose(torso[9:], [-0.086875, 0.0, 0.37743], atol=1e-7) and np.allclose(torso[:9], np.eye(3).ravel(), atol=1e-12)
 
 
+def test_panda_model_reproduces_the_reference_tree_s_one_fk_datum():
+    """tests/planners_test.py:299-309 of the reference holds a Panda configuration and asserts its forward kinematics against a
+    pose to atol = 1e-3 (tests/helpers.py:REFERENCE_PANDA_Q0).  This build's Panda -- the public URDF constants + `panda_hand`
+    -- lands 0.8 mm and 2.5e-4 rad from that pose (the configuration is printed to six decimals and was an IK solution to a
+    tolerance, hence not 1e-7): the model is jrl's, not merely self-consistent."""
+    import torch
+
+    from cppflow_amd.robot_zoo import ROBOT_SPECS
+    from oracle import ref_torch
+
+    q0, want = np.array([H.REFERENCE_PANDA_Q0]), np.array([H.REFERENCE_PANDA_POSE])
+    for got in (H.oracle64("panda").fk(q0), H.oracle32("panda").fk(H.f32(q0)),
+                ref_torch.TorchRobot(ROBOT_SPECS["panda"](), device="cpu", dtype=torch.float64).forward_kinematics(torch.tensor(q0)).numpy()):
+        assert H.pose_close(got, want, 1e-3, 1e-3), got  # the reference's own tolerance
+        assert np.abs(got[0, :3] - want[0, :3]).max() < 6e-4 and np.abs(got[0, 4:]).max() < 2e-4
+
+
 @pytest.mark.parametrize("name,T,pose", [("panda", 24, False), ("panda", 64, False), ("fetch", 40, False), ("panda", 30, True),
                                          ("chain12", 16, False), ("panda", 1, False), ("panda", 2, False)])
 def test_banded_coupled_step_equals_the_reference_s_dense_formulation(name, T, pose):
