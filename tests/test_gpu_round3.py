@@ -512,3 +512,44 @@ def test_fused_launch_is_deterministic_under_concurrency(inputs):
     for xo, pk, sm in outs[1:]:
         assert torch.equal(xo, x_ref) and torch.equal(pk, pk_ref) and torch.equal(sm, sm_ref)
     rb.set_obstacles([], [])
+
+
+def test_resident_dp_search_hand_offs_hold_under_uneven_load():
+    """MI355X_MICROARCH.md: "test every hand-off under UNEVEN load".  The resident dp_search launch (workgroups handing their cost
+    rows on through memory) repeated 40 times while two other streams keep the chip busy with full-size fused launches: every
+    repetition must return the oracle's path, cost table and argmins bit for bit, and never report a hand-off time-out."""
+    import bench
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot("panda")
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    k, T = 175, 96
+    rng = np.random.RandomState(4)
+    ch = H.chain("panda")
+    q = H.f32(np.clip(rng.uniform(ch.lo, ch.hi, size=(k, 1, 7)) + np.cumsum(0.05 * rng.randn(k, T, 7), axis=1), ch.lo, ch.hi))
+    ext = H.f32(rng.choice([0.0, 100.0, 1000.0], size=(k, T), p=[0.8, 0.1, 0.1]))
+    want_idx, want_costs = H.oracle32("panda").dp_search(q, ext)
+    qd, ed = dev(q), dev(ext)
+    S, W = 1024, 256
+    x0, target, _ = bench.make_inputs_problem(rb, S, W, torch.device(DEV), seed=0)
+    load_streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    bufs = [(torch.empty_like(x0), torch.empty(rb.PACKED_BYTES_PER_ROW * S * W, dtype=torch.uint8, device=DEV)) for _ in range(2)]
+    dp_stream = torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    results = []
+    for rep in range(40):
+        for s_, (xo, pk) in zip(load_streams, bufs):  # uneven: the load comes and goes between repetitions
+            if rep % 3 != 2:
+                with torch.cuda.stream(s_):
+                    rb.lm_pose_steps(x0, target, n_steps=10, x_out=xo, packed_out=pk, **LM)
+        with torch.cuda.stream(dp_stream):
+            results.append(rb.dp_search(qd, ed, method="resident"))
+    torch.cuda.synchronize()
+    for path, idx, costsT in results:
+        gi = idx.cpu().numpy()
+        assert (gi >= 0).all(), "hand-off time-out"
+        assert np.array_equal(gi, want_idx)
+        assert np.array_equal(costsT.cpu().numpy().T.astype(np.float64), want_costs)
+        assert np.array_equal(path.cpu().numpy().astype(np.float64), q[want_idx, np.arange(T)])
+    rb.set_obstacles([], [])
