@@ -732,28 +732,31 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     // Dynamic LDS: what the generic kernels stage their capsules in, or -- for a launch of at most two workgroups per compute
     // unit -- a claim sized so that only two workgroups FIT on one (fused_spread_lds): several such launches in flight then
     // spread over the whole chip instead of stacking four deep on the compute units the dispatcher tries first.
+    // (the kernels get `outk`: with the separate reduction its seed_summary is NULL -- handing them `*out` there made the in-launch
+    // summary run on a W it is not built for and write up to n / 64 - S rows past the caller's [S,8] buffer before the reduction
+    // kernel put the right values in: found by the sentinel-arena test of tests/test_gpu_round3.py)
     const size_t lds_need = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
     const size_t lds = std::max(lds_need, fused_spread_lds(robot, n));
     if (use_rtc(robot)) {
-        void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)out};
+        void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&outk};
         const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
         if (int rc = rtc_launch(robot, which, grid_for(n), fused_spread_lds(robot, n), st, args)) return rc;
     } else if (coll && (out->min_self || out->min_env)) {
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
-                       prm, x_in, target, *out)
+                       prm, x_in, target, outk)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else if (coll) {
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
-                       prm, x_in, target, *out)
+                       prm, x_in, target, outk)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     } else {
 #define CPPF_BODY                                                                                               \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), fused_spread_lds(robot, n), st, robot->chain, robot->coll, \
-                       prm, x_in, target, *out)
+                       prm, x_in, target, outk)
         CPPF_DISPATCH_RB(robot)
 #undef CPPF_BODY
     }

@@ -553,3 +553,57 @@ def test_resident_dp_search_hand_offs_hold_under_uneven_load():
         assert np.array_equal(costsT.cpu().numpy().T.astype(np.float64), want_costs)
         assert np.array_equal(path.cpu().numpy().astype(np.float64), q[want_idx, np.arange(T)])
     rb.set_obstacles([], [])
+
+
+def test_kernels_stay_inside_their_output_buffers():
+    """Ragged sizes (rows not a multiple of the workgroup, W not a multiple of the wavefront) with every output carved out of ONE
+    sentinel-filled arena with 1 KB gaps: after the launches the gaps still hold the sentinel (no write past the end or in front of a
+    buffer), for the fused launch in both kernel shapes, the standalone collision launch, FK / Jacobian, and dp_search."""
+    from cppflow_amd import _hip
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot("panda")
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    S, W, d = 5, 77, 7
+    n = S * W
+    x0, target = H.lm_problem("panda", S, W, seed=21)
+    SENT = 0xA5
+    arena = torch.full((64 << 20,), SENT, dtype=torch.uint8, device=DEV)
+    cursor = [4096]
+    spans = []
+
+    def carve(nbytes, dtype, shape):
+        start = (cursor[0] + 255) // 256 * 256
+        t = arena[start : start + nbytes].view(dtype).view(shape)
+        spans.append((start, start + nbytes))
+        cursor[0] = start + nbytes + 1024
+        return t
+
+    def gaps_intact():
+        torch.cuda.synchronize()
+        mask = torch.ones(cursor[0] + 4096, dtype=torch.bool, device=DEV)
+        for a, b in spans:
+            mask[a:b] = False
+        return bool((arena[: cursor[0] + 4096][mask] == SENT).all())
+
+    for shape in (_hip.SHAPE_ROW, _hip.SHAPE_QUAD):
+        xo = carve(n * d * 4, torch.float32, (n, d))
+        pk = carve(rb.PACKED_BYTES_PER_ROW * n, torch.uint8, (rb.PACKED_BYTES_PER_ROW * n,))
+        sm = carve(S * 8 * 4, torch.float32, (S, 8))
+        rb.lm_pose_steps(dev(x0), dev(target), n_steps=3, x_out=xo, packed_out=pk, summary_out=sm, shape=shape, **LM)
+        assert gaps_intact(), ("fused", shape)
+        assert bool(torch.isfinite(xo).all()) and not bool((pk.view(torch.uint8)[-n:] == SENT).all())
+    r = rb.lm_pose_steps(dev(x0), dev(target), n_steps=1, clamp=False, return_residual=True, want_iters=True,
+                         x_out=carve(n * d * 4, torch.float32, (n, d)), **LM)
+    assert gaps_intact() and r["J"].shape == (n, 6, d)
+    q3 = dev(x0).reshape(S, W, d)
+    rb.collision_masks(q3, want_min_dists=True)
+    poses = rb.forward_kinematics(dev(x0))
+    J = rb.jacobian(dev(x0))
+    assert gaps_intact() and poses.shape == (n, 7) and J.shape == (n, 6, d)
+    for k, T in ((5, 77), (130, 9), (300, 5)):
+        qq = dev(H.random_configs("panda", k * T, seed=k).reshape(k, T, d))
+        rb.dp_search(qq, torch.zeros((k, T), device=DEV))
+        assert gaps_intact(), ("dp", k, T)
+    rb.set_obstacles([], [])
