@@ -607,3 +607,132 @@ def test_kernels_stay_inside_their_output_buffers():
         rb.dp_search(qq, torch.zeros((k, T), device=DEV))
         assert gaps_intact(), ("dp", k, T)
     rb.set_obstacles([], [])
+
+
+class _SentinelArena:
+    """Routes torch.empty / zeros / empty_like of CUDA tensors through one sentinel-filled arena with 1 KB gaps, so that a write outside
+    ANY buffer the Python wrappers allocate for a kernel shows up as a damaged gap."""
+
+    SENT = 0xA5
+
+    def __init__(self, mbytes=256):
+        self.arena = torch.full((mbytes << 20,), self.SENT, dtype=torch.uint8, device=DEV)
+        self.cursor, self.spans = 4096, []
+        self._orig = {}
+
+    def alloc(self, shape, dtype):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        start = (self.cursor + 255) // 256 * 256
+        assert start + nbytes + 8192 < self.arena.numel(), "arena too small"
+        self.spans.append((start, start + nbytes))
+        self.cursor = start + nbytes + 1024
+        return self.arena[start : start + nbytes].view(dtype).view(shape)
+
+    def __enter__(self):
+        o_empty, o_zeros, o_like = torch.empty, torch.zeros, torch.empty_like
+        self._orig = dict(empty=o_empty, zeros=o_zeros, empty_like=o_like)
+
+        def on_cuda(kw):
+            d = kw.get("device", None)
+            return d is not None and "cuda" in str(d)
+
+        def empty(*size, **kw):
+            if on_cuda(kw) and not kw.get("pin_memory", False):
+                shape = size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+                return self.alloc(shape, kw.get("dtype", torch.float32))
+            return o_empty(*size, **kw)
+
+        def zeros(*size, **kw):
+            if on_cuda(kw):
+                shape = size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+                t = self.alloc(shape, kw.get("dtype", torch.float32))
+                t.zero_()
+                return t
+            return o_zeros(*size, **kw)
+
+        def empty_like(t, **kw):
+            if t.is_cuda and not kw:
+                return self.alloc(t.shape, t.dtype)
+            return o_like(t, **kw)
+
+        torch.empty, torch.zeros, torch.empty_like = empty, zeros, empty_like
+        return self
+
+    def __exit__(self, *a):
+        torch.empty, torch.zeros, torch.empty_like = self._orig["empty"], self._orig["zeros"], self._orig["empty_like"]
+
+    def intact(self):
+        torch.cuda.synchronize()
+        end = self.cursor + 4096
+        mask = torch.ones(end, dtype=torch.bool, device=DEV)
+        for a, b in self.spans:
+            mask[a:b] = False
+        return bool((self.arena[:end][mask] == self.SENT).all())
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch", "chain12"])
+def test_every_entry_point_stays_inside_the_buffers_its_wrapper_allocates(name):
+    """Every device entry point of the Python mirror at ragged sizes, with the wrappers' own output allocations routed through a
+    sentinel arena (`_SentinelArena`): FK, Jacobian, pose errors / metrics, clamp, distance matrices and their Jacobians, masks, the
+    fused launch (default outputs, residuals, iteration counts, minimum distances), seed validity / summary / selection, plan
+    metrics, the coupled step in its three elimination orders, mjacs and dp_search in its three forms."""
+    from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot(name)
+    d = rb.ndof
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    S, W = 3, 37
+    n = S * W
+    x0, target = H.lm_problem(name, S, W, seed=31)
+    x, tg = dev(x0), dev(target)
+    arena = _SentinelArena()
+    checks = []
+    with arena:
+        def step(label, fn):
+            fn()
+            checks.append((label, arena.intact()))
+
+        step("fk", lambda: rb.forward_kinematics(x))
+        step("jacobian", lambda: rb.jacobian(x))
+        step("pose_error_metrics", lambda: rb.pose_error_metrics(x, tg))
+        step("self distances", lambda: rb.self_collision_distances(x))
+        step("env distances", lambda: rb.env_collision_distances(x, obs[0][0], obs[0][1]))
+        step("self distance jacobian", lambda: rb.self_collision_distances_jacobian(x, return_distances=True))
+        step("env distance jacobian", lambda: rb.env_collision_distances_jacobian(x, obs[0][0], obs[0][1], return_distances=True))
+        step("masks", lambda: rb.collision_masks(x.reshape(S, W, d), want_min_dists=True))
+        step("fused default", lambda: rb.lm_pose_steps(x, tg, n_steps=3, want_errors=True, want_collisions=True, want_min_dists=True, **LM))
+        step("fused residual", lambda: rb.lm_pose_steps(x, tg, n_steps=1, clamp=False, return_residual=True, want_iters=True, **LM))
+        step("fused early-out", lambda: rb.lm_pose_steps(x, tg, n_steps=6, tol_pos_m=1e-4, tol_rot_rad=1e-3, want_iters=True, want_errors=True, **LM))
+        step("seed validity", lambda: rb.seed_validity(x, tg))
+        step("plan metrics", lambda: rb.plan_metrics(x, tg))
+        step("mjacs", lambda: rb.mjacs(x.reshape(S, W, d)))
+        for method in ("table", "resident"):
+            step("dp " + method, lambda: rb.dp_search(x.reshape(S, W, d), torch.zeros((S, W), device=DEV), method=method))
+        rb.debug_set("dp_persistent", 0)
+        step("dp per waypoint", lambda: rb.dp_search(x.reshape(S, W, d), torch.zeros((S, W), device=DEV), method="resident"))
+        rb.debug_set("dp_persistent", None)
+        kw = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+        kw.update(n_virtual_configs=2)
+        pm = OptimizationParameters(**kw)
+        pm.virtual_configs = x.clone()
+        for order, sets in (("default", {}), ("sequential", {"pcr_max_rows": 0}), ("per wave", {"pcr_max_rows": 0, "full_rows": 0})):
+            for k_, v_ in sets.items():
+                rb.debug_set(k_, v_)
+            try:
+                step("coupled " + order, lambda: rb.lm_full_step(x, tg, pm, virtual_configs=pm.virtual_configs))
+            finally:
+                for k_ in sets:
+                    rb.debug_set(k_, None)
+        sm = torch.empty((S, 8), dtype=torch.float32, device=DEV)
+        pk = torch.empty(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=DEV)
+        step("fused packed + summary", lambda: rb.lm_pose_steps(x, tg, n_steps=2, packed_out=pk, summary_out=sm, **LM))
+        step("select", lambda: rb.select_valid_seed(sm, DEFAULT_CONSTRAINTS))
+    bad = [label for label, ok in checks if not ok]
+    assert not bad, bad
+    assert len(arena.spans) > 40
+    rb.set_obstacles([], [])
