@@ -797,3 +797,46 @@ def test_results_do_not_depend_on_what_the_output_and_work_buffers_held_before(n
     assert not differing, differing
     assert torch.equal(x, x_keep) and torch.equal(tg, tg_keep) and torch.equal(pm.virtual_configs, x_keep)
     rb.set_obstacles([], [])
+
+
+@pytest.mark.parametrize("S,T", [(1, 256), (8, 256), (3, 300), (2, 512), (9, 64), (1, 2), (600, 64)])
+def test_coupled_step_and_dp_search_workspaces_hold_at_boundary_shapes(S, T):
+    """The sentinel arena again, at the shapes where the coupled step and dp_search switch kernels (parallel-in-time up to 256
+    waypoints in LDS / beyond in the workspace, rows kernels beyond 512 trajectories; table / resident / per-waypoint dp_search)."""
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot("panda")
+    rb.set_obstacles([c for c, _ in H.PANDA_2CUBES], [T_ for _, T_ in H.PANDA_2CUBES])
+    ch = H.chain("panda")
+    rng = np.random.RandomState(S * 1000 + T)
+    base = np.clip(H.random_configs("panda", 1, seed=T) + np.cumsum(0.02 * rng.randn(T, 7), axis=0), ch.lo, ch.hi)
+    x = dev(np.clip(base[None] + 0.01 * rng.randn(S, T, 7), ch.lo, ch.hi).reshape(S * T, 7))
+    tg = dev(H.oracle64("panda").fk(H.f32(base)))
+    kw = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+    nvc = 4 if T > 8 else 0
+    kw.update(use_virtual_configs=bool(nvc), n_virtual_configs=nvc if nvc else None)
+    pm = OptimizationParameters(**kw)
+    pm.virtual_configs = x.clone() if nvc else torch.tensor([])
+    arena = _SentinelArena(mbytes=512)
+    bad = []
+    with arena:
+        for order, sets in (("default", {}), ("sequential", {"pcr_max_rows": 0}), ("per wave", {"pcr_max_rows": 0, "full_rows": 0}),
+                            ("pcr in workspace", {"pcr_lds": 0})):
+            for k_, v_ in sets.items():
+                rb.debug_set(k_, v_)
+            try:
+                out = rb.lm_full_step(x, tg, pm, virtual_configs=pm.virtual_configs)
+                assert bool(torch.isfinite(out).all()), order
+            finally:
+                for k_ in sets:
+                    rb.debug_set(k_, None)
+            if not arena.intact():
+                bad.append("coupled " + order)
+        q3 = x.reshape(S, T, 7)
+        for method in ("table", "resident") if S <= 256 and T >= 2 else ("resident",):
+            rb.dp_search(q3, torch.zeros((S, T), device=DEV), method=method)
+            if not arena.intact():
+                bad.append("dp " + method)
+    assert not bad, bad
+    rb.set_obstacles([], [])
