@@ -840,3 +840,52 @@ def test_coupled_step_and_dp_search_workspaces_hold_at_boundary_shapes(S, T):
                 bad.append("dp " + method)
     assert not bad, bad
     rb.set_obstacles([], [])
+
+
+@pytest.mark.parametrize("ndof,specialize", [(7, False), (7, True), (5, False), (12, False), (12, True)])
+def test_generic_and_run_time_specialised_kernels_stay_inside_their_buffers(ndof, specialize):
+    """The sentinel arena for robots that are NOT in the generated tables: the generic kernels (chain constants in kernel arguments,
+    capsules staged in LDS) and the run-time-specialised ones, ragged sizes, prismatic joints included."""
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+    from cppflow_amd.robot_model import canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    spec = H.random_chain_spec(ndof, seed=5)
+    rb = Robot(spec, specialize=specialize)
+    ch = canonicalize(spec)
+    o64 = Oracle(ch, f32=False)
+    rng = np.random.RandomState(3)
+    S, W = 3, 41
+    q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(W, ndof)))
+    tg = dev(o64.fk(q_star))
+    x = dev(np.clip(q_star[None] + 0.05 * rng.randn(S, W, ndof), ch.lo, ch.hi).reshape(S * W, ndof))
+    obs = [H.cuboid_obstacle(0.1, 0.1, 0.5, 0.3, 0.3, 0.3)]
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    kw = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+    kw.update(n_virtual_configs=2)
+    pm = OptimizationParameters(**kw)
+    pm.virtual_configs = x.clone()
+    arena = _SentinelArena()
+    bad = []
+    with arena:
+        calls = [
+            ("fused", lambda: rb.lm_pose_steps(x, tg, n_steps=3, want_errors=True, want_collisions=True, want_min_dists=True, **LM)),
+            ("fused residual", lambda: rb.lm_pose_steps(x, tg, n_steps=1, clamp=False, return_residual=True, **LM)),
+            ("masks", lambda: rb.collision_masks(x.reshape(S, W, ndof), want_min_dists=True)),
+            ("self distances", lambda: rb.self_collision_distances(x)),
+            ("env distance jacobian", lambda: rb.env_collision_distances_jacobian(x, obs[0][0], obs[0][1], return_distances=True)),
+            ("plan metrics", lambda: rb.plan_metrics(x, tg)),
+            ("coupled", lambda: rb.lm_full_step(x, tg, pm, virtual_configs=pm.virtual_configs)),
+            ("dp", lambda: rb.dp_search(x.reshape(S, W, ndof), torch.zeros((S, W), device=DEV))),
+        ]
+        if ndof >= 6:
+            from cppflow_amd import _hip
+
+            calls.append(("fused quad", lambda: rb.lm_pose_steps(x, tg, n_steps=3, want_errors=True, want_collisions=True, shape=_hip.SHAPE_QUAD, **LM)))
+        for label, fn in calls:
+            fn()
+            if not arena.intact():
+                bad.append(label)
+    assert not bad, bad
