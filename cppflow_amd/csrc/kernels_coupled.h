@@ -55,6 +55,13 @@ __device__ __forceinline__ void diff_row_options(const FullK& prm, bool pris, fl
     w2 = a * a;
 }
 
+// Closest points nearer than this (1 um) count as TOUCHING: a segment that crosses a cuboid (or another segment) has distance 0 in
+// exact arithmetic and ~1e-9 in fp32, in a direction that is rounding noise -- normalised, that noise became a unit "gradient" on
+// one side and a different one (or none) in the fp64 oracle, and in a system held only by its collision rows the two steps differed
+// by their whole length (found by scripts/fuzz_coupled.py).  Below the bound the direction is undefined and the gradient is 0, on
+// both sides (oracle/lmik_oracle.c ORC_TOUCH).
+constexpr float kTouch = 1e-6f;
+
 // gradient of a point rigidly attached to moving link `link`, projected on n:  n . d(c)/dq_j  for every joint j
 template <class RB>
 __device__ __forceinline__ void point_grad(const RB& rb, int link, const float (&n)[3], const float (&c)[3],
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
             lds_capsule(lds, tid, e, wc, wh);
             sd = seg_box_closest(wc, wh, lo, hi, cs, cb);
             radius = co.cap_r[e];
-            if (sd > 0.f) {
+            if (sd > kTouch) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
             }
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void distance_jacobians_kernel(const ChainK
             lds_capsule(lds, tid, b, cb2, hb);
             sd = seg_seg_closest(ca, ha, cb2, hb, co.cap_a[a], co.cap_ia[a], co.cap_a[b], co.cap_ia[b], c1, c2);
             radius = co.cap_r[a] + co.cap_r[b];
-            if (sd > 0.f) {
+            if (sd > kTouch) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
             }
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
             const float dist = sd - (co.cap_r[a] + co.cap_r[b]);
             if (dist < 0.f) {
                 float nrm[3] = {0.f, 0.f, 0.f}, g[D];
-                if (sd > 0.f) {
+                if (sd > kTouch) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) nrm[i] = (c1[i] - c2[i]) / sd;
                 }
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4
                 const float dist = sd - co.cap_r[c];
                 if (dist < 0.f) {
                     float nrm[3] = {0.f, 0.f, 0.f}, g[D];
-                    if (sd > 0.f) {
+                    if (sd > kTouch) {
 #pragma unroll
                         for (int i = 0; i < 3; ++i) nrm[i] = (cs[i] - cb[i]) / sd;
                     }

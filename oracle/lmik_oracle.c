@@ -1087,9 +1087,14 @@ static void capsules_and_axes(const orc_robot* rb, const REAL* q, REAL (*w0)[3],
     capsules_from_links(rb, links, w0, w1);
 }
 
+/* Closest points nearer than this (1 um) count as TOUCHING: the direction between them is rounding noise there -- a segment that
+ * crosses a box has distance 0 in exact arithmetic and 1e-9 in fp32, in some direction -- so the gradient is 0 (the same constant
+ * and rule as csrc/kernels_coupled.h kTouch). */
+#define ORC_TOUCH RC(1e-6)
+
 /* signed self-collision distances [P] and their gradients [P,d] for one configuration: the derivative of the minimum
  * distance equals the derivative with the closest points held fixed on their links (envelope theorem); where the
- * segments touch (distance 0) the direction is undefined and the gradient is set to 0.
+ * segments touch (distance below ORC_TOUCH) the direction is undefined and the gradient is set to 0.
  * (jrl.Robot.self_collision_distances_jacobian, call site cppflow/optimization_utils.py:670 -- un-vendored; this is the
  * analytic gradient of this build's own distance definition, checked against finite differences in the tests.) */
 static void self_dists_and_grads(const orc_robot* rb, const REAL* q, REAL* dist, REAL* grad) {
@@ -1102,7 +1107,7 @@ static void self_dists_and_grads(const orc_robot* rb, const REAL* q, REAL* dist,
         const REAL sd = seg_seg_closest(w0[a], w1[a], w0[b], w1[b], PAIR_CONSTS(rb, a, b), c1, c2);
         dist[p] = sd - (rb->cap_r[a] + rb->cap_r[b]);
         REAL n[3] = {0, 0, 0};
-        if (sd > 0)
+        if (sd > ORC_TOUCH)
             for (int i = 0; i < 3; ++i) n[i] = (c1[i] - c2[i]) / sd;
         for (int j = 0; j < d; ++j) {
             REAL j1[3], j2[3];
@@ -1122,7 +1127,7 @@ static void env_dists_and_grads(const orc_robot* rb, const REAL* q, const REAL* 
         const REAL sd = seg_box_closest(w0[c], w1[c], lo, hi, cs, cb);
         dist[c] = sd - rb->cap_r[c];
         REAL n[3] = {0, 0, 0};
-        if (sd > 0)
+        if (sd > ORC_TOUCH)
             for (int i = 0; i < 3; ++i) n[i] = (cs[i] - cb[i]) / sd;
         for (int j = 0; j < d; ++j) {
             REAL j1[3];

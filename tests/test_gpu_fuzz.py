@@ -14,7 +14,9 @@ def test_fuzz_sweep_reports_no_disagreement(script, capsys):
     """fuzz_dp: cppf_dp_search in its table / resident / per-waypoint forms over k = 1 .. 300, T = 1 .. 257 with ties, +inf columns,
     1e33 costs and identical candidates -- cost table, argmins and path bit-identical to the oracle (920 comparisons).
     fuzz_coupled: cppf_lm_full_step in its three elimination orders over T = 1 .. 65, S = 1 .. 3, 0 .. 4 virtual configurations,
-    with and without obstacles, three robots (1134 comparisons).
+    with and without obstacles, with the differencing "satisfied" options (filter / scale-down / scale-down + shift), three robots (2349
+    comparisons; where an option's threshold falls within rounding of a joint change the reference's dense formulation on the mirror's
+    matrices arbitrates).
     fuzz_lm: the fused launch over four robots x eleven (S, W) shapes (W = 1 .. 300, ragged and not) x K in {1, 3, 10} x kernel
     shape x solver: x against the oracle, per-row outputs at the launch's own x (masks bit-exact), the per-seed summary against the
     separate reduction, the two kernel shapes against each other (792 launches)."""
