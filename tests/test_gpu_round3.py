@@ -889,3 +889,45 @@ def test_generic_and_run_time_specialised_kernels_stay_inside_their_buffers(ndof
             if not arena.intact():
                 bad.append(label)
     assert not bad, bad
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+def test_robot_at_the_capsule_and_pair_maxima(specialize):
+    """CPPF_MAX_CAPSULES (24) capsules and CPPF_MAX_PAIRS (128) checked pairs on an 8-joint chain with a prismatic joint: the
+    collision stage, standalone and fused, stays bit-exact with the canonical-fp32 oracle in the generic kernels (capsules staged in
+    LDS) and in the run-time-specialised ones (every pair test unrolled)."""
+    from cppflow_amd.robot_model import CapsuleSpec, JointSpec, RobotSpec, canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    rng = np.random.RandomState(2)
+    d = 8
+    joints = [JointSpec(f"j{i}", f"l{i}", tuple(rng.uniform(-0.1, 0.2, 3)), tuple(rng.uniform(-1, 1, 3)), (0, 0, 1),
+                        "revolute" if i != 3 else "prismatic", (-2.0, 2.0) if i != 3 else (-0.1, 0.3)) for i in range(d)]  # fmt: skip
+    joints.append(JointSpec("tool", "tool", (0, 0, 0.1), (0, 0, 0), jtype="fixed"))
+    caps = [CapsuleSpec(f"l{i}", tuple(rng.uniform(-0.05, 0.05, 3)), tuple(rng.uniform(-0.1, 0.1, 3)), 0.02 + 0.01 * r)
+            for i in range(d) for r in range(3)]  # fmt: skip
+    pairs = [(a, b) for a in range(24) for b in range(a + 1, 24) if b // 3 - a // 3 >= 2][:128]
+    spec = RobotSpec("maxcaps", "24 capsules, 128 pairs", "base", joints, caps, collision_pairs=pairs)
+    ch = canonicalize(spec)
+    assert ch.n_capsules == 24 and ch.n_pairs == 128
+    o32 = Oracle(ch, f32=True)
+    S, W = 4, 100
+    q = H.f32(rng.uniform(ch.lo, ch.hi, size=(S * W, d)))
+    obs = [H.cuboid_obstacle(0.2, 0.1, 0.3, 0.3, 0.3, 0.3), H.cuboid_obstacle(-0.2, 0.1, 0.5, 0.2, 0.2, 0.2)]
+    lo, hi = H.box_corners([c for c, _ in obs], [T for _, T in obs])
+    rb = Robot(spec, specialize=specialize)
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    jl_lo, jl_hi = rb.padded_joint_limits()
+    want = o32.masks(q, lo, hi, jl_lo, jl_hi)
+    assert want["self_mask"].sum() > 50 and want["env_mask"].sum() > 50
+    keys = ("self_mask", "env_mask", "jlim_mask", "ext_cost", "min_self", "min_env")
+    got = rb.collision_masks(dev(q).reshape(S, W, d), want_min_dists=True)
+    for k in keys:
+        assert np.array_equal(got[k].cpu().numpy().reshape(-1).astype(want[k].dtype), want[k]), k
+    tg = dev(Oracle(ch, f32=False).fk(q[:W]))
+    r = rb.lm_pose_steps(dev(q), tg, n_steps=3, want_errors=True, want_collisions=True, want_min_dists=True, **LM)
+    w1 = o32.masks(host(r["x"]), lo, hi, jl_lo, jl_hi)
+    for k in keys:
+        assert np.array_equal(r[k].cpu().numpy().astype(w1[k].dtype), w1[k]), ("fused", k)
