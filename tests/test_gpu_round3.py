@@ -931,3 +931,47 @@ def test_robot_at_the_capsule_and_pair_maxima(specialize):
     w1 = o32.masks(host(r["x"]), lo, hi, jl_lo, jl_hi)
     for k in keys:
         assert np.array_equal(r[k].cpu().numpy().astype(w1[k].dtype), w1[k]), ("fused", k)
+
+
+def test_coupled_step_at_the_capsule_pair_and_obstacle_maxima():
+    """24 capsules, 128 pairs and 8 cuboids at once: the screening bit sets of the coupled step's block kernel wrap (more candidates
+    than bits), which may cost work but never a collision row -- the step equals the oracle's dense restatement."""
+    from cppflow_amd.lm_hyper_parameters import ALT_LOSS_V2_1_DIFF, OptimizationParameters
+    from cppflow_amd.robot_model import CapsuleSpec, JointSpec, RobotSpec, canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    rng = np.random.RandomState(2)
+    d = 8
+    joints = [JointSpec(f"j{i}", f"l{i}", tuple(rng.uniform(-0.1, 0.2, 3)), tuple(rng.uniform(-1, 1, 3)), (0, 0, 1),
+                        "revolute" if i != 3 else "prismatic", (-2.0, 2.0) if i != 3 else (-0.1, 0.3)) for i in range(d)]  # fmt: skip
+    joints.append(JointSpec("tool", "tool", (0, 0, 0.1), (0, 0, 0), jtype="fixed"))
+    caps = [CapsuleSpec(f"l{i}", tuple(rng.uniform(-0.05, 0.05, 3)), tuple(rng.uniform(-0.1, 0.1, 3)), 0.02 + 0.01 * r)
+            for i in range(d) for r in range(3)]  # fmt: skip
+    pairs = [(a, b) for a in range(24) for b in range(a + 1, 24) if b // 3 - a // 3 >= 2][:128]
+    spec = RobotSpec("maxcaps", "24 capsules, 128 pairs", "base", joints, caps, collision_pairs=pairs)
+    ch = canonicalize(spec)
+    o64 = Oracle(ch, f32=False)
+    obs = [H.cuboid_obstacle(*rng.uniform(-0.4, 0.4, 3), *rng.uniform(0.05, 0.25, 3)) for _ in range(8)]
+    lo, hi = H.box_corners([c for c, _ in obs], [T for _, T in obs])
+    S, T = 3, 14
+    base = np.clip(rng.uniform(ch.lo, ch.hi, size=(1, d)) * 0.5 + np.cumsum(0.03 * rng.randn(T, d), axis=0), ch.lo, ch.hi)
+    x = H.f32(np.clip(base[None] + 0.01 * rng.randn(S, T, d), ch.lo, ch.hi).reshape(S * T, d))
+    target = H.f32(o64.fk(H.f32(base)))
+    kw = dict(ALT_LOSS_V2_1_DIFF.__dict__)
+    kw.update(n_virtual_configs=2)
+    pm = OptimizationParameters(**kw)
+    xv = H.f32(x + 0.01 * rng.randn(*x.shape))
+    pm.virtual_configs = dev(xv)
+    want, r = o64.lm_full_step(x, target, pm, S, T, virtual_configs=xv, boxes_lo=lo, boxes_hi=hi, return_residual=True)
+    n_fixed = (T - 1) * d + 4 * d
+    assert r.shape[0] > n_fixed + 20, "the case must carry many active collision rows"
+    step = np.abs(want - x).max()
+    for specialize in (False, True):
+        rb = Robot(spec, specialize=specialize)
+        rb.set_obstacles([c for c, _ in obs], [T_ for _, T_ in obs])
+        for sets in ({}, {"pcr_max_rows": 0}, {"pcr_max_rows": 0, "full_rows": 0}):
+            for k_, v_ in sets.items():
+                rb.debug_set(k_, v_)
+            got = host(rb.lm_full_step(dev(x), dev(target), pm, virtual_configs=pm.virtual_configs))
+            assert np.abs(got - want).max() < 2e-4 + 2e-3 * step, (specialize, sets, np.abs(got - want).max(), step)
