@@ -146,6 +146,15 @@ def test_offset_and_resample():
     out = offset_target_path(rb, path, "world", [1, 2, 3], Rz90)
     np.testing.assert_allclose(out[:, :3], path[:, :3] + [1, 2, 3])
     np.testing.assert_allclose(np.abs(out[0, 3:]), [math.sqrt(0.5), 0, 0, math.sqrt(0.5)], atol=1e-12)
+    # a non-identity waypoint orientation pins the ORDER: R_waypoint * R_offset (klampt's so3.mul(R_i, R_offset), data_type_utils.py:79-82)
+    from cppflow_amd.data_type_utils import _quat_to_matrix
+
+    c, s_ = math.cos(math.pi / 4), math.sin(math.pi / 4)
+    rx90 = np.array([[0.2, 0, 0, c, s_, 0, 0]])  # 90 deg about x
+    Rx90 = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=float)
+    got = _quat_to_matrix(offset_target_path(rb, rx90, "world", [0, 0, 0], Rz90)[0, 3:7])
+    np.testing.assert_allclose(got, Rx90 @ np.array(Rz90, dtype=float), atol=1e-12)
+    assert not np.allclose(got, np.array(Rz90, dtype=float) @ Rx90, atol=1e-3)
     r = resample_path(path, 7)
     assert r.shape == (7, 7)
     np.testing.assert_allclose(r[:, 0], np.linspace(0, 0.3, 7), atol=1e-12)
