@@ -107,15 +107,23 @@ constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
 
+// static LDS of a fused kernel: the gate's slots of its four wavefronts + the summary staging (an upper bound, scripts/kernel_resources.py)
+inline size_t fused_static_lds(const cppf_robot* rb) {
+    return (rb->desc.ndof >= 6 ? (size_t)(kBlock / 64) * (size_t)gate_lds_floats(rb->desc.ndof) * sizeof(float) : 0) + 1024;
+}
 // Dynamic LDS (bytes) a fused row-shape launch of n rows claims purely to bound how many of its workgroups share a compute unit
-// (CPPF_TUNE_SPREAD_KB; 0 = none): 12.5 KB static + 42 KB means two fit on a unit's 160 KB and a third does not.  Only launches
-// of at most 128 workgroups take it -- half a workgroup per compute unit, so the four launches the hardware keeps in flight
-// (profiles/r3_streams_sweep.txt) still all fit.  Measured on a 32 768-row shard, four launches in flight: 8.46 -> 7.8 us per
-// step (the dispatcher otherwise stacks the launches four deep on the units it tries first and leaves others idle); at 65 536
-// rows the same claim would hold two of the four launches back (10.1 -> 12.8 us), hence the bound.
+// (CPPF_TUNE_SPREAD_KB; 0 = none): static LDS (the conditioning gate's slots: 13 KB at 7 joints, 17 KB at 12) + the claim stays
+// under the 64 KB a workgroup may have without asking, and two such workgroups fit on a unit's 160 KB where a third does not.  Only
+// launches of at most 128 workgroups take it -- half a workgroup per compute unit, so the four launches the hardware keeps in
+// flight (profiles/r3_streams_sweep.txt) still all fit.  Measured on a 32 768-row shard, four launches in flight: 8.46 -> 7.1 ..
+// 7.8 us per step (the dispatcher otherwise stacks the launches four deep on the units it tries first and leaves others idle);
+// at 65 536 rows the same claim would hold two of the four launches back (10.1 -> 12.8 us), hence the bound.
 inline size_t fused_spread_lds(const cppf_robot* rb, size_t n) {
     const int kb = tune(rb, CPPF_TUNE_SPREAD_KB);
-    return (kb > 0 && n <= (size_t)128 * kBlock) ? (size_t)kb * 1024 : 0;
+    if (kb <= 0 || n > (size_t)128 * kBlock) return 0;
+    const size_t stat = fused_static_lds(rb);
+    const size_t room = stat + 512 < 65536 ? 65536 - 512 - stat : 0;
+    return std::min((size_t)kb * 1024, room);
 }
 }  // namespace
 
@@ -737,6 +745,10 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     // kernel put the right values in: found by the sentinel-arena test of tests/test_gpu_round3.py)
     const size_t lds_need = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
     const size_t lds = std::max(lds_need, fused_spread_lds(robot, n));
+    // the generic kernels stage 6 floats per capsule per lane: with the gate's slots beside them, 12 joints x 24 capsules no longer
+    // fit the 160 KB of a compute unit (the launch would take the process down) -- such a robot has to be specialised
+    if (coll && !use_rtc(robot) && lds_need + fused_static_lds(robot) > (size_t)160 * 1024)
+        return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: the generic kernels cannot stage this many capsules at this ndof; cppf_robot_specialize() the robot");
     if (use_rtc(robot)) {
         void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&outk};
         const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);

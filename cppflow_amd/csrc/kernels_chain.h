@@ -365,89 +365,118 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
 // besides its own row's state.  Everything stays inside one wavefront: no barrier, LDS accesses of a wavefront complete in
 // order.  On a planner's inputs 17 % of the wavefronts take the detour in the first iteration and <= 3 % later (bench.py's C4
 // workload, scripts/gate_census.py); independent random configurations (13 % of the rows flagged at first) are the worst case.
-constexpr int kGateSlots = 16;
+constexpr int kGateSlots = 8;
+// floats of LDS per wavefront (also what the host sizes the residency claim of small launches by, cppflow_hip.hip)
+constexpr int gate_lds_floats(int d) { return (6 * d + 6 + 2 * (21 + 6)) * kGateSlots; }
 template <int D>
 struct GateLds {
-    static constexpr int kFloats = (6 * D + 6) * kGateSlots;  // per wavefront: slot s, element i at [i * kGateSlots + s]
+    // per wavefront: slot s, float element i (J [6][D] at i * D + k, e at 6 D + i) at [i * kGateSlots + s]; behind them, as doubles,
+    // the 21 entries of the lower triangle of A and the 6 of y: double element m of slot s at [m * kGateSlots + s]
+    static constexpr int kJe = (6 * D + 6) * kGateSlots;
+    static constexpr int kFloats = gate_lds_floats(D);
 };
 
-// solve slot `s` (J [6][D] at elements i * D + k, e at 6 D + i) in double precision; delta [D] comes back in elements 0 .. D-1.
-// The wavefront that runs this is waiting for it (a round is pure latency for a launch of one wavefront per SIMD), so the code is
-// laid out for short dependency chains where registers allow: A is formed in a rolled loop over the joints with the next column
-// requested one trip ahead (21 independent accumulation chains; unrolled, the kernel spills 111 registers), J^T y is D independent
-// chains fully unrolled (A is dead by then), with a compiler barrier between the two passes over J (without it the 6 D
-// conversions of the first pass are kept alive across the factorisation: +84 VGPRs), and one Newton step on v_rsq_f64 (2^-26 ->
-// ~1e-15, ample next to the 6e-7 the step has to meet).
-template <int D>
-__device__ __forceinline__ void gate_solve_slot(float* __restrict__ w, int s, double lam_r, double lam_p) {
-    float* const ws = w + s;
-    double A[6][6];  // lower triangle; L overwrites it
-#pragma unroll
+// entry m (0 .. 20) of the lower triangle, row-major: (i, j), three bits each
+constexpr unsigned long long gate_tri_pack(bool rows) {
+    unsigned long long p = 0;
+    int m = 0;
     for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) A[i][j] = (i == j) ? (i < 3 ? lam_r : lam_p) : 0.0;
-    float nx[6];  // the next column of J, requested one trip ahead
-#pragma unroll
-    for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D) * kGateSlots];
+        for (int j = 0; j <= i; ++j, ++m) p |= (unsigned long long)(rows ? i : j) << (3 * m);
+    return p;
+}
+
+// The double-precision re-solve of up to kGateSlots rows of a wavefront, by the WHOLE wavefront (it is waiting for it anyway; in a
+// launch of one wavefront per SIMD a round is pure latency): (1) the 21 entries of A = J J^T + lambda S^-2 of every slot are one
+// task each -- 7 .. 12 FMAs -- spread over the 64 lanes (one lane per slot forming its own A was 21 D FMAs in a row, more than
+// half of the round); (2) lanes 0 .. cnt-1 factor and substitute, one slot each, A coming from LDS; (3) the D entries of
+// delta = J^T y of every slot are one task each again.  J is only ever read from LDS, by whoever needs an entry.
+// Everything stays inside one wavefront: no barrier, the LDS accesses of a wavefront complete in order (s_waitcnt lgkmcnt(0)
+// between the stages).
+template <int D>
+__device__ __forceinline__ void gate_solve_slots(float* __restrict__ w, int cnt, int lane, int nact, double lam_r, double lam_p) {
+    double* const wd = reinterpret_cast<double*>(w + GateLds<D>::kJe);
+    constexpr unsigned long long kRow = gate_tri_pack(true), kCol = gate_tri_pack(false);
+    // (1) A
+    // (the tasks go round the ACTIVE lanes: lanes 0 .. nact-1, a prefix of the wavefront -- the last wavefront of a launch may be
+    // partly empty)
+    const int n_a = cnt * 21;
 #pragma unroll 1
-    for (int k = 0; k < D; ++k) {  // rolled: unrolled, the 6 D loads and conversions of all trips are in flight at once
-        double c[6];
+    for (int base = 0; base < n_a; base += nact) {
+        const int tau = base + lane;
+        if (tau < n_a) {
+            const int s = (tau * 3121) >> 16;  // tau / 21 (exact for tau < 21 * kGateSlots)
+            const int m = tau - 21 * s;
+            const int i = (int)((kRow >> (3 * m)) & 7ull), j = (int)((kCol >> (3 * m)) & 7ull);
+            double a = i == j ? (i < 3 ? lam_r : lam_p) : 0.0;
+            const float* ji = w + (i * D) * kGateSlots + s;
+            const float* jj = w + (j * D) * kGateSlots + s;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c[i] = (double)nx[i];
-        const int kn = k + 1 < D ? k + 1 : k;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) nx[i] = ws[(i * D + kn) * kGateSlots];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j <= i; ++j) A[i][j] = __builtin_fma(c[i], c[j], A[i][j]);
-    }
-    asm volatile("" ::: "memory");  // (J is READ AGAIN below rather than kept)
-    double inv[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const double lam = j < 3 ? lam_r : lam_p;
-#pragma unroll
-        for (int i = j; i < 6; ++i) {
-            double t = A[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) t = __builtin_fma(-A[i][k], A[j][k], t);
-            if (i == j) {
-                t = t > lam ? t : lam;
-                double r = __builtin_amdgcn_rsq(t);
-                r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
-                inv[j] = r;
-            } else {
-                A[i][j] = t * inv[j];
-            }
+            for (int k = 0; k < D; ++k) a = __builtin_fma((double)ji[k * kGateSlots], (double)jj[k * kGateSlots], a);
+            wd[m * kGateSlots + s] = a;
         }
     }
-    double y[6];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (2) Cholesky with the damping as pivot floor, forward and back substitution: one lane per slot
+    if (lane < cnt) {
+        double A[6][6];  // lower triangle; L overwrites it
+        {
+            int m = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double t = (double)ws[(6 * D + i) * kGateSlots];
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int k = 0; k < i; ++k) t = __builtin_fma(-A[i][k], y[k], t);
-        y[i] = t * inv[i];
+                for (int j = 0; j <= i; ++j, ++m) A[i][j] = wd[m * kGateSlots + lane];
+        }
+        double inv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double lam = j < 3 ? lam_r : lam_p;
+#pragma unroll
+            for (int i = j; i < 6; ++i) {
+                double t = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) t = __builtin_fma(-A[i][k], A[j][k], t);
+                if (i == j) {
+                    t = t > lam ? t : lam;
+                    double r = __builtin_amdgcn_rsq(t);  // v_rsq_f64 (~2^-26) + one Newton step: ~1e-15
+                    r = __builtin_fma(r * 0.5, __builtin_fma(-t * r, r, 1.0), r);
+                    inv[j] = r;
+                } else {
+                    A[i][j] = t * inv[j];
+                }
+            }
+        }
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double t = (double)w[(6 * D + i) * kGateSlots + lane];
+#pragma unroll
+            for (int k = 0; k < i; ++k) t = __builtin_fma(-A[i][k], y[k], t);
+            y[i] = t * inv[i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            double t = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-A[k][i], y[k], t);
+            y[i] = t * inv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wd[(21 + i) * kGateSlots + lane] = y[i];
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (3) delta = J^T y; entry k of slot s goes to float element k of the slot (the task that overwrites J[0][k] is the only reader of it)
+    const int n_d = cnt * D;
+#pragma unroll 1
+    for (int base = 0; base < n_d; base += nact) {
+        const int tau = base + lane;
+        if (tau < n_d) {
+            const int s = tau / D, k = tau - D * s;
+            double t = 0.0;
 #pragma unroll
-    for (int i = 5; i >= 0; --i) {
-        double t = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-A[k][i], y[k], t);
-        y[i] = t * inv[i];
+            for (int i = 0; i < 6; ++i) t = __builtin_fma((double)w[(i * D + k) * kGateSlots + s], wd[(21 + i) * kGateSlots + s], t);
+            w[k * kGateSlots + s] = (float)t;
+        }
     }
-    asm volatile("" ::: "memory");
-    double t[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) t[k] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < D; ++k) t[k] = __builtin_fma((double)ws[(i * D + k) * kGateSlots], y[i], t[k]);
-    asm volatile("" ::: "memory");  // every read of this slot's J is done
-#pragma unroll
-    for (int k = 0; k < D; ++k) ws[k * kGateSlots] = (float)t[k];
 }
 
 // One round of the gate, in two halves.  `todo` = ballot of `flag`, non-zero; must be called by every active lane of the wavefront;
@@ -479,9 +508,9 @@ __device__ __forceinline__ void lm_gate_solve(double lam_r, double lam_p, unsign
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int cnt = min((int)__builtin_popcountll(todo), kGateSlots);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are written (one wavefront: its LDS accesses complete in order)
-    // The solvers are the first `cnt` lanes that entered this call (a prefix of the wavefront's active lanes, whose rows are
-    // consecutive), not necessarily flagged themselves.
-    if (lane < cnt) gate_solve_slot<D>(w, lane, lam_r, lam_p);
+    // Every lane of the wavefront works on the slots (gate_solve_slots), flagged itself or not.
+    const int nact = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+    gate_solve_slots<D>(w, cnt, lane, nact, lam_r, lam_p);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (flag && rank < kGateSlots) {
 #pragma unroll

@@ -360,7 +360,7 @@ class Robot:
         the kernel shape (`_hip.SHAPE_ROW`: one row per lane; `_hip.SHAPE_QUAD`: four lanes per row; default: by batch size);
         `solver` the precision of the damped solve: `_hip.SOLVER_AUTO` (default: the reference's dtype with the conditioning gate --
         rows whose fp32 solve is estimated to be off by more than 1e-5 in task space redo it in double precision),
-        `_hip.SOLVER_F64` (every row in double precision, ~1.9x the iteration time) or `_hip.SOLVER_F32` (no gate)."""
+        `_hip.SOLVER_F64` (every row in double precision: a verification mode, ~10x the iteration time) or `_hip.SOLVER_F32` (no gate)."""
         x = self._x2d(x)
         target = _require_device_tensor(target, "target_path")
         n, W = x.shape[0], target.shape[0]

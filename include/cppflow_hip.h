@@ -94,7 +94,8 @@ typedef struct cppf_lm_params {
      *     precision.  The step is then never farther from the exactly solved one than the reference's own fp32 arithmetic
      *     (torch.linalg.solve on the primal system, cppflow/optimization.py:85-88) gets -- near-singular rows included.
      *   CPPF_SOLVER_F64: every row in double precision (J J^T, its factorisation, the substitutions and J^T y): the exactly
-     *     solved step of the fp32 Jacobian on every row (task-space difference to the fp64 oracle <= 6e-7); ~1.9x the iteration.
+     *     solved step of the fp32 Jacobian on every row (task-space difference to the fp64 oracle <= 6e-7).  A verification mode: every
+     *     wavefront runs eight re-solve rounds per iteration (~10x the iteration time).
      *   CPPF_SOLVER_F32: fp32 only, no gate (the round-2 behaviour; up to 6e-2 off in task space on near-singular rows). */
     int32_t solver;
     /* Tolerance of CPPF_SOLVER_AUTO's gate in the scaled task-space units of the residual (rad * alpha_rotation, m *
@@ -150,7 +151,9 @@ int cppf_robot_specialization(const cppf_robot* robot);
  * collision and quad kernels are compiled for THIS robot with hipRTC -- chain constants become literals, capsule end points
  * stay in registers, exactly as for the shipped robots -- and cached on disk under `cache_dir` (NULL: $CPPF_CACHE_DIR, else
  * $HOME/.cache/cppflow_amd) keyed by a hash of the description and of the kernel sources, so that later processes load the code
- * object without compiling.  Results are bit-identical to the generic kernels.  After success cppf_robot_specialization()
+ * object without compiling.  Results are bit-identical to the generic kernels.  (The generic fused kernel stages capsule end
+ * points in LDS, 6 KB per capsule: at 12 joints x 24 capsules that no longer fits a compute unit and the fused launch with
+ * collision outputs returns CPPF_ERR_UNSUPPORTED -- such a robot must be specialised.)  After success cppf_robot_specialization()
  * returns CPPF_SPECIALIZATION_RTC.  Stands in for jrl.robots.get_robot returning a robot class with baked-in kinematics
  * (cppflow/data_type_utils.py:197).  A no-op (CPPF_OK) for a handle that already runs a generated table. */
 #define CPPF_SPECIALIZATION_RTC 1000

@@ -933,6 +933,41 @@ def test_robot_at_the_capsule_and_pair_maxima(specialize):
         assert np.array_equal(r[k].cpu().numpy().astype(w1[k].dtype), w1[k]), ("fused", k)
 
 
+def test_generic_kernels_refuse_what_they_cannot_stage():
+    """12 joints x 24 capsules: the generic fused kernels would need 144 KB of capsule staging beside the conditioning gate's slots --
+    more than a compute unit's 160 KB of LDS.  The launch must be refused with a message (it used to take the process down), and
+    the same robot specialised at run time runs and meets the oracle."""
+    from cppflow_amd import _hip
+    from cppflow_amd.robot_model import CapsuleSpec, JointSpec, RobotSpec, canonicalize
+    from cppflow_amd.robots import Robot
+    from oracle.oracle import Oracle
+
+    rng = np.random.RandomState(5)
+    d = 12
+    joints = [JointSpec(f"j{i}", f"l{i}", tuple(rng.uniform(-0.1, 0.2, 3)), tuple(rng.uniform(-1, 1, 3)), (0, 0, 1), "revolute", (-2.0, 2.0))
+              for i in range(d)]  # fmt: skip
+    joints.append(JointSpec("tool", "tool", (0, 0, 0.1), (0, 0, 0), jtype="fixed"))
+    caps = [CapsuleSpec(f"l{i}", tuple(rng.uniform(-0.05, 0.05, 3)), tuple(rng.uniform(-0.1, 0.1, 3)), 0.03) for i in range(d) for _ in range(2)]
+    pairs = [(a, b) for a in range(24) for b in range(a + 1, 24) if b // 2 - a // 2 >= 2][:128]
+    spec = RobotSpec("wide", "12 joints, 24 capsules", "base", joints, caps, collision_pairs=pairs)
+    ch = canonicalize(spec)
+    o32 = Oracle(ch, f32=True)
+    q = H.f32(rng.uniform(ch.lo, ch.hi, size=(300, d)))
+    tg = dev(Oracle(ch, f32=False).fk(q[:100]))
+    rb = Robot(spec, specialize=False)
+    with pytest.raises(RuntimeError, match="specialize"):
+        rb.lm_pose_steps(dev(q), tg, n_steps=2, want_errors=True, want_collisions=True, shape=_hip.SHAPE_ROW, **LM)
+    r0 = rb.lm_pose_steps(dev(q), tg, n_steps=2, want_errors=True, want_collisions=False, shape=_hip.SHAPE_ROW, **LM)  # nothing staged
+    rs = Robot(spec, specialize=True)
+    rs.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    r = rs.lm_pose_steps(dev(q), tg, n_steps=2, want_errors=True, want_collisions=True, shape=_hip.SHAPE_ROW, **LM)
+    assert torch.equal(r["x"], r0["x"])
+    jl_lo, jl_hi = rs.padded_joint_limits()
+    want = o32.masks(host(r["x"]), None, None, jl_lo, jl_hi)
+    for k in ("self_mask", "jlim_mask", "ext_cost"):
+        assert np.array_equal(r[k].cpu().numpy().astype(want[k].dtype), want[k]), k
+
+
 def test_coupled_step_at_the_capsule_pair_and_obstacle_maxima():
     """24 capsules, 128 pairs and 8 cuboids at once: the screening bit sets of the coupled step's block kernel wrap (more candidates
     than bits), which may cost work but never a collision row -- the step equals the oracle's dense restatement."""
