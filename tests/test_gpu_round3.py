@@ -132,6 +132,35 @@ def test_gate_flags_what_it_should_and_every_mode_lands_where_it_says(name):
         step(_hip.SOLVER_AUTO, -1.0)
 
 
+@pytest.mark.parametrize("name", ["panda", "fetch_arm"])
+def test_a_row_does_not_depend_on_which_rows_share_its_wavefront(name):
+    """The conditioning gate's double-precision re-solve is done by the whole wavefront (tasks dealt to the ACTIVE lanes, one slot per
+    flagged row, further rounds when more rows are flagged than there are slots): a row's result must not depend on how many lanes
+    are active, on which slot it got or on how many rounds its wavefront took.  K = 3 clamped steps on random rows (about a tenth of
+    them near-singular), the same rows launched as 4096, as every prefix length that leaves a partly empty last wavefront, and in
+    reverse order: bit for bit the same per row, in the default (gated) mode and with every row in double precision."""
+    from cppflow_amd import _hip
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot(name)
+    x0, target = H.lm_problem(name, 64, 64, seed=5)
+    tg = np.tile(target, (64, 1))  # one target per row: the launch is one "seed" of n waypoints
+    for solver in (_hip.SOLVER_AUTO, _hip.SOLVER_F64):
+        full = rb.lm_pose_steps(dev(x0), dev(tg), n_steps=3, want_errors=True, shape=_hip.SHAPE_ROW, solver=solver, **LM)
+        xf, pf = full["x"].cpu(), full["pos_err_m"].cpu()
+        flagged = (rb.lm_pose_steps(dev(x0), dev(tg), n_steps=3, shape=_hip.SHAPE_ROW, solver=_hip.SOLVER_F32, **LM)["x"].cpu() != xf).any(dim=1)
+        assert flagged.float().mean() > 0.01, (name, solver, flagged.float().mean())  # the gate is at work on these rows
+        for n in (1, 2, 9, 63, 65, 127, 200, 1000, 4059, 4095):
+            r = rb.lm_pose_steps(dev(x0[:n]), dev(tg[:n]), n_steps=3, want_errors=True, shape=_hip.SHAPE_ROW, solver=solver, **LM)
+            assert torch.equal(r["x"].cpu(), xf[:n]) and torch.equal(r["pos_err_m"].cpu(), pf[:n]), (name, solver, n)
+        rev = rb.lm_pose_steps(dev(x0[::-1].copy()), dev(tg[::-1].copy()), n_steps=3, shape=_hip.SHAPE_ROW, solver=solver, **LM)
+        assert torch.equal(rev["x"].cpu().flip(0), xf), (name, solver, "reversed")
+        # and a permutation that scatters the flagged rows over other wavefronts
+        perm = np.random.RandomState(1).permutation(x0.shape[0])
+        pr = rb.lm_pose_steps(dev(x0[perm]), dev(tg[perm]), n_steps=3, shape=_hip.SHAPE_ROW, solver=solver, **LM)
+        assert torch.equal(pr["x"].cpu(), xf[torch.as_tensor(perm)]), (name, solver, "permuted")
+
+
 def _coupled_case(name, S, T, seed):
     """S trajectories tracking one smooth path that passes through a colliding configuration (so that collision rows are active
     in the block system), perturbed per seed like the seeds of one planning problem."""
