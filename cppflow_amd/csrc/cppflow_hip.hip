@@ -31,6 +31,14 @@
 
 using namespace cppf;
 
+namespace cppf {
+// fused_static.hip: lm_fused_kernel<StaRobot<table static_id>, coll> -- the row-shape fused kernel of the shipped robots lives in
+// its own translation unit (another machine scheduler, see there)
+bool launch_fused_static(int static_id, int coll, unsigned grid, size_t lds, hipStream_t st, const ChainK& ch, const CollK& co,
+                         const LmK& prm, const float* x_in, const float* target, const cppf_lm_outputs& out);
+int fused_static_block();
+}  // namespace cppf
+
 namespace {
 
 #ifndef CPPF_BLOCK
@@ -46,7 +54,8 @@ constexpr int kBlock = CPPF_BLOCK;
 #define CPPF_WAVES_COLL 2
 #endif
 
-// the device code, by topic (one translation unit; everything below lives in this anonymous namespace)
+// the device code, by topic (everything below lives in this anonymous namespace; the row-shape fused kernel of the shipped
+// robots is instantiated in fused_static.hip instead)
 #include "kernels_chain.h"
 #include "kernels_collision.h"
 #include "kernels_fused.h"
@@ -228,6 +237,22 @@ int find_static_robot(const cppf_robot_desc& d) {
             case 12: { using RB = DynRobot<12>; CPPF_BODY; } break;                                                   \
             default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in 3..12");     \
         }                                                                                                             \
+    }
+
+// the generic instantiations only (the caller has dealt with the generated tables)
+#define CPPF_DISPATCH_DYN(robot)                                                                                      \
+    switch ((robot)->desc.ndof) {                                                                                     \
+        case 3: { using RB = DynRobot<3>; CPPF_BODY; } break;                                                         \
+        case 4: { using RB = DynRobot<4>; CPPF_BODY; } break;                                                         \
+        case 5: { using RB = DynRobot<5>; CPPF_BODY; } break;                                                         \
+        case 6: { using RB = DynRobot<6>; CPPF_BODY; } break;                                                         \
+        case 7: { using RB = DynRobot<7>; CPPF_BODY; } break;                                                         \
+        case 8: { using RB = DynRobot<8>; CPPF_BODY; } break;                                                         \
+        case 9: { using RB = DynRobot<9>; CPPF_BODY; } break;                                                         \
+        case 10: { using RB = DynRobot<10>; CPPF_BODY; } break;                                                       \
+        case 11: { using RB = DynRobot<11>; CPPF_BODY; } break;                                                       \
+        case 12: { using RB = DynRobot<12>; CPPF_BODY; } break;                                                       \
+        default: return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: kernels are built for ndof in 3..12");         \
     }
 
 constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP call), for cppf_debug_rtc_compile
@@ -412,6 +437,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     }
     rb->lds_bytes = (size_t)co.ncaps * 6 * kBlock * sizeof(float);
     rb->static_id = find_static_robot(*desc);
+    if (fused_static_block() != kBlock) rb->static_id = -1;  // (the two translation units were built for different workgroup sizes)
     rb->rtc = nullptr;
     rb->d_quad = nullptr;
     // device tables of the quad shape (static per robot: pair list, thresholds)
@@ -753,23 +779,29 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
         void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&outk};
         const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
         if (int rc = rtc_launch(robot, which, grid_for(n), fused_spread_lds(robot, n), st, args)) return rc;
+    } else if (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) {
+        // a generated table: the kernel lives in fused_static.hip
+        const int c = !coll ? 0 : ((out->min_self || out->min_env) ? 2 : 1);
+        if (!launch_fused_static(robot->static_id, c, grid_for(n), fused_spread_lds(robot, n), st, robot->chain, robot->coll, prm, x_in,
+                                 target, outk))
+            return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: no fused kernel for this generated table");
     } else if (coll && (out->min_self || out->min_env)) {
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
                        prm, x_in, target, outk)
-        CPPF_DISPATCH_RB(robot)
+        CPPF_DISPATCH_DYN(robot)
 #undef CPPF_BODY
     } else if (coll) {
 #define CPPF_BODY                                                                                                 \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
                        prm, x_in, target, outk)
-        CPPF_DISPATCH_RB(robot)
+        CPPF_DISPATCH_DYN(robot)
 #undef CPPF_BODY
     } else {
 #define CPPF_BODY                                                                                               \
     hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), fused_spread_lds(robot, n), st, robot->chain, robot->coll, \
                        prm, x_in, target, outk)
-        CPPF_DISPATCH_RB(robot)
+        CPPF_DISPATCH_DYN(robot)
 #undef CPPF_BODY
     }
     if (int rc = check_launch(robot)) return rc;

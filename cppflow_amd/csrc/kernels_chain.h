@@ -1,5 +1,5 @@
 // kernels_chain.h -- per-row chain evaluation: FK with joint axes, pose error, geometric Jacobian, the damped solve, the clamp.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Included inside the anonymous namespace of cppflow_hip.hip and of fused_static.hip (and handed to hipRTC); gfx950 only.
 #pragma once
 
 // ---- per-row chain evaluation ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // kernels_collision.h -- collision stage of one row: capsule FK (registers or LDS), wave-uniform broad phase, exact pair / cuboid tests.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Included inside the anonymous namespace of cppflow_hip.hip and of fused_static.hip (and handed to hipRTC); gfx950 only.
 #pragma once
 
 // ---- collision stage --------------------------------------------------------------------------------------------------------

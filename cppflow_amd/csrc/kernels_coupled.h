@@ -1,5 +1,5 @@
 // kernels_coupled.h -- the coupled LM step: waypoint-local blocks, distance Jacobians, the eliminations of the block-tridiagonal system.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Part of the translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
 #pragma once
 
 // ---- coupled ("full") LM step: cppflow/optimization.py:95-144 + LmResidualFns.get_r_and_J (optimization_utils.py:486-731) -------

@@ -1,5 +1,5 @@
 // kernels_dp.h -- dp_search: time-major transpose, one (min,max) product per waypoint, back-trace; the mjac tensor.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Part of the translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
 #pragma once
 
 // ---- dp_search (cppflow/search.py:100-191) -----------------------------------------------------------------------------------

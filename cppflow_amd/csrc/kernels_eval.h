@@ -1,5 +1,5 @@
 // kernels_eval.h -- per-path reductions: Plan metrics and the per-seed summary of a fused launch's outputs.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Part of the translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
 #pragma once
 
 // ---- Plan metrics for every seed at once (cppflow/data_types.py:140-264) ------------------------------------------------------

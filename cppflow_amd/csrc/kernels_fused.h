@@ -1,5 +1,5 @@
 // kernels_fused.h -- the fused launch and the single-purpose row kernels (FK, Jacobian, pose errors / metrics, clamp, distances, seed validity).
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Included inside the anonymous namespace of cppflow_hip.hip and of fused_static.hip (and handed to hipRTC); gfx950 only.
 #pragma once
 
 // ---- kernels ----------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 // kernels_quad.h -- the latency shape of the fused launch: FOUR lanes cooperate on one (seed, waypoint) row.
-// Part of the one translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
+// Part of the translation unit cppflow_hip.hip (included inside its anonymous namespace); gfx950 only.
 //
 // Why.  lm_fused_kernel (one row per lane) is the throughput shape: it needs >= 4 wavefronts per SIMD (262 144 rows) to reach
 // the VALU issue ceiling.  A strong-scaling shard (32 768 rows = half a wavefront per SIMD), BASELINE config C2 (8 192 rows)

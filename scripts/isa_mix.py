@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from kernel_resources import LLVM, extract_code_object  # noqa: E402
+from kernel_resources import LLVM, extract_code_objects  # noqa: E402
 
 
 def classify(op):
@@ -93,22 +93,21 @@ def main():
     flt = sys.argv[1]
     here = os.path.dirname(os.path.abspath(__file__))
     lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(here, "..", "cppflow_amd", "csrc", "libcppflow_hip.so")
-    co = "/tmp/cppflow_gfx950.co"
-    extract_code_object(lib, co)
-    syms = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "--wide", co], capture_output=True, text=True, check=True).stdout
-    names = sorted({ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln})
-    for mangled in names:
-        dn = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
-        if flt not in dn:
-            continue
-        lines = disassemble(co, mangled)
-        loop, whole = analyse(lines)
-        print(dn[:160])
-        for title, st in (("  hottest loop", loop), ("  whole kernel", whole)):
-            if st:
-                print(f"{title}: {st['n']} instructions: VALU {st['valu']} (DPP {st['dpp']}, FMA {st['fma']}, mul/add {st['muladd']}, "
-                      f"trans {st['trans']}), MFMA {st['mfma']}, SALU {st['salu']}, LDS {st['lds']}, VMEM {st['vmem']}; "
-                      f"flops per VALU lane-op {st['flops_per_valu_lane_op']:.3f}")
+    for co in extract_code_objects(lib, "/tmp/cppflow_gfx950.co"):  # one code object per translation unit
+        syms = subprocess.run([f"{LLVM}/llvm-readelf", "-s", "--wide", co], capture_output=True, text=True, check=True).stdout
+        names = sorted({ln.split()[-1] for ln in syms.splitlines() if " FUNC " in ln})
+        for mangled in names:
+            dn = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
+            if flt not in dn:
+                continue
+            lines = disassemble(co, mangled)
+            loop, whole = analyse(lines)
+            print(dn[:160])
+            for title, st in (("  hottest loop", loop), ("  whole kernel", whole)):
+                if st:
+                    print(f"{title}: {st['n']} instructions: VALU {st['valu']} (DPP {st['dpp']}, FMA {st['fma']}, mul/add {st['muladd']}, "
+                          f"trans {st['trans']}), MFMA {st['mfma']}, SALU {st['salu']}, LDS {st['lds']}, VMEM {st['vmem']}; "
+                          f"flops per VALU lane-op {st['flops_per_valu_lane_op']:.3f}")
 
 
 if __name__ == "__main__":

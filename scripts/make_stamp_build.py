@@ -78,7 +78,8 @@ if args.prio != "none":
         f"        const int age_rank = (int)(blockIdx.x >> 8);\n        for (int it = 0; it < prm.n_steps; ++it) {{\n            rotate_prio(age_rank + {key});\n            const bool conv = lm_row_iterate")
 open(p, "w").write(s)
 os.makedirs(os.path.dirname(args.out), exist_ok=True)
-cmd = ["hipcc"] + build.HIPCC_FLAGS + ['-DCPPF_BUILD_ID="stamp"', "-o", args.out, os.path.join(tree, "cppflow_amd", "csrc", "cppflow_hip.hip")]
+# (one hipcc call over both translation units; the diagnostic build does not need fused_static.hip's own scheduler flags)
+cmd = ["hipcc"] + build.HIPCC_FLAGS + ["-shared", '-DCPPF_BUILD_ID="stamp"', "-o", args.out] + [os.path.join(tree, "cppflow_amd", "csrc", f) for f in build.SOURCES]
 print(" ".join(cmd))
 subprocess.check_call(cmd)
 shutil.rmtree(tree)
