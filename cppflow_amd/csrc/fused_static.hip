@@ -1,11 +1,14 @@
 // fused_static.hip -- the row-shape fused kernel (lm_fused_kernel, kernels_fused.h) of the SHIPPED robots, as its own translation
 // unit of libcppflow_hip.so (gfx950 only) because it is compiled with another machine scheduler than the rest of the library:
-//     -mllvm -amdgpu-sched-strategy=max-ilp
+//     -O2 -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0
 // The default strategy orders a kernel for the smallest register footprint first; on this kernel that leaves dependent
 // instructions back to back where independent ones were available.  Scheduled for instruction-level parallelism the same code
 // (same instructions, same results bit for bit: -ffp-contract=off, every FMA explicit) takes 124 instead of 118 VGPRs -- still
 // four wavefronts per SIMD -- and the headline workload steps in 37.5 instead of 38.6 us, Fetch's in 18.7 instead of 19.4, a
-// 32 768-row shard in 6.85 instead of 7.0 (profiles/README.md).  Library-wide the same switch costs registers where they matter
+// 32 768-row shard in 6.85 instead of 7.0 (profiles/README.md).  The post-register-allocation scheduler then moves instructions
+// again, for latencies that four resident wavefronts hide anyway: without it the full-size launch gains another 1 % (36.9 -> 36.5
+// us per step; with the DEFAULT pre-RA strategy and no post-RA pass it is as fast, 36.3, but the shard-sized launch falls back to
+// 7.2 us); -O2 instead of -O3 measured 0.5 % better again on this unit.  Library-wide the ILP switch costs registers where they matter
 // (the coupled step's block kernel 117 -> 167 VGPRs, scratch in three generic instantiations, the collision kernel one occupancy
 // step), hence one translation unit for the kernel that gains.  cppflow_hip.hip calls launch_fused_static() for a handle whose
 // description equals a generated table; everything else (generic and run-time-specialised kernels, every other stage) stays there.

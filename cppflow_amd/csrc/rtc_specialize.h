@@ -39,7 +39,7 @@ const char* const kRtcNameExpr[RTC_COUNT] = {
 // (the machine scheduler of fused_static.hip: the fused kernel gains 2.4 %, the quad kernels 1.5 %, the collision kernel loses 1 %)
 const char* const kRtcOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wno-comment",
-                                   "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+                                   "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-enable-post-misched=0"};
 constexpr int kRtcOptionCount = (int)(sizeof(kRtcOptions) / sizeof(kRtcOptions[0]));
 
 struct RtcModule {
