@@ -200,3 +200,32 @@ def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib):
 
     assert lib.cppf_build_id().decode() == build.source_hash() == build.built_id()
     assert not build.needs_build()
+
+
+def test_build_id_covers_every_translation_unit_and_its_flags(monkeypatch):
+    """The library is linked from two translation units (csrc/fused_static.hip holds the headline kernel under other scheduler
+    flags): the build id must change when either source, a shared header or the flags of ONE unit change -- otherwise records keyed
+    by the build id (profiles/r3_issue.json, bench.py's roofline) could outlive the code they were taken from."""
+    import os
+
+    from cppflow_amd import build
+
+    assert set(build.SOURCES) == {"cppflow_hip.hip", "fused_static.hip"}
+    for src in build.SOURCES:
+        assert os.path.exists(os.path.join(build.CSRC, src))
+    assert "-amdgpu-sched-strategy=max-ilp" in build.EXTRA_FLAGS["fused_static.hip"]
+    base = build.source_hash()
+    monkeypatch.setitem(build.EXTRA_FLAGS, "fused_static.hip", build.EXTRA_FLAGS["fused_static.hip"] + ["-O1"])
+    assert build.source_hash() != base
+    monkeypatch.undo()
+    assert build.source_hash() == base
+    # the code object of EACH unit is found by the resource tool (the headline kernel lives in the second one)
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(build.CSRC), "..", "scripts", "kernel_resources.py"), "",
+                          "lm_fused_kernel<cppf::StaRobot<cppf::gen::Panda>, 1>"], capture_output=True, text=True, check=True).stdout  # fmt: skip
+    line = [ln for ln in out.splitlines() if "lm_fused_kernel" in ln]
+    assert len(line) == 1, out
+    vgpr, scratch = int(line[0].split()[1]), int(line[0].split()[7])
+    assert vgpr <= 128 and scratch == 0, line[0]  # four wavefronts per SIMD, nothing spilled
