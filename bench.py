@@ -30,8 +30,18 @@ the worst case for the wave-uniform collision broad phase; at N = 1 that figure 
 `random_inputs`, and the one-stream figure as `one_stream`.
 
 Timing: `--prewarm-ms` (60) of untimed launches bring the GPU to its sustained clocks, then W untimed warm-up steps, then
-exactly K steps between barrier + synchronize pairs; the maximum over ranks is reported.  Consecutive steps are independent
-batches (a ring of output-buffer sets) alternating between `--streams` HIP streams.
+exactly K steps: barrier + synchronize, clock, the K steps (+ the exchange of a partly filled bucket), this rank's synchronize,
+clock; the maximum over ranks is reported.  The group's CLOSING barrier comes after the clock has stopped (its cost is recorded in
+config.timed_region.closing_barrier_us): at the driver's `--steps 20` a sharded region is ~100 us long, and an 8-rank barrier
+inside it would be most of what is timed.  Consecutive steps are independent batches (a ring of output-buffer sets) alternating
+between `--streams` HIP streams.
+
+Steps per launch (`--batch`, cppf_lm_batch_*).  A launch of the fused kernel carries B consecutive steps -- B independent problems
+laid end to end in one grid, each with its own outputs, bit for bit what B separate launches produce.  B = how many of this rank's
+steps make one full-width launch (262 144 rows, four wavefronts per SIMD), at most 16: ONE at N = 1 (the 1024-seed step IS a
+full-width launch; it goes through the same batch entry point), 2 / 4 / 8 for the 131 072 / 65 536 / 32 768-row shards of N = 2 / 4 /
+8 -- so every GPU issues launches of the same width at every N instead of small launches whose only overlap is the four hardware
+queues.  A timed region of K steps is floor(K / B) full launches and one launch of the K mod B steps left over.
 
 Prints ONE JSON line (rank 0).
 """
@@ -98,7 +108,7 @@ def workload_key(robot, S, W, K, collide, inputs="problem"):
     return f"{robot}_S{S}_W{W}_K{K}_coll{int(collide)}" + ("" if inputs == "problem" else f"_{inputs}")
 
 
-PROFILE_ROUND = "r3"  # the committed record pass these lookups read (scripts/record_pass.sh -> profiles/r3_*)
+PROFILE_ROUND = "r4"  # the committed record pass these lookups read (scripts/record_pass.sh -> profiles/r4_*)
 
 
 def traffic_from_profiles(robot, S, W, K, collide, build_id):
@@ -350,6 +360,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather-every", type=int, default=0,
                     help="N > 1: steps per all-gather of the per-seed summaries (the summaries of G steps travel in one collective); "
                     "0 = 8, 32 for shards of <= 65 536 rows, 64 for <= 32 768: a collective's latency is paid once per G steps")  # fmt: skip
+    ap.add_argument("--batch", type=int, default=0,
+                    help="steps per launch (cppf_lm_batch_*: B independent problems in one grid); 0 = as many of this rank's steps as "
+                    "make one full-width launch of 262 144 rows, at most 16 (1 at N = 1 / C4)")  # fmt: skip
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the independent steps alternate between (0 = 2, or 4 for strong-scaling shards that cannot "
                     "fill the chip with two launches in flight)")  # fmt: skip
@@ -579,16 +592,20 @@ class NoGather:
 
 class Runner:
     """One workload (a batch of S seeds x W waypoints on this rank) and the machinery that steps it: a ring of output-buffer
-    sets and `n_streams` launch streams.
+    sets, `n_streams` launch streams, and launches of B consecutive steps each (cppf_lm_batch_*: B independent problems in one grid;
+    B = 1 is one step per launch through the same entry point).
 
-    Without a transport (N = 1) consecutive steps alternate between the streams.  With one, the ring is `n_streams` BUCKETS of G
-    steps; a bucket's launches all go to ONE stream and its exchange step -- the all-gather of the G [S,8] summaries and the seed
-    selection over every rank's seeds -- is enqueued on that same stream right behind them, so producer -> collective -> consumer
-    -> reuse of the bucket's buffers are ordered by the stream itself.  No cross-stream event anywhere: measured on a 32 768-row
-    shard, making an auxiliary stream wait on events of four launch streams cost 22.5 us per step against 7.2 us without the
-    waits (the kernels stopped overlapping), while buckets on their own streams keep the full overlap, `n_streams` buckets deep."""
+    A LAUNCH GROUP is B consecutive ring slots; a launch always starts at a group's first slot and carries 1 .. B of its steps (the
+    K mod B steps left over at the end of a region go out as one shorter launch, after which the ring moves on to the next group).
+    Without a transport (N = 1) consecutive groups alternate between the streams.  With one, the ring is `n_streams` BUCKETS of G
+    steps (G a multiple of B); a bucket's launches all go to ONE stream and its exchange step -- the all-gather of the G [S,8]
+    summaries and the seed selection over every rank's seeds -- is enqueued on that same stream right behind them, so producer ->
+    collective -> consumer -> reuse of the bucket's buffers are ordered by the stream itself.  No cross-stream event anywhere:
+    measured on a 32 768-row shard, making an auxiliary stream wait on events of four launch streams cost 22.5 us per step against
+    7.2 us without the waits (the kernels stopped overlapping), while buckets on their own streams keep the full overlap."""
 
-    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0, graphs=False):
+    def __init__(self, robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver=0, graphs=False, batch=1):
+        from cppflow_amd import _hip
         from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
 
         self.robot, self.x0, self.target, self.K, self.collide, self.device = robot, x0, target, K, collide, device
@@ -597,26 +614,46 @@ class Runner:
         self.transport = transport if collide else None
         self.n_streams = max(1, n_streams)
         self.use_graphs = bool(graphs)
-        # bucket mode: a ring of `n_streams` buckets of G consecutive steps, one stream per bucket
+        self.B = B = max(1, min(int(batch), _hip.MAX_BATCH))
+        # the batch entry point is the row shape; an explicit --shape quad keeps the plain per-step launches (B = 1)
+        self.use_batch_api = shape != _hip.SHAPE_QUAD
+        if not self.use_batch_api:
+            self.B = B = 1
+        # bucket mode: a ring of `n_streams` buckets of G consecutive steps (G a multiple of B), one stream per bucket
         self.buckets = self.transport is not None or self.use_graphs
-        self.G = G = max(1, G) if self.buckets else 1
-        self.NBUF = NBUF = self.n_streams * G if self.buckets else max(4, self.n_streams)
+        self.G = G = (max(B, (max(1, G) // B) * B) if self.buckets else B)
+        self.NBUF = NBUF = self.n_streams * G if self.buckets else max(4, self.n_streams) * B
         prm = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_LOSS_V2_1_POSE
         self.prm = prm
         self.x_outs = [torch.empty_like(x0) for _ in range(NBUF)]
         self.packeds = [torch.empty(robot.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=device) if collide else None
                         for _ in range(NBUF)]  # fmt: skip
         self.summ_all = torch.empty((NBUF, self.S, 8), dtype=torch.float32, device=device) if collide else None
+        self.errs = None if collide else [(torch.empty(n, device=device), torch.empty(n, device=device)) for _ in range(NBUF)]
         self.shape, self.solver = shape, solver
-        if collide:
-            self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, packed_out=pk, summary_out=self.summ_all[b],
-                                               shape=shape, solver=solver, **prm)
-                          for b, (xo, pk) in enumerate(zip(self.x_outs, self.packeds))]  # fmt: skip
-        else:  # FK + Jacobian + LM only (BASELINE configs[1]): the result and its pose errors, no collision stage
-            self.errs = [(torch.empty(n, device=device), torch.empty(n, device=device)) for _ in range(NBUF)]
-            self.plans = [robot.lm_launch_plan(x0, target, n_steps=K, x_out=xo, errors_out=er, shape=shape, solver=solver, **prm)
-                          for xo, er in zip(self.x_outs, self.errs)]
-        self.outputs = self.plans[0].outputs
+
+        def item(b):
+            it = dict(x=x0, target=target, x_out=self.x_outs[b])
+            if collide:
+                it.update(packed_out=self.packeds[b], summary_out=self.summ_all[b])
+            else:  # FK + Jacobian + LM only (BASELINE configs[1]): the result and its pose errors, no collision stage
+                it.update(errors_out=self.errs[b])
+            return it
+
+        # launches[g][c - 1]: the launch of the first c steps of group g (c = B: the group; c < B: what is left at the end of a region)
+        self.launches = []
+        for g in range(NBUF // B):
+            if self.use_batch_api:
+                self.launches.append([robot.lm_batch_plan([item(g * B + j) for j in range(c)], n_steps=K, solver=solver, **prm)
+                                      for c in range(1, B + 1)])
+            elif collide:
+                self.launches.append([robot.lm_launch_plan(x0, target, n_steps=K, x_out=self.x_outs[g], packed_out=self.packeds[g],
+                                                           summary_out=self.summ_all[g], shape=shape, solver=solver, **prm)])
+            else:
+                self.launches.append([robot.lm_launch_plan(x0, target, n_steps=K, x_out=self.x_outs[g], errors_out=self.errs[g],
+                                                           shape=shape, solver=solver, **prm)])
+        first = self.launches[0][0].outputs
+        self.outputs = first[0] if isinstance(first, list) else first  # ring slot 0's output views
         if self.transport is not None:
             self.gathered = [torch.empty((world, G, self.S, 8), dtype=torch.float32, device=device) for _ in range(self.n_streams)]
             self.selected = [torch.empty((G, 4), dtype=torch.int32, device=device) for _ in range(self.n_streams)]
@@ -626,59 +663,57 @@ class Runner:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(device))
-        self.step_no = 0
+        self.step_no = 0  # always a multiple of B: the ring position of the next launch
         self.graphs = None
         if self.use_graphs:
-            # One hipGraph per bucket = its G launches in stream order, captured on the bucket's own stream (every launch once
+            # One hipGraph per bucket = its G / B launches in stream order, captured on the bucket's own stream (every launch once
             # eagerly first: nothing lazy may happen inside a capture).  A replay costs the host one call per G steps.
-            for b in range(NBUF):
-                self.plans[b].launch_on(self.streams[b // G])
+            for g in range(NBUF // B):
+                self.launches[g][B - 1].launch_on(self.streams[(g * B) // G])
             torch.cuda.synchronize()
             try:
                 graphs = []
                 for bucket in range(self.n_streams):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.streams[bucket], capture_error_mode="thread_local"):
-                        for b in range(bucket * G, (bucket + 1) * G):
-                            self.plans[b].launch_on(self.streams[bucket])
-                    graphs.append(g)
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, stream=self.streams[bucket], capture_error_mode="thread_local"):
+                        for g in range(bucket * G // B, (bucket + 1) * G // B):
+                            self.launches[g][B - 1].launch_on(self.streams[bucket])
+                    graphs.append(gr)
                 torch.cuda.synchronize()
                 self.graphs = graphs
-            except RuntimeError as e:  # capture refused on this box: the eager path does the same work, one host call per step
+            except RuntimeError as e:  # capture refused on this box: the eager path does the same work, one host call per launch
                 print(f"bench: hipGraph capture failed ({e}); continuing with eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
                 self.graphs = None
 
-    def launch(self):
-        """one launch on torch's current stream (ring slot 0)"""
-        self.plans[0].launch()
+    def stream_of(self, b):
+        return self.streams[b // self.G] if self.buckets else self.streams[(b // self.B) % self.n_streams]
 
-    def step(self):
-        b = self.step_no % self.NBUF
-        self.step_no += 1
-        if not self.buckets:
-            self.plans[b].launch_on(self.streams[b % self.n_streams])
-            return
-        bucket = b // self.G
-        self.plans[b].launch_on(self.streams[bucket])
-        if b % self.G == self.G - 1 and self.transport is not None:
-            self.exchange(bucket)  # the bucket is complete: gather its G summaries from every rank and consume them
+    def launch(self):
+        """one full launch (B steps) on torch's current stream (group 0)"""
+        self.launches[0][self.B - 1].launch()
 
     def run_steps(self, n):
-        """`n` steps; whole buckets go out as one graph replay each when graphs are on"""
+        """`n` steps = floor(n / B) launches of B steps and one of n mod B; whole buckets go out as one graph replay each when
+        graphs are on.  A bucket's exchange step follows its last launch."""
+        B, G = self.B, self.G
         while n > 0:
             b = self.step_no % self.NBUF
-            if self.graphs is not None and b % self.G == 0 and n >= self.G:
-                bucket = b // self.G
+            if self.graphs is not None and b % G == 0 and n >= G:
+                bucket = b // G
                 with torch.cuda.stream(self.streams[bucket]):
                     self.graphs[bucket].replay()
-                self.step_no += self.G
-                n -= self.G
+                self.step_no += G
+                n -= G
                 if self.transport is not None:
                     self.exchange(bucket)
-            else:
-                self.step()
-                n -= 1
+                continue
+            c = min(B, n)
+            self.launches[b // B][c - 1].launch_on(self.stream_of(b))
+            self.step_no += B  # (a shorter launch leaves the rest of its group unused: the ring moves on to the next group)
+            n -= c
+            if self.buckets and self.transport is not None and (b + B) % G == 0:
+                self.exchange(b // G)  # the bucket is complete: gather its G summaries from every rank and consume them
 
     def exchange(self, bucket):
         G = self.G
@@ -693,32 +728,42 @@ class Runner:
                 self.exchange((self.step_no % self.NBUF) // self.G)
             self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
 
-    def timed(self, steps, warmup, prewarm_ms, barrier, repeats=1):
+    def timed(self, steps, warmup, prewarm_ms, barrier, repeats=1, closing_barrier=None):
         """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then `repeats` times:
-        exactly `steps` steps between barrier + synchronize pairs.  Returns this rank's elapsed seconds of every repetition."""
+        opening barrier + synchronize, clock, exactly `steps` steps (+ the exchange of a partly filled bucket), THIS RANK's
+        synchronize, clock.  The group's closing barrier (`closing_barrier`, N > 1) comes after the clock: the caller takes the
+        maximum over ranks of the elapsed times, which is what a barrier-closed region measures minus the barrier's own latency.
+        Returns (elapsed seconds of every repetition, seconds the closing barrier took each time)."""
         # the pre-warm is time-based, so it must not contain collectives (ranks would issue different numbers of them):
-        # bare launches round-robin over the ring slots and streams
+        # bare full launches round-robin over the groups and streams
         t_pre = time.perf_counter()
+        ngroups = self.NBUF // self.B
         while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
-            for i in range(48):
-                self.plans[i % self.NBUF].launch_on(self.streams[i % self.n_streams])
+            for i in range(max(1, 48 // self.B)):
+                g = i % ngroups
+                self.launches[g][self.B - 1].launch_on(self.stream_of(g * self.B))
             torch.cuda.synchronize()
         self.run_steps(warmup)
         self.drain()
-        out = []
+        out, closing = [], []
         for _ in range(max(1, repeats)):
             barrier()
             t0 = time.perf_counter()
             self.run_steps(steps)
             self.drain()
-            barrier()
-            out.append(time.perf_counter() - t0)
-        return out
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out.append(t1 - t0)
+            if closing_barrier is not None:
+                closing_barrier()
+                closing.append(time.perf_counter() - t1)
+        return out, closing
 
     def host_enqueue_us(self):
         """diagnostic: host cost of issuing one step (64 steps into an empty queue, no waiting on the GPU)"""
         torch.cuda.synchronize()
-        nh = 64 if self.graphs is None else 4 * self.G
+        nh = max(64, 4 * self.G) if self.graphs is None else 4 * self.G
+        nh = (nh // self.B) * self.B
         th = time.perf_counter()
         self.run_steps(nh)
         t = (time.perf_counter() - th) / nh
@@ -730,7 +775,8 @@ class Runner:
         """Isolated launch duration: HIP events bracketing single launches on the launch stream (torch's current stream IS
         the stream the kernel is launched on), one launch in flight at a time, no collective inside the bracket.  `prewarm`
         untimed launches first (an idle gap drops the clocks: the first launches after one run 30-40 % long), then the MEDIAN of
-        `reps` pairs -- one host hiccup of a millisecond moves a mean of 50 by 20 us and a median not at all.  Returns a dict."""
+        `reps` pairs -- one host hiccup of a millisecond moves a mean of 50 by 20 us and a median not at all.  Returns a dict.
+        (A launch is B steps: `launch_steps` says how many.)"""
         for _ in range(prewarm):
             self.launch()
         torch.cuda.synchronize()
@@ -744,7 +790,7 @@ class Runner:
         torch.cuda.synchronize()
         t = np.array([a.elapsed_time(b) for a, b in kev])
         return {"median": float(np.median(t)), "mean": float(t.mean()), "min": float(t.min()), "p10": float(np.quantile(t, 0.1)),
-                "p90": float(np.quantile(t, 0.9)), "max": float(t.max()), "n": int(reps)}
+                "p90": float(np.quantile(t, 0.9)), "max": float(t.max()), "n": int(reps), "launch_steps": self.B}
 
 
 def dryrun(args, world, rank):
@@ -915,6 +961,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def closing_barrier():
+        # the closing half of the bracket: AFTER the rank's clock has stopped (Runner.timed), so its latency -- tens of microseconds
+        # across eight ranks, as long as the whole region at --steps 20 -- is recorded, not timed
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     def max_over_ranks(v):
         t = torch.tensor([v], dtype=torch.float64, device=device)
         if dist is not None:
@@ -924,17 +977,28 @@ def main():
         return float(t.item())
 
     rows_main = S_main * W
-    # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket
-    G = args.gather_every if args.gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
-    # a shard of <= 2 wavefronts per SIMD: two launches in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
-    n_streams = args.streams if args.streams > 0 else (4 if rows_main <= 131072 else 2)
+    FULL_WIDTH_ROWS = 262144  # four wavefronts per SIMD of the row shape: the launch width of the N = 1 workload
+    # steps per launch: as many of this rank's steps as make one full-width launch (1 at N = 1 / C4; 2 / 4 / 8 for the shards of 2 /
+    # 4 / 8 GPUs), so that every GPU issues launches of the same width at every N
+    batch = args.batch if args.batch > 0 else max(1, min(_hip.MAX_BATCH, FULL_WIDTH_ROWS // max(rows_main, 1)))
+    if shape == _hip.SHAPE_QUAD:
+        batch = 1
+    rows_launch = rows_main * batch
+    # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket; never more than the
+    # timed region holds (at the driver's --steps 20 at least one FULL exchange must lie inside the region), a multiple of the batch
+    G_req = args.gather_every if args.gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
+    G = max(batch, (min(G_req, max(args.steps, 1)) // batch) * batch)
+    # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
+    n_streams = args.streams if args.streams > 0 else (4 if rows_launch <= 131072 else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
-    use_graphs = args.graphs == "on" or (args.graphs == "auto" and rows_main <= 65536)
-    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver, graphs=use_graphs)
+    use_graphs = args.graphs == "on" or (args.graphs == "auto" and rows_launch <= 65536)
+    run = Runner(robot, x0, target, K, collide, n_streams, G, transport, world, shape, device, solver, graphs=use_graphs, batch=batch)
     n = run.n
     # the timed region, `--repeats` times back to back; every repetition is the maximum over ranks, the headline the median one
-    reps_s = [max_over_ranks(t) for t in run.timed(args.steps, args.warmup, args.prewarm_ms, barrier, args.repeats)]
+    reps_local, closing_local = run.timed(args.steps, args.warmup, args.prewarm_ms, barrier, args.repeats, closing_barrier if dist is not None else None)
+    reps_s = [max_over_ranks(t) for t in reps_local]
+    closing_us = [1e6 * max_over_ranks(t) for t in closing_local]
     elapsed = float(np.median(reps_s))
     host_us = run.host_enqueue_us()
     kstats = run.kernel_ms(max(200, args.kernel_reps))
@@ -999,14 +1063,18 @@ def main():
     def measure_sibling(S_local, mode, kind, streams, steps):
         """a second workload / pipeline depth measured like the headline (same barriers, same max over ranks)"""
         xs, tg, _ = inputs_for(S_local, mode, kind)
-        r2 = Runner(robot, xs, tg, K, collide, streams, G, transport, world, shape, device, solver)
-        el = float(np.median([max_over_ranks(t) for t in r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier, 3)]))
+        b2 = max(1, min(_hip.MAX_BATCH, FULL_WIDTH_ROWS // max(xs.shape[0], 1))) if args.batch <= 0 else args.batch
+        b2 = 1 if shape == _hip.SHAPE_QUAD else b2
+        G2 = max(b2, (min(G_req, max(steps, 1)) // b2) * b2)
+        r2 = Runner(robot, xs, tg, K, collide, streams, G2, transport, world, shape, device, solver, batch=b2)
+        el = float(np.median([max_over_ranks(t) for t in r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier, 3,
+                                                                    closing_barrier if dist is not None else None)[0]]))
         km = r2.kernel_ms(200, prewarm=200)["median"]
         rows = float(r2.n) * world
         del r2
         torch.cuda.empty_cache()
         return {"value": rows * K * steps / el, "ms_per_step": 1e3 * el / steps, "kernel_ms": km, "streams": streams,
-                "rows_per_gpu": int(rows // world)}  # fmt: skip
+                "rows_per_gpu": int(rows // world), "steps_per_launch": b2}  # fmt: skip
 
     def measure_neighbour_stages(robot, run, W, d, device):
         """The two stages on either side of the hot path, on this workload's own result, untimed and
@@ -1065,10 +1133,16 @@ def main():
         alg_tflops = alg_flops / t_k / 1e12
         ach_gbps = bytes_launch / t_k / 1e9
         build_id = _hip.lib().cppf_build_id().decode()
-        rec, rec_why = (issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs, build_id) if args.solver == "auto"
-                        else (None, "no record for this solver"))
+        # the committed counters describe ONE launch of `run.B` steps of this workload (scripts/pmc_probe.py records the launch shapes
+        # bench.py issues); B > 1 launches of a shard are keyed with their batch
+        rec, rec_why = (issue_record_from_profiles(args.robot, run.S, W, K, collide, args.inputs + ("" if run.B == 1 else f"_b{run.B}"), build_id)
+                        if args.solver == "auto" else (None, "no counter record for this solver mode"))
         kname = "lm_fused_kernel" if shape != _hip.SHAPE_QUAD else "lm_quad_kernel"
         kprof, kprof_why = kernel_profile_from_profiles(f"{kname}<cppf::StaRobot<cppf::gen::{''.join(p.capitalize() for p in args.robot.split('_'))}>, {1 if collide else 0}", build_id)
+        if kprof and run.B != 1:
+            kprof, kprof_why = None, "the committed kernel-trace summary is of the N = 1 command (one step per launch)"
+        step_s = elapsed / args.steps
+        alg_launch = alg_flops * run.B  # one launch = B steps
         roof = {
             # the binding resource is the fp32 VALU issue rate (157.3 TFLOP/s of FMAs = one wave-instruction per SIMD per 2
             # cycles); the contract's vocabulary has no word for it, so `bound` says what it is and `mfma_used` that no
@@ -1079,51 +1153,45 @@ def main():
             "unit": "TFLOP/s",
             "kernel": kname,
             "kernel_ms": kernel_ms,
-            "kernel_ms_how": f"median of {kstats['n']} isolated launches (HIP events on the launch stream, one in flight) after a pre-warm",
+            "kernel_launch_steps": run.B,
+            "kernel_ms_how": f"median of {kstats['n']} isolated launches of {run.B} step(s) (HIP events on the launch stream, one in flight) after a pre-warm",
             "kernel_ms_stats": kstats,
             # the same kernel's average duration in the committed `rocprofv3 --kernel-trace --stats` summary of this command
-            # (profiles/r3_fused_kernel_stats.csv), when that summary was taken with this build of the library
+            # (profiles/r4_fused_kernel_stats.csv), when that summary was taken with this build of the library
             "kernel_ms_profile": kprof["ms"] if kprof else None,
             "kernel_profile": kprof if kprof else {"unavailable": kprof_why},
             "drift": (kernel_ms / kprof["ms"]) if kprof else None,
             "library_build_id": build_id,
+            # the SURVEY 8(d) flop model, for comparison ONLY (never `frac`): it prices the reference's formulation -- primal J^T J +
+            # d^3/3 Cholesky, every collision test -- not what this kernel executes (dual 6x6 solve, broad-phase culls)
             "algorithmic": {
-                "tflops": alg_tflops,
-                "frac": alg_tflops / F32_PEAK_TFLOPS,
-                "note": "SURVEY 8d flop model (primal J^T J + d^3/3 Cholesky, every collision test counted) / kernel time: "
-                "what the reference's formulation would need, NOT what this kernel executes (dual 6x6 solve, broad-phase culls)",
+                "tflops": alg_launch / t_k / 1e12,
+                "note": "SURVEY 8d flop model / isolated kernel time: what the reference's formulation would need, NOT a utilisation figure",
             },
-            "traffic": traffic_from_profiles(args.robot, run.S, W, K, collide, build_id),
-            "hbm": {"achieved": ach_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps / HBM_PEAK_GBPS},
+            "traffic": traffic_from_profiles(args.robot, run.S, W, K, collide, build_id) if run.B == 1 else None,
+            "hbm": {"achieved": ach_gbps * run.B, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach_gbps * run.B / HBM_PEAK_GBPS},
         }
         if rec is not None:
             valu = float(rec["valu_insts_per_launch"])
-            exe_tflops = valu * 64.0 * float(rec["flops_per_valu_lane_op"]) / t_k / 1e12
+            flops_launch = valu * 64.0 * float(rec["flops_per_valu_lane_op"])
+            exe_tflops = flops_launch / t_k / 1e12
             issue_s = valu * 2.0 / N_SIMD / (CLOCK_GHZ * 1e9)
             roof.update({
                 "achieved": exe_tflops,
                 "frac": exe_tflops / F32_PEAK_TFLOPS,
-                "basis": "executed flops: SQ_INSTS_VALU of the matching launch (profiles/r3_issue.json, same library build) x 64 lanes x flops per VALU "
-                "lane-op from the kernel's ISA (FMA = 2, mul / add = 1, moves / selects / compares = 0), / live kernel time",
+                "basis": f"executed flops: SQ_INSTS_VALU_* of the matching launch (profiles/{PROFILE_ROUND}_issue.json, same library build) x 64 lanes x "
+                "flops per VALU lane-op (FMA = 2, mul / add = 1, moves / selects / compares / transcendentals = 0), / live isolated kernel time",
                 "valu_issue_frac": issue_s / t_k,
-                "valu_issue_frac_at_step_rate": issue_s / (elapsed / args.steps),
+                "at_step_rate": {"ms_per_step": 1e3 * step_s, "launches_in_flight": run.n_streams, "executed_tflops": flops_launch / run.B / step_s / 1e12,
+                                 "frac": flops_launch / run.B / step_s / 1e12 / F32_PEAK_TFLOPS, "valu_issue_frac": issue_s / run.B / step_s},
             })  # fmt: skip
         else:
-            capped = alg_tflops / F32_PEAK_TFLOPS
-            roof.update({
-                "achieved": alg_tflops if capped <= 1.0 else None,
-                "frac": capped if capped <= 1.0 else None,
-                "basis": f"algorithmic flop model ({rec_why})"
-                + ("" if capped <= 1.0 else "; the model counts collision tests the broad phase skips, so the fraction would exceed 1 and is withheld"),
-            })  # fmt: skip
+            roof.update({"achieved": None, "frac": None, "basis": f"unavailable: {rec_why} (the executed-flop basis needs the committed counters of this "
+                         "launch shape and library build; the algorithmic model is kept apart under `algorithmic`)",
+                         "at_step_rate": {"ms_per_step": 1e3 * step_s, "launches_in_flight": run.n_streams}})  # fmt: skip
         if kprof and abs(kernel_ms / kprof["ms"] - 1.0) > 0.15:
             print(f"bench: WARNING: live kernel time {1e3 * kernel_ms:.1f} us differs from the committed rocprofv3 average "
                   f"{1e3 * kprof['ms']:.1f} us by more than 15 % (drift {kernel_ms / kprof['ms']:.2f})", file=sys.stderr)
-        roof["at_step_rate"] = {
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "batches_in_flight": run.n_streams,
-            "algorithmic_tflops": alg_flops / (elapsed / args.steps) / 1e12,
-        }
         line = {
             "metric": "LM-IK iterations/sec (seeds x waypoints)",
             "value": iters / elapsed,
@@ -1146,7 +1214,13 @@ def main():
                 "streams": run.n_streams,
                 "timed_region": {"repeats": len(reps_s), "reported": "median", "ms_per_step_min": 1e3 * min(reps_s) / args.steps,
                                  "ms_per_step_max": 1e3 * max(reps_s) / args.steps,
-                                 "ms_per_step_all": [1e3 * t / args.steps for t in reps_s]},
+                                 "ms_per_step_all": [1e3 * t / args.steps for t in reps_s],
+                                 "clock": "opening barrier + synchronize | K steps (+ the exchange of a partly filled bucket) | this rank's "
+                                          "synchronize; maximum over ranks.  The group's closing barrier follows the clock.",
+                                 "closing_barrier_us": closing_us if closing_us else None},
+                "steps_per_launch": run.B,
+                "launches_per_region": f"{args.steps // run.B} x {run.B} steps" + (f" + 1 x {args.steps % run.B} steps" if args.steps % run.B else ""),
+                "rows_per_launch": run.n * run.B,
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 "hip_graphs": (f"on: each stream's {run.G} consecutive steps replayed as one captured graph" if run.graphs is not None else "off (one host call per step)"),
                 "kernel_shape": args.shape,
@@ -1168,11 +1242,13 @@ def main():
                 "collective_backend": (None if dist is None else ("gloo, host-staged (one-GPU rehearsal: NOT a multi-GPU result)" if share_gpu else
                                                                   {"RcclGather": "nccl (RCCL) through torch.distributed", "CAbiGather": "RCCL through the C ABI "
                                                                    "(cppf_allgather_bytes on the auxiliary stream)", "NoGather": "none (diagnostic)", "NoneType": "none (diagnostic)"}[type(transport).__name__])),
-                "per_step": "one fused launch incl. the per-seed summary reduction"
-                + (f" + async all-gather of the [S,8] summaries, {G} steps per collective, + x_is_valid seed selection over all "
+                "per_step": ("one fused launch" if run.B == 1 else f"1/{run.B} of a fused launch of {run.B} independent steps (cppf_lm_batch_launch)")
+                + " incl. the per-seed summary reduction"
+                + (f" + async all-gather of the [S,8] summaries, {run.G} steps per collective, + x_is_valid seed selection over all "
                    f"{run.S * world} seeds of every step on each rank" if run.gathered is not None else ""),
                 "allgather_bytes_per_rank_per_step": int(run.summ_all[0].numel() * 4) if run.gathered is not None else 0,
-                "steps_per_allgather": G if run.gathered is not None else 0,
+                "steps_per_allgather": run.G if run.gathered is not None else 0,
+                "steps_per_allgather_requested": G_req if run.gathered is not None else 0,
                 "selected_seed_last_bucket": selected,
                 "converged_frac_pos_err_lt_1e-4": conv_frac,
             },

@@ -66,7 +66,8 @@ SOLVER_AUTO, SOLVER_F64, SOLVER_F32 = 0, 1, 2  # AUTO = fp32 with the conditioni
 # cppflow_hip_debug.h: per-handle test / tuning switches (cppf_debug_set)
 TUNE_DEFAULT = -(2**31)
 TUNE_KEYS = {"force_generic": 0, "pcr_max_rows": 1, "quad_max_rows": 2, "dp_persistent": 3, "full_rows": 4, "pcr_lds": 5,
-             "rows_pose": 6, "quad_mfma": 7, "spread_kb": 8}  # fmt: skip
+             "rows_pose": 6, "quad_mfma": 7, "spread_kb": 8, "dp_spin_log2": 9}  # fmt: skip
+DP_AUTO, DP_RESIDENT, DP_LAUNCHES = 0, 1, 2  # cppf_dp_search's `mode`
 
 
 class Constraints(ctypes.Structure):
@@ -115,6 +116,15 @@ class LmOutputs(ctypes.Structure):
     ]
 
 
+MAX_BATCH = 16  # CPPF_MAX_BATCH
+
+
+class LmBatchItem(ctypes.Structure):
+    """struct cppf_lm_batch_item: one problem of a batched fused launch (cppf_lm_batch_create)"""
+
+    _fields_ = [("x_in", _vp), ("target", _vp), ("S", _i32), ("W", _i32), ("out", LmOutputs)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "cppf_abi_version": (ctypes.c_int, []),
@@ -128,7 +138,7 @@ SIGNATURES = {
     "cppf_debug_rtc_compile": (ctypes.c_int, [ctypes.POINTER(RobotDesc), ctypes.c_char_p]),
     "cppf_debug_set": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "cppf_debug_get": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
-    "cppf_debug_rcp_sweep": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
+    "cppf_debug_fused_single_offset": (ctypes.c_int, []),
     "cppf_set_obstacles": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_set_joint_limit_padding": (ctypes.c_int, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     "cppf_forward_kinematics": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
@@ -139,6 +149,9 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(LmParams), ctypes.POINTER(LmOutputs), _vp],
     ),
+    "cppf_lm_batch_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(LmBatchItem), ctypes.POINTER(LmParams), ctypes.POINTER(_vp)]),
+    "cppf_lm_batch_launch": (ctypes.c_int, [_vp, _vp]),
+    "cppf_lm_batch_destroy": (None, [_vp]),
     "cppf_collision_masks": (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cppf_self_collision_distances": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp]),
     "cppf_env_collision_distances": (
@@ -172,7 +185,7 @@ SIGNATURES = {
     "cppf_comm_destroy": (None, [_vp]),
     "cppf_dp_search": (
         ctypes.c_int,
-        [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
+        [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, _vp],
     ),
     "cppf_dp_table_floats": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "cppf_dp_search_tabled": (

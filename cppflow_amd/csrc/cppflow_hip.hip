@@ -34,8 +34,7 @@ using namespace cppf;
 namespace cppf {
 // fused_static.hip: lm_fused_kernel<StaRobot<table static_id>, coll> -- the row-shape fused kernel of the shipped robots lives in
 // its own translation unit (another machine scheduler, see there)
-bool launch_fused_static(int static_id, int coll, unsigned grid, size_t lds, hipStream_t st, const ChainK& ch, const CollK& co,
-                         const LmK& prm, const float* x_in, const float* target, const cppf_lm_outputs& out);
+bool launch_fused_static(int static_id, int coll, unsigned grid, size_t lds, hipStream_t st, const FusedArgs& args);
 int fused_static_block();
 }  // namespace cppf
 
@@ -112,14 +111,13 @@ namespace {
 constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
     /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
     /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
-    /* SPREAD_KB */ 42,
+    /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
 
-// static LDS of a fused kernel: the gate's slots of its four wavefronts + the summary staging (an upper bound, scripts/kernel_resources.py)
-inline size_t fused_static_lds(const cppf_robot* rb) {
-    return (rb->desc.ndof >= 6 ? (size_t)(kBlock / 64) * (size_t)gate_lds_floats(rb->desc.ndof) * sizeof(float) : 0) + 1024;
-}
+// static LDS of a fused kernel: the gate's slots of its four wavefronts + the summary staging -- the bound the kernel itself
+// static_asserts next to its __shared__ declarations (fused_static_lds_bound, kernels_fused.h)
+inline size_t fused_static_lds(const cppf_robot* rb) { return fused_static_lds_bound(rb->desc.ndof); }
 // Dynamic LDS (bytes) a fused row-shape launch of n rows claims purely to bound how many of its workgroups share a compute unit
 // (CPPF_TUNE_SPREAD_KB; 0 = none): static LDS (the conditioning gate's slots: 13 KB at 7 joints, 17 KB at 12) + the claim stays
 // under the 64 KB a workgroup may have without asking, and two such workgroups fit on a unit's 160 KB where a third does not.  Only
@@ -318,19 +316,6 @@ struct DeviceGuard {
 }  // namespace
 
 namespace {
-// cppf_debug_rcp_sweep: rcp_rn (lmik_device.h) against the correctly rounded division, bit for bit, by biased exponent
-__global__ __launch_bounds__(kBlock) void rcp_sweep_kernel(uint64_t first, uint64_t count, unsigned long long* mism) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride) {
-        const uint32_t bits = (uint32_t)(first + i);
-        const float x = __uint_as_float(bits);
-        const float want = fabsf(x) >= 0x1p-100f ? 1.0f / x : 0.f;  // IEEE division (-fhip-fp32-correctly-rounded-divide-sqrt)
-        const float got = rcp_rn(x);
-        const bool both_nan = want != want && got != got;
-        if (!both_nan && __float_as_uint(want) != __float_as_uint(got)) atomicAdd(&mism[(bits >> 23) & 0xffu], 1ull);
-    }
-}
-
 int rtc_launch(const cppf_robot* rb, RtcKernel which, unsigned grid, size_t lds, hipStream_t st, void** args) {
     hipFunction_t f = rb->rtc->fn[which];
     if (!f) return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: this kernel is not part of the handle's specialised module");
@@ -523,17 +508,7 @@ int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
 
 int cppf_robot_ndof(const cppf_robot* robot) { return robot ? robot->desc.ndof : CPPF_ERR_INVALID; }
 
-int cppf_debug_rcp_sweep(int device, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream) {
-    CPPF_REQUIRE(mismatches, "mismatches is NULL");
-    CPPF_REQUIRE(first <= (1ull << 32) && count <= (1ull << 32) - first, "first + count exceeds 2^32 bit patterns");
-    if (count == 0) return CPPF_OK;
-    DeviceGuard guard(device);
-    if (guard.err != hipSuccess) return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the device failed: ") + hipGetErrorString(guard.err));
-    hipLaunchKernelGGL(rcp_sweep_kernel, dim3(4096), dim3(kBlock), 0, (hipStream_t)stream, first, count,
-                       reinterpret_cast<unsigned long long*>(mismatches));
-    CPPF_HIP(hipGetLastError());
-    return CPPF_OK;
-}
+int cppf_debug_fused_single_offset(void) { return (int)__builtin_offsetof(FusedArgs, single); }
 
 int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir) {
     cppf_robot* rb = nullptr;
@@ -644,23 +619,24 @@ int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* s
     return check_launch(robot);
 }
 
-int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
-                       const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream) {
-    CPPF_ENTER(robot);
-    CPPF_REQUIRE(params && out, "params / out is NULL");
-    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+}  // extern "C"
+
+namespace {
+
+// cppf_lm_params -> the kernels' LmK (validation included); n / W are the caller's to fill
+int make_lm_kernel_params(const cppf_lm_params* params, LmK& prm) {
+    CPPF_REQUIRE(params, "params is NULL");
     CPPF_REQUIRE(params->n_steps >= 1, "n_steps must be >= 1");
     CPPF_REQUIRE(params->clamp == 1 || params->n_steps == 1, "clamp = 0 is only defined for a single step");
     CPPF_REQUIRE(params->lm_lambda > 0.f, "lm_lambda must be > 0");
-    const size_t n = (size_t)S * W;
-    if (n == 0) return CPPF_OK;
-    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
-    CPPF_REQUIRE(x_in && target, "x_in / target is NULL");
     CPPF_REQUIRE(params->alpha_position > 0.f && params->alpha_rotation > 0.f, "alpha_position / alpha_rotation must be > 0");
     CPPF_REQUIRE(params->solver == CPPF_SOLVER_AUTO || params->solver == CPPF_SOLVER_F32 || params->solver == CPPF_SOLVER_F64,
                  "unknown solver");
     CPPF_REQUIRE(params->solver_gate >= 0.f, "solver_gate must be >= 0 (0 = the default tolerance)");
-    LmK prm;
+    CPPF_REQUIRE(params->shape == CPPF_SHAPE_AUTO || params->shape == CPPF_SHAPE_ROW || params->shape == CPPF_SHAPE_QUAD,
+                 "unknown kernel shape");
+    CPPF_REQUIRE(params->tol_pos_m >= 0.f && params->tol_rot_rad >= 0.f, "early-out tolerances must be >= 0");
+    CPPF_REQUIRE((params->tol_pos_m > 0.f) == (params->tol_rot_rad > 0.f), "set both early-out tolerances or neither");
     prm.lm_lambda = params->lm_lambda;
     prm.a_pos = params->alpha_position;
     prm.a_rot = params->alpha_rotation;
@@ -670,29 +646,101 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     prm.lam_r = (float)prm.lam_r_d;
     prm.lam_p = (float)prm.lam_p_d;
     // conditioning gate (lm_solve_gated): redo a row's solve in double precision when eps * a_max * max diag(A) * max |y| > tau
-    {
-        const float tau = params->solver_gate > 0.f ? params->solver_gate : CPPF_SOLVER_GATE_DEFAULT;
-        const float a_max = std::fmax(params->alpha_position, params->alpha_rotation);
-        prm.gate_thr = params->solver == CPPF_SOLVER_F32 ? INFINITY
-                       : params->solver == CPPF_SOLVER_F64 ? -INFINITY
-                                                           : tau / (6e-8f * a_max);
-    }
+    const float tau = params->solver_gate > 0.f ? params->solver_gate : CPPF_SOLVER_GATE_DEFAULT;
+    const float a_max = std::fmax(params->alpha_position, params->alpha_rotation);
+    prm.gate_thr = params->solver == CPPF_SOLVER_F32 ? INFINITY : params->solver == CPPF_SOLVER_F64 ? -INFINITY : tau / (6e-8f * a_max);
     prm.n_steps = params->n_steps;
     prm.clamp = params->clamp;
-    prm.n = (int)n;
-    prm.W = W;
-    CPPF_REQUIRE(params->tol_pos_m >= 0.f && params->tol_rot_rad >= 0.f, "early-out tolerances must be >= 0");
-    CPPF_REQUIRE((params->tol_pos_m > 0.f) == (params->tol_rot_rad > 0.f), "set both early-out tolerances or neither");
-    CPPF_REQUIRE(!(params->tol_pos_m > 0.f && (out->J_out || out->e_out)), "early-out is not combinable with J_out / e_out");
+    prm.n = 0;
+    prm.W = 0;
     prm.tol_pos2 = params->tol_pos_m * params->tol_pos_m;
     prm.tol_rot2 = params->tol_rot_rad * params->tol_rot_rad;
-    const bool coll = out->self_mask || out->env_mask || out->jlim_mask || out->ext_cost || out->min_self ||
-                      out->min_env || out->seed_summary;
+    return CPPF_OK;
+}
+
+inline bool outputs_want_collision(const cppf_lm_outputs& o) {
+    return o.self_mask || o.env_mask || o.jlim_mask || o.ext_cost || o.min_self || o.min_env || o.seed_summary;
+}
+// the per-seed summary is an epilogue of the fused launch when a 256-row workgroup holds whole seeds (W = 64, 128, 256)
+inline bool summary_in_launch(int W) { return W >= 64 && kBlock % W == 0 && (W & (W - 1)) == 0; }
+
+// One launch of the row-shape fused kernel over `grid` workgroups: the problem `single` (table == NULL) or the problems of a device
+// table (cppf_lm_batch_*).  coll = lm_fused_kernel's COLL; n_rows = all rows of the launch (what the residency claim goes by).
+int launch_fused_rows(const cppf_robot* robot, int coll, size_t n_rows, unsigned grid, hipStream_t st, const LmK& prm,
+                      const BatchItemK& single, const void* table) {
+    // Dynamic LDS: what the generic kernels stage their capsules in, or -- for a launch of at most two workgroups per compute
+    // unit -- a claim sized so that only two workgroups FIT on one (fused_spread_lds): several such launches in flight then
+    // spread over the whole chip instead of stacking four deep on the compute units the dispatcher tries first.
+    const bool generic = !use_rtc(robot) && !(robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC));
+    const size_t spread = fused_spread_lds(robot, n_rows);
+    const size_t lds_need = (generic && coll) ? robot->lds_bytes : 0;
+    // the generic kernels stage 6 floats per capsule per lane: with the gate's slots beside them, 12 joints x 24 capsules no longer
+    // fit the 160 KB of a compute unit (the launch would take the process down) -- such a robot has to be specialised
+    if (generic && coll && lds_need + fused_static_lds(robot) > (size_t)160 * 1024)
+        return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: the generic kernels cannot stage this many capsules at this ndof; cppf_robot_specialize() the robot");
+    FusedArgs fa;
+    fa.ch = robot->chain;
+    fa.co = robot->coll;
+    fa.prm = prm;
+    fa.single = single;
+    fa.table = table;
+    if (use_rtc(robot)) {
+        void* args[] = {(void*)&fa.ch, (void*)&fa.co, (void*)&fa.prm, (void*)&fa.single, (void*)&fa.table};
+        if (int rc = rtc_launch(robot, coll == 0 ? RTC_FUSED0 : (coll == 2 ? RTC_FUSED2 : RTC_FUSED1), grid, spread, st, args)) return rc;
+    } else if (!generic) {
+        // a generated table: the kernel lives in fused_static.hip
+        if (!launch_fused_static(robot->static_id, coll, grid, spread, st, fa))
+            return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: no fused kernel for this generated table");
+    } else {
+        const size_t lds = std::max(lds_need, spread);
+#define CPPF_BODY                                                                                          \
+    if (coll == 2)                                                                                         \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid), dim3(kBlock), lds, st, fa.ch, fa.co, fa.prm, fa.single, fa.table);               \
+    else if (coll == 1)                                                                                    \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid), dim3(kBlock), lds, st, fa.ch, fa.co, fa.prm, fa.single, fa.table);               \
+    else                                                                                                   \
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid), dim3(kBlock), lds, st, fa.ch, fa.co, fa.prm, fa.single, fa.table)
+        CPPF_DISPATCH_DYN(robot)
+#undef CPPF_BODY
+    }
+    return check_launch(robot);
+}
+
+}  // namespace
+
+// A batched fused launch (cppflow_hip.h): the item descriptors live in a device table the batch object owns.
+struct cppf_lm_batch {
+    const cppf_robot* robot;
+    LmK prm;
+    void* d_table;        // { BatchHeadK ; BatchItemK[n_items] }
+    int n_items, coll;
+    unsigned grid;
+    size_t n_rows;
+    std::vector<cppf_lm_batch_item> after;  // items whose per-seed summary needs the separate reduction launch (W not 64 / 128 / 256)
+};
+
+extern "C" {
+
+int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
+                       const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream) {
+    CPPF_ENTER(robot);
+    CPPF_REQUIRE(params && out, "params / out is NULL");
+    CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
+    LmK prm;
+    if (int rc = make_lm_kernel_params(params, prm)) return rc;
+    const size_t n = (size_t)S * W;
+    if (n == 0) return CPPF_OK;
+    CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+    CPPF_REQUIRE(x_in && target, "x_in / target is NULL");
+    prm.n = (int)n;
+    prm.W = W;
+    CPPF_REQUIRE(!(params->tol_pos_m > 0.f && (out->J_out || out->e_out)), "early-out is not combinable with J_out / e_out");
+    const bool coll = outputs_want_collision(*out);
     hipStream_t st = (hipStream_t)stream;
     // per-seed summary: fused into the launch when a workgroup holds whole seeds, else the separate reduction afterwards
     cppf_lm_outputs outk = *out;
     float* const summary_dst = out->seed_summary;
-    const bool summary_after = out->seed_summary && !(W >= 64 && kBlock % W == 0 && (W & (W - 1)) == 0);  // 64, 128, 256
+    const bool summary_after = out->seed_summary && !summary_in_launch(W);
     if (summary_after) {
         CPPF_REQUIRE(out->x_out && out->pos_err_m && out->rot_err_rad && out->self_mask && out->env_mask &&
                          out->jlim_mask && out->ext_cost,
@@ -704,8 +752,6 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     const bool quad_can = d >= 6 && !out->J_out && !out->e_out && !out->min_self && !out->min_env &&
                           (!out->seed_summary || (out->x_out && out->pos_err_m && out->rot_err_rad && out->self_mask &&
                                                   out->env_mask && out->jlim_mask && out->ext_cost));
-    CPPF_REQUIRE(params->shape == CPPF_SHAPE_AUTO || params->shape == CPPF_SHAPE_ROW || params->shape == CPPF_SHAPE_QUAD,
-                 "unknown kernel shape");
     CPPF_REQUIRE(params->shape != CPPF_SHAPE_QUAD || quad_can,
                  "CPPF_SHAPE_QUAD needs ndof >= 6, no J_out / e_out / min_self / min_env, and (with seed_summary) every per-row output");
     // AUTO: the quad shape when the batch is at most one of its wavefronts per SIMD AND no per-seed summary is asked for (in
@@ -763,52 +809,97 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
                                      oq.jlim_mask, summary_dst, stream);
         return CPPF_OK;
     }
-    // Dynamic LDS: what the generic kernels stage their capsules in, or -- for a launch of at most two workgroups per compute
-    // unit -- a claim sized so that only two workgroups FIT on one (fused_spread_lds): several such launches in flight then
-    // spread over the whole chip instead of stacking four deep on the compute units the dispatcher tries first.
-    // (the kernels get `outk`: with the separate reduction its seed_summary is NULL -- handing them `*out` there made the in-launch
+    // (the kernel gets `outk`: with the separate reduction its seed_summary is NULL -- handing it `*out` there made the in-launch
     // summary run on a W it is not built for and write up to n / 64 - S rows past the caller's [S,8] buffer before the reduction
     // kernel put the right values in: found by the sentinel-arena test of tests/test_gpu_round3.py)
-    const size_t lds_need = (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) ? 0 : robot->lds_bytes;
-    const size_t lds = std::max(lds_need, fused_spread_lds(robot, n));
-    // the generic kernels stage 6 floats per capsule per lane: with the gate's slots beside them, 12 joints x 24 capsules no longer
-    // fit the 160 KB of a compute unit (the launch would take the process down) -- such a robot has to be specialised
-    if (coll && !use_rtc(robot) && lds_need + fused_static_lds(robot) > (size_t)160 * 1024)
-        return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: the generic kernels cannot stage this many capsules at this ndof; cppf_robot_specialize() the robot");
-    if (use_rtc(robot)) {
-        void* args[] = {(void*)&robot->chain, (void*)&robot->coll, (void*)&prm, (void*)&x_in, (void*)&target, (void*)&outk};
-        const RtcKernel which = !coll ? RTC_FUSED0 : ((out->min_self || out->min_env) ? RTC_FUSED2 : RTC_FUSED1);
-        if (int rc = rtc_launch(robot, which, grid_for(n), fused_spread_lds(robot, n), st, args)) return rc;
-    } else if (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC)) {
-        // a generated table: the kernel lives in fused_static.hip
-        const int c = !coll ? 0 : ((out->min_self || out->min_env) ? 2 : 1);
-        if (!launch_fused_static(robot->static_id, c, grid_for(n), fused_spread_lds(robot, n), st, robot->chain, robot->coll, prm, x_in,
-                                 target, outk))
-            return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: no fused kernel for this generated table");
-    } else if (coll && (out->min_self || out->min_env)) {
-#define CPPF_BODY                                                                                                 \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
-                       prm, x_in, target, outk)
-        CPPF_DISPATCH_DYN(robot)
-#undef CPPF_BODY
-    } else if (coll) {
-#define CPPF_BODY                                                                                                 \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid_for(n)), dim3(kBlock), lds, st, robot->chain, robot->coll, \
-                       prm, x_in, target, outk)
-        CPPF_DISPATCH_DYN(robot)
-#undef CPPF_BODY
-    } else {
-#define CPPF_BODY                                                                                               \
-    hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid_for(n)), dim3(kBlock), fused_spread_lds(robot, n), st, robot->chain, robot->coll, \
-                       prm, x_in, target, outk)
-        CPPF_DISPATCH_DYN(robot)
-#undef CPPF_BODY
-    }
-    if (int rc = check_launch(robot)) return rc;
+    BatchItemK item;
+    item.x_in = x_in, item.target = target, item.out = outk, item.n = (int)n, item.W = W;
+    const int c = !coll ? 0 : ((out->min_self || out->min_env) ? 2 : 1);
+    if (int rc = launch_fused_rows(robot, c, n, grid_for(n), st, prm, item, nullptr)) return rc;
     if (summary_after)
         return cppf_seed_summary(robot, outk.x_out, S, W, outk.ext_cost, outk.pos_err_m, outk.rot_err_rad, outk.self_mask,
                                  outk.env_mask, outk.jlim_mask, summary_dst, stream);
     return CPPF_OK;
+}
+
+int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_batch_item* items, const cppf_lm_params* params,
+                         cppf_lm_batch** out) {
+    CPPF_ENTER(robot);
+    CPPF_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    CPPF_REQUIRE(items && n_items >= 1 && n_items <= CPPF_MAX_BATCH, "n_items must be in 1 .. CPPF_MAX_BATCH");
+    LmK prm;
+    if (int rc = make_lm_kernel_params(params, prm)) return rc;
+    CPPF_REQUIRE(params->shape != CPPF_SHAPE_QUAD, "a batched launch is the row shape (CPPF_SHAPE_AUTO or CPPF_SHAPE_ROW)");
+    std::vector<unsigned char> host(sizeof(BatchHeadK) + (size_t)n_items * sizeof(BatchItemK));
+    BatchHeadK* head = reinterpret_cast<BatchHeadK*>(host.data());
+    BatchItemK* tab = reinterpret_cast<BatchItemK*>(host.data() + sizeof(BatchHeadK));
+    std::vector<cppf_lm_batch_item> after;
+    size_t blocks = 0, rows = 0;
+    bool coll = false;
+    for (int i = 0; i < n_items; ++i) {
+        const cppf_lm_batch_item& it = items[i];
+        CPPF_REQUIRE(it.S >= 1 && it.W >= 1, "every item needs S >= 1 and W >= 1");
+        const size_t n = (size_t)it.S * it.W;
+        CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
+        CPPF_REQUIRE(it.x_in && it.target, "x_in / target is NULL");
+        CPPF_REQUIRE(!it.out.J_out && !it.out.e_out && !it.out.min_self && !it.out.min_env,
+                     "J_out / e_out / min_self / min_env are not available in a batched launch");
+        BatchItemK k;
+        k.x_in = it.x_in, k.target = it.target, k.out = it.out, k.n = (int)n, k.W = it.W;
+        if (it.out.seed_summary && !summary_in_launch(it.W)) {
+            CPPF_REQUIRE(it.out.x_out && it.out.pos_err_m && it.out.rot_err_rad && it.out.self_mask && it.out.env_mask &&
+                             it.out.jlim_mask && it.out.ext_cost,
+                         "seed_summary with W not in {64, 128, 256} needs x_out, pos_err_m, rot_err_rad, the three masks and ext_cost");
+            k.out.seed_summary = nullptr;
+            after.push_back(it);
+        }
+        coll = coll || outputs_want_collision(it.out);
+        tab[i] = k;
+        blocks += grid_for(n);
+        rows += n;
+        head->block_end[i] = (uint32_t)blocks;
+    }
+    CPPF_REQUIRE(blocks <= 0x7fffffffu, "the batch exceeds 2^31-1 workgroups");
+    for (int i = n_items; i < CPPF_MAX_BATCH; ++i) head->block_end[i] = 0xffffffffu;
+    cppf_lm_batch* b = new (std::nothrow) cppf_lm_batch();
+    if (!b) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
+    b->robot = robot, b->prm = prm, b->d_table = nullptr, b->n_items = n_items, b->coll = coll ? 1 : 0;
+    b->grid = (unsigned)blocks, b->n_rows = rows;
+    b->after = after;
+    hipError_t e = hipMalloc(&b->d_table, host.size());
+    if (e == hipSuccess) e = hipMemcpy(b->d_table, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (b->d_table) (void)hipFree(b->d_table);
+        delete b;
+        return fail(CPPF_ERR_HIP, std::string("cppflow_hip: the batch's device table: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return CPPF_OK;
+}
+
+int cppf_lm_batch_launch(const cppf_lm_batch* batch, void* stream) {
+    CPPF_REQUIRE(batch, "batch is NULL");
+    const cppf_robot* robot = batch->robot;
+    CPPF_ENTER(robot);
+    BatchItemK none;
+    std::memset(&none, 0, sizeof none);
+    if (int rc = launch_fused_rows(robot, batch->coll, batch->n_rows, batch->grid, (hipStream_t)stream, batch->prm, none, batch->d_table))
+        return rc;
+    for (const cppf_lm_batch_item& it : batch->after)
+        if (int rc = cppf_seed_summary(robot, it.out.x_out, it.S, it.W, it.out.ext_cost, it.out.pos_err_m, it.out.rot_err_rad,
+                                       it.out.self_mask, it.out.env_mask, it.out.jlim_mask, it.out.seed_summary, stream))
+            return rc;
+    return CPPF_OK;
+}
+
+void cppf_lm_batch_destroy(cppf_lm_batch* batch) {
+    if (!batch) return;
+    {
+        DeviceGuard guard(batch->robot->device);
+        if (batch->d_table) (void)hipFree(batch->d_table);
+    }
+    delete batch;
 }
 
 int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,
@@ -1174,20 +1265,25 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
     return check_launch(robot);
 }
 
+constexpr int kDpResidentMaxK = 1024;  // four destinations per workgroup x 256 compute units (dp_resident_kernel)
+
 // dynamic LDS of dp_backtrace_kernel: the memo table as bytes when it fits (k <= 256, T k <= 60 KB), else 0 = walk it in global memory
 static size_t dp_stage_bytes(int k, int T) { return (k <= 256 && (size_t)k * T <= 60 * 1024) ? (size_t)k * T : 0; }
 
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
-                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
+                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx, int mode,
                    void* stream) {
     CPPF_ENTER(robot);
     CPPF_REQUIRE(k >= 1 && T >= 1, "k, T must be >= 1");
     CPPF_REQUIRE(q && ext_cost && work_qT && work_costsT && work_memoT && best_path && best_idx, "NULL pointer");
     CPPF_REQUIRE((size_t)k * T * robot->desc.ndof <= 0x7fffffffu, "k*T*d exceeds 2^31-1");
+    CPPF_REQUIRE(mode == CPPF_DP_AUTO || mode == CPPF_DP_RESIDENT || mode == CPPF_DP_LAUNCHES, "unknown dp_search mode");
+    CPPF_REQUIRE(mode != CPPF_DP_RESIDENT || k <= kDpResidentMaxK, "CPPF_DP_RESIDENT: the resident launch holds at most 1024 candidates");
     hipStream_t st = (hipStream_t)stream;
     const int d = robot->desc.ndof;
     const size_t total = (size_t)k * T * d;
-    const bool persistent = tune(robot, CPPF_TUNE_DP_PERSISTENT) && k <= 256 && T >= 2;
+    const bool persistent = T >= 2 && k <= kDpResidentMaxK &&
+                            (mode == CPPF_DP_RESIDENT || (mode == CPPF_DP_AUTO && tune(robot, CPPF_TUNE_DP_PERSISTENT)));
     if (persistent)  // every cost word starts as "not yet" (kernels_dp.h); 16-byte multiple, from the allocation's start
         CPPF_HIP(hipMemsetAsync(work_costsT, 0xFF, sizeof(float) * (size_t)k * T, st));
     hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
@@ -1195,13 +1291,23 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     // memo[:,0] is never read by the back-trace's result but is read as a value: define it (search.py:154 zero-inits memo)
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
     if (persistent) {
+        const int spin_log2 = tune(robot, CPPF_TUNE_DP_SPIN_LOG2);
+        const uint32_t spin = spin_log2 <= 0 ? 0u : (1u << (spin_log2 > 30 ? 30 : spin_log2));
         if (k <= 64) {
             CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost,
-                                                 k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT));
-        } else {
+                                                 k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT, spin));
+        } else if (k <= 256) {
             CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
                                                  work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
-                                                 work_memoT));
+                                                 work_memoT, spin));
+        } else if (k <= 512) {  // one source per lane, <= 128 workgroups
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_resident_kernel<D, 1>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
+                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
+                                                 work_memoT, spin));
+        } else {  // two sources per lane, <= 256 workgroups: one per compute unit
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_resident_kernel<D, 2>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
+                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
+                                                 work_memoT, spin));
         }
         hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
                        dp_stage_bytes(k, T) != 0, best_idx,

@@ -39,29 +39,28 @@ constexpr int kBlock = CPPF_BLOCK;
 #include "kernels_fused.h"
 
 template <class Type>
-void launch_one(int coll, unsigned grid, size_t lds, hipStream_t st, const ChainK& ch, const CollK& co, const LmK& prm,
-                const float* x_in, const float* target, const cppf_lm_outputs& out) {
+void launch_one(int coll, unsigned grid, size_t lds, hipStream_t st, const FusedArgs& args) {
     using RB = StaRobot<Type>;
     if (coll == 2)
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid), dim3(kBlock), lds, st, ch, co, prm, x_in, target, out);
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 2>), dim3(grid), dim3(kBlock), lds, st, args.ch, args.co, args.prm, args.single, args.table);
     else if (coll == 1)
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid), dim3(kBlock), lds, st, ch, co, prm, x_in, target, out);
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 1>), dim3(grid), dim3(kBlock), lds, st, args.ch, args.co, args.prm, args.single, args.table);
     else
-        hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid), dim3(kBlock), lds, st, ch, co, prm, x_in, target, out);
+        hipLaunchKernelGGL((lm_fused_kernel<RB, 0>), dim3(grid), dim3(kBlock), lds, st, args.ch, args.co, args.prm, args.single, args.table);
 }
 
 }  // namespace
 
 namespace cppf {
 
-// coll: 0 = no collision stage, 1 = masks / cost, 2 = masks / cost / signed minimum distances (lm_fused_kernel's COLL).
+// coll: 0 = no collision stage, 1 = masks / cost, 2 = masks / cost / signed minimum distances (lm_fused_kernel's COLL).  `args` is the
+// kernel's whole argument segment: one problem (args.single) or a device table of them (args.table, cppf_lm_batch_launch).
 // Returns false for a static_id this unit has no table for (nothing launched); launch errors are the caller's hipGetLastError.
-bool launch_fused_static(int static_id, int coll, unsigned grid, size_t lds, hipStream_t st, const ChainK& ch, const CollK& co,
-                         const LmK& prm, const float* x_in, const float* target, const cppf_lm_outputs& out) {
+bool launch_fused_static(int static_id, int coll, unsigned grid, size_t lds, hipStream_t st, const FusedArgs& args) {
     switch (static_id) {
-#define CPPF_STATIC_LAUNCH(idx, Type)                                       \
-    case idx:                                                               \
-        launch_one<Type>(coll, grid, lds, st, ch, co, prm, x_in, target, out); \
+#define CPPF_STATIC_LAUNCH(idx, Type)                  \
+    case idx:                                          \
+        launch_one<Type>(coll, grid, lds, st, args);   \
         return true;
         CPPF_FOR_EACH_STATIC_ROBOT(CPPF_STATIC_LAUNCH)
 #undef CPPF_STATIC_LAUNCH

@@ -44,8 +44,9 @@ __device__ __forceinline__ void fk_ee(const RB& rb, const float (&q)[RB::D], flo
     fk_fixed_ee(rb, R, p);
 }
 
-// FK keeping every joint's world axis and origin (for the Jacobian)
-template <class RB>
+// FK keeping every joint's world axis and origin (for the Jacobian).  FAST: the hardware's sine / cosine (sincos_hw) -- the leading
+// iterations of a fused K-step launch only.
+template <class RB, bool FAST = false>
 __device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
                                            float (&ax)[RB::D][3], float (&og)[RB::D][3]) {
     frame_identity(R, p);
@@ -57,7 +58,7 @@ __device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D]
             ax[j][i] = R[3 * i + 2];
             og[j][i] = p[i];
         }
-        fk_joint(R, p, rb.pris(j), q[j]);
+        fk_joint<FAST>(R, p, rb.pris(j), q[j]);
     }
     fk_fixed_ee(rb, R, p);
 }
@@ -368,6 +369,12 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
 constexpr int kGateSlots = 8;
 // floats of LDS per wavefront (also what the host sizes the residency claim of small launches by, cppflow_hip.hip)
 constexpr int gate_lds_floats(int d) { return (6 * d + 6 + 2 * (21 + 6)) * kGateSlots; }
+// Upper bound of a fused kernel's STATIC LDS (bytes): the gate's slots of its kBlock / 64 wavefronts (declared for every ndof) + the per-seed
+// summary's staging ((ndof + 8) floats per wavefront) -- static_asserted in lm_fused_kernel next to the declarations, and what the
+// host sizes its residency claim and its 160 KB feasibility check by (cppflow_hip.hip: fused_static_lds).
+constexpr size_t fused_static_lds_bound(int d) {
+    return (size_t)(kBlock / 64) * ((size_t)gate_lds_floats(d) + (size_t)d + 8) * sizeof(float) + 64;
+}
 template <int D>
 struct GateLds {
     // per wavefront: slot s, float element i (J [6][D] at i * D + k, e at 6 D + i) at [i * kGateSlots + s]; behind them, as doubles,

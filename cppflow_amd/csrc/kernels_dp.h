@@ -135,11 +135,18 @@ constexpr uint32_t kDpSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDpQuietNan = 0x7FC00000u;
 constexpr int32_t kDpTimedOut = 0x40000000;
 
-__device__ __forceinline__ float dp_wait_cost(const float* p, int32_t* timed_out_flag) {
+// `spin_budget`: re-reads before a wait gives up (the host passes 2^22, a few seconds; cppf_debug_set(CPPF_TUNE_DP_SPIN_LOG2) shrinks it
+// so that a test can see the timeout path).  Once ANY wait of the launch has expired the launch has no result (dp_backtrace_kernel
+// reports -1), so every later wait looks at the flag every 1024 re-reads and gives up at once when it is up: a CU-masked device pays
+// for ONE expired wait, not for (T - 1) x workgroups of them (minutes of an apparently hung GPU at T = 256).
+__device__ __forceinline__ float dp_wait_cost(const float* p, int32_t* timed_out_flag, uint32_t spin_budget) {
     uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t spins = 0; bits == kDpSentinel && spins < (1u << 22); ++spins) {
+    for (uint32_t spins = 0; bits == kDpSentinel && spins < spin_budget; ++spins) {
         __builtin_amdgcn_s_sleep(1);
         bits = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((spins & 1023u) == 1023u &&
+            (__hip_atomic_load(timed_out_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kDpTimedOut))
+            break;
     }
     if (bits == kDpSentinel) atomicOr(timed_out_flag, kDpTimedOut);
     return bits == kDpSentinel ? INFINITY : __uint_as_float(bits);
@@ -157,7 +164,7 @@ __device__ __forceinline__ void dp_publish_cost(float* p, float v) {
 template <int D>
 __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
                                                            int T, uint32_t pris_mask, float pscale, float* costsT,
-                                                           int32_t* __restrict__ memoT) {
+                                                           int32_t* __restrict__ memoT, uint32_t spin_budget) {
     constexpr int AMAX = 2;
     const int b = blockIdx.x, lane = threadIdx.x;
     const int A = (k + 63) >> 6;  // sources per lane (wave-uniform)
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
         for (int s = 0; s < AMAX; ++s) {
             const int a = lane + 64 * s;
             if (s < A && a < k) {
-                const float c = dp_wait_cost(cost_prev + a, memoT);
+                const float c = dp_wait_cost(cost_prev + a, memoT, spin_budget);
                 const float v = fmaxf(m[s], c) + eb;  // search.py:157-158
                 if (v < best) {
                     best = v;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
 template <int D>
 __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
                                                              int T, uint32_t pris_mask, float pscale, float* costsT,
-                                                             int32_t* __restrict__ memoT) {
+                                                             int32_t* __restrict__ memoT, uint32_t spin_budget) {
     // 512 lanes: lane (h, a) = (tid >> 8, tid & 255) handles source a for destinations 2h and 2h + 1 of the workgroup's four, so
     // the cost-independent part is two (source, destination) pairs per lane on two wavefronts per SIMD -- short enough to finish
     // inside the hand-off latency for every ndof -- while each cost word is still polled by only two lanes per workgroup.
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
         unsigned long long (*img)[256] = keys[t & 1];
         {
             float c = INFINITY;
-            if (a < k) c = dp_wait_cost(cost_prev + a, memoT);
+            if (a < k) c = dp_wait_cost(cost_prev + a, memoT, spin_budget);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float v = fmaxf(m[u], c) + e_now[u];  // search.py:157-158
@@ -273,6 +280,100 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
             unsigned long long key = img[i][lane];
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
+                const unsigned long long o = img[i][lane + 64 * w];
+                key = o < key ? o : key;
+            }
+            key = dp_wave_min_to_lane63(key);
+            if (lane == 63 && b0 + i < k) {
+                memoT[(size_t)t * k + b0 + i] = (int32_t)(uint32_t)key;  // read only by the back-trace launch
+                dp_publish_cost(costsT + (size_t)t * k + b0 + i, dp_key_value(key));
+            }
+        }
+    }
+}
+
+// The resident form for 257 .. 1024 candidates (the reference's rerun searches k = 300, cppflow/planners.py:47, 253-258; eight ranks
+// gather 8 x 128 = 1024): FOUR destinations per 512-lane workgroup again -- at most 256 workgroups, one per compute unit, all
+// resident -- but every lane now owns NS = 1 or 2 SOURCES (tid, tid + 512) and meets all four destinations with them, so that each
+// cost word of step t - 1 is polled by exactly ONE lane of a workgroup (k x k / 4 flag reads per step chip-wide: at k = 1024 one
+// megabyte per polling round, where one wavefront per destination would read four).  The four destinations are the same for every
+// lane: their configurations and external costs are wave-uniform (scalar loads).  Per step: the cost-independent part (NS x 4 wrapped
+// joint changes per lane) and the operand loads of step t + 1 come BEFORE the wait; then each lane waits for its NS words, forms its
+// four (value, index) keys, one 64-bit minimum per destination over its own sources, and the workgroup reduces the four columns of
+// the 512-entry LDS image (wavefront i takes destination i: 8 entries per lane, then DPP); the image is double-buffered by the
+// parity of t, one barrier per step.  Same arithmetic and the same first-minimal-index rule as dp_step_kernel -- the 64-bit key
+// orders (value, index) lexicographically whatever order the sources are visited in.
+template <int D, int NS>
+__global__ __launch_bounds__(512) void dp_resident_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k, int T,
+                                                          uint32_t pris_mask, float pscale, float* costsT,
+                                                          int32_t* __restrict__ memoT, uint32_t spin_budget) {
+    constexpr int BP = 4;
+    __shared__ unsigned long long keys[2][BP][512];
+    const int b0 = blockIdx.x * BP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float qa[NS][D], qb[BP][D], eb[BP];
+    auto load_operands = [&](int t, float (&qa_)[NS][D], float (&qb_)[BP][D], float (&eb_)[BP]) {
+        const float* q_prev = qT + (size_t)(t - 1) * k * D;
+        const float* q_cur = qT + (size_t)t * k * D;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int a = min(tid + 512 * s, k - 1);
+#pragma unroll
+            for (int j = 0; j < D; ++j) qa_[s][j] = q_prev[(size_t)a * D + j];
+        }
+#pragma unroll
+        for (int u = 0; u < BP; ++u) {
+            const int b = min(b0 + u, k - 1);  // wave-uniform
+            eb_[u] = ext[(size_t)b * T + t];
+#pragma unroll
+            for (int j = 0; j < D; ++j) qb_[u][j] = q_cur[(size_t)b * D + j];
+        }
+    };
+    if (T > 1) load_operands(1, qa, qb, eb);
+    for (int t = 1; t < T; ++t) {
+        const float* cost_prev = costsT + (size_t)(t - 1) * k;
+        // ---- independent of the costs ----
+        float m[NS][BP], e_now[BP];
+#pragma unroll
+        for (int u = 0; u < BP; ++u) e_now[u] = eb[u];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int u = 0; u < BP; ++u) {
+                float dq[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    dq[j] = qb[u][j] - qa[s][j];
+                    if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
+                }
+                m[s][u] = max_wrapped_change<D>(dq);
+            }
+        if (t + 1 < T) load_operands(t + 1, qa, qb, eb);  // (in flight during the wait below)
+        // ---- dependent: wait for exactly the costs this lane reads ----
+        unsigned long long best[BP];
+#pragma unroll
+        for (int u = 0; u < BP; ++u) best[u] = dp_key(INFINITY, 0);  // lanes / sources beyond k carry (+inf, 0), like the idle lanes of dp_step_kernel
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int a = tid + 512 * s;
+            if (a < k) {
+                const float c = dp_wait_cost(cost_prev + a, memoT, spin_budget);
+#pragma unroll
+                for (int u = 0; u < BP; ++u) {
+                    const float v = fmaxf(m[s][u], c) + e_now[u];  // search.py:157-158
+                    const unsigned long long key = dp_key(v < INFINITY ? v : INFINITY, v < INFINITY ? a : 0);
+                    best[u] = key < best[u] ? key : best[u];
+                }
+            }
+        }
+        unsigned long long (*img)[512] = keys[t & 1];
+#pragma unroll
+        for (int u = 0; u < BP; ++u) img[u][tid] = best[u];
+        __syncthreads();
+        if (wave < BP) {
+            const int i = wave;
+            unsigned long long key = img[i][lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
                 const unsigned long long o = img[i][lane + 64 * w];
                 key = o < key ? o : key;
             }

@@ -114,23 +114,29 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
 
 // ---- one row of the fused launch, in three pieces: load, one LM iteration, finish (store, metrics, collision stage) -----------
 template <class RB>
-__device__ __forceinline__ void lm_row_load(const LmK& prm, const float* __restrict__ x_in, const float* __restrict__ target,
+__device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_in, const float* __restrict__ target,
                                             size_t row, float (&q)[RB::D], float (&Rt)[9], float (&tt)[3]) {
     load_x<RB::D>(x_in, row, q);
-    load_target(target, (int)(row % (size_t)prm.W), Rt, tt);
+    load_target(target, (int)((uint32_t)row % (uint32_t)W), Rt, tt);
 }
 
 // One LM iteration of one row.  Returns true when the row was ALREADY converged at this linearisation point (early-out
 // tolerances of cppf_lm_params, off when 0): such a row is left untouched -- the reference's loop likewise stops stepping
 // once the pose is valid (cppflow/optimization.py:251-258, 326-358).
 // The damped solve is conditioning-gated (kernels_chain.h): a row whose fp32 solve is estimated to be off by more than the gate's
-// tolerance is re-solved in double precision by a lane of its own wavefront through an LDS slot.  The common case -- no row of
-// the wavefront flagged -- is straight-line code behind ONE scalar branch.  Inside a clamped loop (K > 1) a row whose fp32 step
-// leaves the joint limits is not re-solved: where it lands is decided by the clamp, not by the last digits of the solve (these
-// are the rows that sit against a limit iteration after iteration; re-solving them bought nothing and put one wavefront per
-// such row 2 us per iteration behind the others).  The single bare step (clamp = 0, the reference's own cadence) re-solves every
-// flagged row.
-template <class RB>
+// tolerance is re-solved in double precision by its wavefront through LDS slots.  The common case -- no row of the wavefront
+// flagged -- is straight-line code behind ONE scalar branch.  Under CPPF_SOLVER_AUTO inside a clamped loop a row whose fp32 step
+// leaves the joint limits is not re-solved: where it lands is decided by the clamp, not by the last digits of the solve (these are
+// the rows that sit against a limit iteration after iteration; re-solving them bought nothing and put one wavefront per such row
+// 2 us per iteration behind the others).  CPPF_SOLVER_F64 (gate_thr = -inf) re-solves EVERY row, clamped or not, as the header
+// promises; so does the single bare step (clamp = 0, the reference's own cadence).
+//
+// Two instantiations per kernel.  LEAD = true is a LEADING iteration of a plain K-step launch (iterations 0 .. K-2, the hot loop):
+// the hardware's sine / cosine (sincos_hw: 3 instructions per joint instead of 23, 4e-7 absolute), no early-out tests, no J / e
+// outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration in the canonical arithmetic: the LAST
+// iteration of every launch -- so x_out is always one canonical LM step from its predecessor, and a K = 1 launch (the reference's
+// cadence) is canonical throughout -- and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
+template <class RB, bool LEAD>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
                                                const float (&Rt)[9], const float (&tt)[3], float* __restrict__ gate_lds,
                                                float (&q)[RB::D]) {
@@ -139,11 +145,13 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
     bool conv = false;
     {
         float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6];
-        fk_ee_axes<RB>(rb, q, R, p, ax, og);
+        fk_ee_axes<RB, LEAD>(rb, q, R, p, ax, og);
         pose_error(Rt, tt, R, p, e);
-        if (prm.tol_pos2 > 0.f) {  // wave-uniform
-            conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
-            if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
+        if constexpr (!LEAD) {
+            if (prm.tol_pos2 > 0.f) {  // wave-uniform
+                conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
+                if (__builtin_amdgcn_ballot_w64(!conv) == 0ull) return true;  // every row of the wavefront is done: skip the solve
+            }
         }
         jacobian_from_axes<RB>(rb, p, ax, og, J);
         float est = 0.f;
@@ -154,24 +162,26 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
             lm_dual_solve_y<D>(J, e, prm.lam_r, prm.lam_p, y, est);
             lm_dual_apply<D>(J, y, delta);
         }
-        if (last) {
-            // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
-            if (out.J_out) {
-                float* Jo = out.J_out + row * 6 * D;
+        if constexpr (!LEAD) {
+            if (last) {
+                // the reference returns J and e scaled in place (optimization.py:77-80, 90-92)
+                if (out.J_out) {
+                    float* Jo = out.J_out + row * 6 * D;
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
+                    for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
-            }
-            if (out.e_out) {
+                        for (int j = 0; j < D; ++j) Jo[i * D + j] = J[i][j] * (i < 3 ? prm.a_rot : prm.a_pos);
+                }
+                if (out.e_out) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+                    for (int i = 0; i < 6; ++i) out.e_out[row * 6 + i] = e[i] * (i < 3 ? prm.a_rot : prm.a_pos);
+                }
             }
         }
         if constexpr (D >= 6) {
             bool flag = !conv && est > prm.gate_thr;  // NaN: not flagged (the row is NaN either way)
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(flag) != 0ull, 0)) {  // wave-uniform; rare
-                if (prm.clamp) {
+                if (prm.clamp && prm.gate_thr > -INFINITY) {  // (CPPF_SOLVER_AUTO only: the all-rows mode re-solves all rows)
                     bool cut = false;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
@@ -190,7 +200,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
                         float R2[9], p2[3], ax2[D][3], og2[D][3], J2[6][D], e2[6];
 #pragma unroll
                         for (int j = 0; j < D; ++j) asm volatile("" : "+v"(q[j]));  // (unchanged, but the compiler must not know)
-                        fk_ee_axes<RB>(rb, q, R2, p2, ax2, og2);
+                        fk_ee_axes<RB, LEAD>(rb, q, R2, p2, ax2, og2);
                         pose_error(Rt, tt, R2, p2, e2);
                         jacobian_from_axes<RB>(rb, p2, ax2, og2, J2);
                         rank = lm_gate_hand_over<D>(J2, e2, todo, gate_lds, flag);
@@ -200,13 +210,15 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
             }
         }
     }
-    if (prm.tol_pos2 > 0.f) {  // wave-uniform: the predicated update only exists on the early-out path
-        if (!conv) {
+    if constexpr (!LEAD) {
+        if (prm.tol_pos2 > 0.f) {  // wave-uniform: the predicated update only exists on the early-out path
+            if (!conv) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) q[j] += delta[j];
-            if (prm.clamp) clamp_row<RB>(rb, q);
+                for (int j = 0; j < D; ++j) q[j] += delta[j];
+                if (prm.clamp) clamp_row<RB>(rb, q);
+            }
+            return conv;
         }
-        return conv;
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) q[j] += delta[j];
@@ -276,30 +288,84 @@ constexpr int lm_waves() {
     return RB::kStatic ? (RB::D <= 7 ? 4 : 3) : (RB::D <= 6 ? 4 : (RB::D <= 8 ? 3 : 2));
 }
 
+// A pointer that was loaded from memory is a generic one to the compiler (flat_load / flat_store, which also count on the LDS
+// counter lgkmcnt -- the per-seed summary's LDS-only barrier would then wait for the row's output stores after all); the buffers of
+// a launch are global memory by contract, so say so: the address-space round trip is what LLVM's InferAddressSpaces keys on.
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+    return (T*)(__attribute__((address_space(1))) T*)p;
+}
+
+typedef const __attribute__((address_space(4))) BatchItemK* BatchItemPtr;
+
+// The problem this workgroup belongs to, and the workgroup's index within it.  Plain launch (a.table == NULL): FusedArgs::single in
+// the kernel-argument segment, blockIdx.x.  Batched launch: entry b of the device table, b from ONE 64-byte scalar load of the
+// cumulative workgroup counts and CPPF_MAX_BATCH - 1 scalar compares.  Either way a constant-address-space pointer: every field is
+// fetched with a scalar load when (and where) it is needed, nothing is copied into registers up front.
+__device__ __forceinline__ BatchItemPtr fused_item(const void* table, uint32_t& blk) {
+    typedef const __attribute__((address_space(4))) char* CPtr;
+    blk = blockIdx.x;
+    // (the kernel's arguments are laid out like the members of FusedArgs -- in order, each at its natural alignment -- which
+    // tests/test_abi.py checks against the code object's own argument offsets)
+    BatchItemPtr itp = (BatchItemPtr)((CPtr)__builtin_amdgcn_kernarg_segment_ptr() + __builtin_offsetof(FusedArgs, single));
+    if (table) {  // wave-uniform
+        const CPtr tab = (CPtr)(uintptr_t)table;
+        const __attribute__((address_space(4))) BatchHeadK* hd = (const __attribute__((address_space(4))) BatchHeadK*)tab;
+        uint32_t b = 0, begin = 0;
+#pragma unroll
+        for (int i = 0; i < CPPF_MAX_BATCH - 1; ++i) {
+            const uint32_t e = hd->block_end[i];
+            const bool past = blk >= e;
+            b = past ? (uint32_t)(i + 1) : b;
+            begin = past ? e : begin;
+        }
+        blk -= begin;
+        itp = (BatchItemPtr)(tab + sizeof(BatchHeadK)) + b;
+    }
+    return itp;
+}
+
+__device__ __forceinline__ cppf_lm_outputs fused_outputs(BatchItemPtr itp) {
+    cppf_lm_outputs o;
+    o.x_out = as_global(itp->out.x_out), o.J_out = as_global(itp->out.J_out), o.e_out = as_global(itp->out.e_out);
+    o.pos_err_m = as_global(itp->out.pos_err_m), o.rot_err_rad = as_global(itp->out.rot_err_rad);
+    o.self_mask = as_global(itp->out.self_mask), o.env_mask = as_global(itp->out.env_mask), o.jlim_mask = as_global(itp->out.jlim_mask);
+    o.ext_cost = as_global(itp->out.ext_cost), o.min_self = as_global(itp->out.min_self), o.min_env = as_global(itp->out.min_env);
+    o.seed_summary = as_global(itp->out.seed_summary), o.n_iters = as_global(itp->out.n_iters);
+    return o;
+}
+
 // COLL: 0 = no collision stage, 1 = masks / cost only (no square roots), 2 = masks / cost and the signed minimum distances.
 // out.seed_summary (host: only when W is 64, 128 or 256 and COLL != 0) adds the per-seed reduction as an epilogue.
 // The precision of the damped solve is a run-time parameter (prm.gate_thr, lm_solve_gated).
 // Registers: the masks-only instantiations of the shipped robots need <= 128 VGPRs without being told to (Panda 115; round 2
 // needed a second, occupancy-capped build with 36 B of scratch per lane for that), so all four wavefronts per SIMD of a
 // 262 144-row launch are resident at once and no launch touches scratch.
+// One grid serves ONE problem (cppf_lm_pose_steps) or up to CPPF_MAX_BATCH independent ones laid end to end (cppf_lm_batch_launch):
+// each workgroup belongs to exactly one problem (fused_item), so a problem's rows see exactly the code of a launch of their own.
 template <class RB, int COLL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves<RB>(), lm_waves<RB>()))) void lm_fused_kernel(const ChainK ch, const CollK co, const LmK prm,
-                                                          const float* __restrict__ x_in,
-                                                          const float* __restrict__ target, const cppf_lm_outputs out) {
+                                                          const BatchItemK single, const void* table) {
     extern __shared__ float lds[];
+    (void)single;  // read through the kernel-argument segment's address (fused_item), like a table entry
     constexpr int D = RB::D;
     __shared__ float s_gate[kBlock / 64][GateLds<D>::kFloats];  // the conditioning gate's slots, per wavefront (lm_solve_gated)
+    // (+ block_seed_summary's s_q [kBlock / 64][D] and s_red [kBlock / 64][8]: the host's bound must cover all of it)
+    static_assert(sizeof(s_gate) + (kBlock / 64) * (D + 8) * sizeof(float) <= fused_static_lds_bound(D), "fused_static_lds_bound is stale");
     const RB rb{ch, co};
+    uint32_t blk;
+    const BatchItemPtr itp = fused_item(table, blk);
+    const cppf_lm_outputs out = fused_outputs(itp);
     const int tid = threadIdx.x;
-    const size_t row = (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid);  // n < 2^31 (host): one register across the LM loop
-    const bool active = row < (size_t)prm.n;
+    const size_t row = (size_t)(blk * (unsigned)kBlock + (unsigned)tid);  // n < 2^31 (host): one register across the LM loop
+    const bool active = row < (size_t)itp->n;
     float q[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) q[j] = 0.f;
     RowSummary rs;
     if (active) {
         float Rt[9], tt[3];
-        lm_row_load<RB>(prm, x_in, target, row, q, Rt, tt);
+        lm_row_load<RB>(itp->W, as_global(itp->x_in), as_global(itp->target), row, q, Rt, tt);
         // A non-finite input stays non-finite in the reference (torch.clamp and the solve propagate NaN); here fminf / fmaxf
         // of the clamp would turn it into a joint limit, so such a row is poisoned after the loop instead (once per launch).
         float chk = tt[0] + tt[1] + tt[2];
@@ -312,9 +378,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
         unsigned long long bad_mask = __builtin_amdgcn_ballot_w64(!(fabsf(chk) < INFINITY));
         asm volatile("" : "+s"(bad_mask));
         float* const gate_lds = s_gate[__builtin_amdgcn_readfirstlane(tid >> 6)];  // wave-uniform: a scalar base
-        int iters = 0;
-        for (int it = 0; it < prm.n_steps; ++it) {
-            const bool conv = lm_row_iterate<RB>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, gate_lds, q);
+        int iters = 0, it = 0;
+        // the hot loop: the K - 1 leading iterations of a plain launch (lm_row_iterate<LEAD = true>)
+        if (!(prm.tol_pos2 > 0.f)) {  // wave-uniform
+            for (; it < prm.n_steps - 1; ++it) (void)lm_row_iterate<RB, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
+            iters = it;
+        }
+        // the general iteration: the last one of a plain launch, every one of an early-out launch
+        for (; it < prm.n_steps; ++it) {
+            const bool conv = lm_row_iterate<RB, false>(rb, prm, out, row, it == prm.n_steps - 1, Rt, tt, gate_lds, q);
             iters += conv ? 0 : 1;
             if (prm.tol_pos2 > 0.f && __builtin_amdgcn_ballot_w64(!conv) == 0ull) break;
         }
@@ -323,7 +395,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
         // (the last ones it spilled to scratch at 128 VGPRs): the loop itself only needs the index when it stores J / e.
         int tid_b = threadIdx.x;
         asm volatile("" : "+v"(tid_b));
-        const size_t row_b = (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid_b);
+        const size_t row_b = (size_t)(blk * (unsigned)kBlock + (unsigned)tid_b);
         if (out.n_iters) out.n_iters[row_b] = iters;
         if ((bad_mask >> (tid_b & 63)) & 1ull) {
 #pragma unroll
@@ -335,7 +407,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
         if (out.seed_summary) {
             int tid_c = threadIdx.x;
             asm volatile("" : "+v"(tid_c));
-            block_seed_summary<RB>(rb, prm.W, (size_t)(blockIdx.x * (unsigned)kBlock + (unsigned)tid_c), active, q, rs, out.seed_summary);
+            block_seed_summary<RB>(rb, itp->W, (size_t)(blk * (unsigned)kBlock + (unsigned)tid_c), active, q, rs, out.seed_summary);
         }
     }
 }

@@ -297,8 +297,19 @@ __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const
     {
         const float dmax = fmaxf(fmaxf(fmaxf(A[0][0], A[1][1]), A[2][2]) + lam_r, fmaxf(fmaxf(A[3][3], A[4][4]), A[5][5]) + lam_p);
         const float ymax = fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))), fmaxf(fabsf(y[4]), fabsf(y[5])));
-        const bool flag = !conv && dmax * ymax > prm.gate_thr;  // the same value in the quad's four lanes; NaN: not flagged
-        if (__builtin_amdgcn_ballot_w64(flag) != 0ull) {      // wave-uniform
+        bool flag = !conv && dmax * ymax > prm.gate_thr;  // the same value in the quad's four lanes; NaN: not flagged
+        if (__builtin_amdgcn_ballot_w64(flag) != 0ull) {  // wave-uniform
+            // the same rule as the row shape (lm_row_iterate): under CPPF_SOLVER_AUTO inside a clamped launch a flagged row whose
+            // fp32 step leaves the joint limits keeps that step -- a row's precision must not depend on which shape the batch size picked
+            if (prm.clamp && prm.gate_thr > -INFINITY) {
+                bool cut = false;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float v = q[j] + delta[j];
+                    cut |= (v < rb.lo(j)) | (v > rb.hi(j));
+                }
+                flag = flag && !cut;
+            }
             float Jf[6][D], d64[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {

@@ -67,6 +67,36 @@ struct LmK {
                                // solve in double precision (lm_solve_gated); +inf = never (pure fp32), -inf = always (pure fp64)
 };
 
+// One problem of a fused launch: what cppf_lm_pose_steps takes as (x_in, target, S * W, W, outputs).  The same layout sits in the
+// kernel-argument segment (FusedArgs::single, the plain launch) and, for a batched launch (cppf_lm_batch_*), in a device table of
+// these behind a BatchHeadK -- the kernel picks one or the other base address and reads the fields with scalar loads either way.
+struct BatchItemK {
+    const float* x_in;
+    const float* target;
+    cppf_lm_outputs out;
+    int32_t n, W;
+};
+
+// Head of the device table of a batched launch: block_end[i] = number of workgroups of items 0 .. i (cumulative; entries past the
+// last item are 0xffffffff), so that a workgroup finds its item with CPPF_MAX_BATCH - 1 scalar compares on ONE 64-byte scalar load.
+struct BatchHeadK {
+    uint32_t block_end[CPPF_MAX_BATCH];
+};
+
+// The fused kernel's kernel-argument segment: lm_fused_kernel(ChainK, CollK, LmK, BatchItemK single, const void* table) takes these
+// five by value, and the segment lays arguments out like the members of a struct (in order, natural alignment), so `single` sits at
+// offsetof(FusedArgs, single) from the segment's base -- which is what lets the kernel address it through the same
+// constant-address-space pointer type as a table entry.  (One struct argument instead was tried: clang copies a by-value struct
+// argument to private memory and relies on the optimiser to elide the copy; with the generic kernels' run-time capsule indices it did
+// not, and the 3.6 KB copy went to scratch.)  The host carries a launch's arguments in one of these.
+struct FusedArgs {
+    ChainK ch;
+    CollK co;
+    LmK prm;            // (prm.n / prm.W are NOT read by the fused kernel: the item's are)
+    BatchItemK single;  // the problem of a plain launch
+    const void* table;  // NULL, or the device table { BatchHeadK ; BatchItemK[n_items] } of a batched launch
+};
+
 // ---- multiply / fma by a chain constant --------------------------------------------------------------------------------------
 // In the robot-specialised instantiations every chain constant is a literal after unrolling; 0 and +-1 are peeled off
 // here.  Each shortcut returns exactly what the general fmaf would (x*1 and acc + x*1 round once either way; x*0 and
@@ -153,6 +183,16 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
     c = __uint_as_float(co);
 }
 
+// The hardware's own sine / cosine (v_sin_f32 / v_cos_f32 take REVOLUTIONS, valid for |x| <= 256 of them; joint angles are bounded by
+// the joint limits): 3 instructions instead of 23, 4e-7 of absolute error (scripts/ubench/hw_sincos.hip).  Used ONLY by the leading
+// iterations of a fused K-step launch, whose iterates nobody sees: the last iteration -- the one that decides x_out -- every iteration
+// of an early-out launch, and everything in the bit-exact set (FK, capsules, metrics, masks) use sincos_cw.
+__device__ __forceinline__ void sincos_hw(float x, float& s, float& c) {
+    const float r = x * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+}
+
 // ---- canonical FK steps ---------------------------------------------------------------------------------------------------
 // frame <- frame * F      (F = 12 wave-uniform floats: R row-major, t)
 __device__ __forceinline__ void fk_fixed(float (&R)[9], float (&p)[3], const float (&F)[12]) {
@@ -187,10 +227,14 @@ __device__ __forceinline__ void fk_fixed_ee(const RB& rb, float (&R)[9], float (
 }
 
 // frame <- frame * M_z(q): rotation about (revolute) or translation along (prismatic) the local z axis
+template <bool FAST = false>
 __device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool prismatic, float q) {
     if (!prismatic) {
         float s, c;
-        sincos_cw(q, s, c);
+        if constexpr (FAST)
+            sincos_hw(q, s, c);
+        else
+            sincos_cw(q, s, c);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             // a0, a1 are literals for the first joint of a specialised chain (R = F_0): cmul / cfma fold the 0 / +-1 cases

@@ -430,6 +430,15 @@ class Robot:
         return LmLaunchPlan(self, x, target, lm_lambda, alpha_position, alpha_rotation, n_steps, x_out, packed_out, clamp,
                             summary_out, shape, solver, errors_out)
 
+    def lm_batch_plan(self, items: Sequence[dict], lm_lambda: float, alpha_position: float, alpha_rotation: float, n_steps: int,
+                      clamp: bool = True, solver: int = _hip.SOLVER_AUTO) -> "LmBatchPlan":
+        """Several INDEPENDENT problems of this robot in ONE fused launch (cppf_lm_batch_*; at most `_hip.MAX_BATCH`): what a planner
+        serving several requests holds on to, and what a GPU that owns only a shard of the candidate seeds needs to fill the chip.
+        Each item is a dict with `x` [S*W, d], `target` [W, 7], `x_out` [S*W, d] and optionally `packed_out` (15 bytes per row: cost,
+        pose errors, masks -- makes it a launch with the collision stage), `summary_out` [S, 8], `errors_out` = (pos_err_m [n],
+        rot_err_rad [n]).  Every problem's results are bit for bit those of `lm_pose_steps` / `lm_launch_plan` on it alone."""
+        return LmBatchPlan(self, items, lm_lambda, alpha_position, alpha_rotation, n_steps, clamp, solver)
+
     def select_valid_seed(self, seed_summary: torch.Tensor, constraints, self_collisions_ignored: bool = False,
                           env_collisions_ignored: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x_is_valid's seed selection (cppflow/optimization_utils.py:856-909) over [S,8] per-seed summaries (one GPU's, or
@@ -583,12 +592,14 @@ class Robot:
         return x_out
 
     def dp_search(self, q: torch.Tensor, ext_cost: torch.Tensor, prismatic_joint_scaling: float = 5.0, method: str = "auto",
-                  return_memo: bool = False):
+                  return_memo: bool = False, return_method: bool = False):
         """q [k,T,d], ext_cost [k,T] -> (best_path [T,d], best_idx [T] int32, cost table [T,k]); cppflow/search.py:128-191.
         `method`: "table" (k <= 256: transition table + the recurrence on one compute unit, cppf_dp_search_tabled), "resident"
-        (cppf_dp_search: resident workgroups handing the cost row on, or one launch per waypoint beyond k = 256), "auto" = whichever
-        is faster at this k (table up to 128 candidates, 192 for chains of more than 8 joints).  Bit-identical results."""
-        assert method in ("auto", "table", "resident"), method
+        (cppf_dp_search: ONE launch of resident workgroups handing the cost row on up to k = 1024, one launch per waypoint beyond),
+        "launches" (one launch per waypoint, any k -- for THIS call, no handle state involved), "auto" = whichever is fastest at this k
+        (table up to 128 candidates, 192 for chains of more than 8 joints; resident up to 1024; launches beyond).  Bit-identical results.
+        `return_method` appends the method that ran ("table" / "resident" / "launches") to the result."""
+        assert method in ("auto", "table", "resident", "launches"), method
         q = _require_device_tensor(q, "q")
         ext_cost = _require_device_tensor(ext_cost, "q_costs_external")
         assert q.dim() == 3 and q.shape[2] == self.ndof, tuple(q.shape)
@@ -609,6 +620,7 @@ class Robot:
         k_table = 128 if d <= 8 else 192
         tabled = method == "table" or (method == "auto" and k <= k_table and 2 <= T <= 65536 and n_table.value * 4 <= (1 << 30))
         if tabled:
+            ran = "table"
             table = torch.empty(max(n_table.value, 1), dtype=torch.float32, device=dev)
             _hip.check(
                 _hip.lib().cppf_dp_search_tabled(
@@ -618,15 +630,19 @@ class Robot:
                 )  # fmt: skip
             )
         else:
+            # ("resident" = this entry point as it decides itself, i.e. resident up to 1024 candidates unless the handle's
+            # CPPF_TUNE_DP_PERSISTENT test switch is 0; "launches" forces one launch per waypoint for this call only)
+            mode = _hip.DP_LAUNCHES if method == "launches" else _hip.DP_AUTO
+            resident_on = self._tuning.get(_hip.TUNE_KEYS["dp_persistent"], 1) not in (0,)
+            ran = "resident" if T >= 2 and k <= 1024 and mode == _hip.DP_AUTO and resident_on else "launches"
             _hip.check(
                 _hip.lib().cppf_dp_search(
                     self._handle(dev), q.data_ptr(), ext_cost.data_ptr(), k, T, float(prismatic_joint_scaling), qT.data_ptr(),
-                    costsT.data_ptr(), memoT.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(), _stream_ptr(dev),
+                    costsT.data_ptr(), memoT.data_ptr(), best_path.data_ptr(), best_idx.data_ptr(), mode, _stream_ptr(dev),
                 )  # fmt: skip
             )
-        if return_memo:
-            return best_path, best_idx, costsT, memoT
-        return best_path, best_idx, costsT
+        res = (best_path, best_idx, costsT) + ((memoT,) if return_memo else ())
+        return res + ((ran,) if return_method else ())
 
     def plan_metrics(self, x: torch.Tensor, target: torch.Tensor, self_mask: Optional[torch.Tensor] = None,
                      env_mask: Optional[torch.Tensor] = None, q_init: Optional[torch.Tensor] = None) -> torch.Tensor:  # fmt: skip
@@ -772,6 +788,75 @@ class LmLaunchPlan:
                 _hip.check(rc)
 
         return launch
+
+
+class LmBatchPlan:
+    """`Robot.lm_batch_plan`: owns a cppf_lm_batch (a device table of the items' pointers) and references to every buffer in it."""
+
+    def __init__(self, robot: Robot, items, lm_lambda, alpha_position, alpha_rotation, n_steps, clamp=True, solver=_hip.SOLVER_AUTO):
+        assert 1 <= len(items) <= _hip.MAX_BATCH, f"a batch holds 1 .. {_hip.MAX_BATCH} problems"
+        arr = (_hip.LmBatchItem * len(items))()
+        self._keep, self.outputs, dev = [robot], [], None
+        for i, it in enumerate(items):
+            x = robot._x2d(it["x"])
+            target = _require_device_tensor(it["target"], "target_path")
+            x_out = _require_output_tensor(it["x_out"], "x_out")
+            n, W = x.shape[0], target.shape[0]
+            assert target.dim() == 2 and target.shape[1] == 7 and W > 0 and n % W == 0 and x_out.shape == x.shape
+            dev = x.device if dev is None else dev
+            assert x.device == dev and target.device == dev and x_out.device == dev, "every buffer of a batch lives on one device"
+            arr[i].x_in, arr[i].target, arr[i].S, arr[i].W = x.data_ptr(), target.data_ptr(), n // W, W
+            out, views = arr[i].out, {"x": x_out}
+            out.x_out = x_out.data_ptr()
+            self._keep += [x, target, x_out]
+            packed = it.get("packed_out")
+            if packed is not None:
+                assert packed.dtype == torch.uint8 and packed.is_cuda and packed.is_contiguous() and packed.device == dev
+                assert packed.numel() == robot.PACKED_BYTES_PER_ROW * n and packed.data_ptr() % 4 == 0
+                f, m = packed[: 12 * n].view(torch.float32), packed[12 * n :]
+                v = dict(ext_cost=f[:n], pos_err_m=f[n : 2 * n], rot_err_rad=f[2 * n :], self_mask=m[:n], env_mask=m[n : 2 * n],
+                         jlim_mask=m[2 * n :])  # fmt: skip
+                for k, t in v.items():
+                    setattr(out, k, t.data_ptr())
+                views.update(v)
+                self._keep.append(packed)
+            if it.get("errors_out") is not None:
+                assert packed is None, "packed_out already holds the pose errors"
+                pe, re = (_require_output_tensor(t, nm) for t, nm in zip(it["errors_out"], ("pos_err_m", "rot_err_rad")))
+                assert pe.numel() == n and re.numel() == n
+                out.pos_err_m, out.rot_err_rad = pe.data_ptr(), re.data_ptr()
+                views.update(pos_err_m=pe, rot_err_rad=re)
+                self._keep += [pe, re]
+            if it.get("summary_out") is not None:
+                _check_summary_buffer(it["summary_out"], n // W, dev)
+                out.seed_summary = it["summary_out"].data_ptr()
+                views["seed_summary"] = it["summary_out"]
+                self._keep.append(it["summary_out"])
+            self.outputs.append(views)
+        prm = _hip.LmParams(float(lm_lambda), float(alpha_position), float(alpha_rotation), int(n_steps), int(bool(clamp)),
+                            0.0, 0.0, _hip.SHAPE_ROW, int(solver))
+        self._h = ctypes.c_void_p()
+        self._lib = _hip.lib()
+        _hip.check(self._lib.cppf_lm_batch_create(robot._handle(dev), len(items), arr, ctypes.byref(prm), ctypes.byref(self._h)))
+        self._fn, self._device, self.n_items = self._lib.cppf_lm_batch_launch, dev, len(items)
+
+    def launch(self) -> None:
+        rc = self._fn(self._h, torch.cuda.current_stream(self._device).cuda_stream)
+        if rc:
+            _hip.check(rc)
+
+    def launch_on(self, stream: "torch.cuda.Stream") -> None:
+        rc = self._fn(self._h, stream.cuda_stream)
+        if rc:
+            _hip.check(rc)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            try:
+                self._lib.cppf_lm_batch_destroy(h)
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
 
 
 def get_robot(name: str) -> Robot:

@@ -54,7 +54,7 @@ def dp_search(
     q_costs: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """min-max dynamic programme over k candidate paths (cppflow/search.py:128-191) -> best path [T, d], on the device
-    (`cppf_dp_search`: one small launch per timestep; the reference moves q to the CPU, `search.py:140-141`).
+    (`cppf_dp_search`: one resident launch up to 1024 candidates; the reference moves q to the CPU, `search.py:140-141`).
 
     The external cost is `100*jlim + 1000*env + 1000*self` (`:146-150`): pass the two violation masks like the reference
     does, or `q_costs` directly (the `ext_cost` output of the collision / fused launch)."""
@@ -66,15 +66,14 @@ def dp_search(
             + K_COLLISION_COST * env_collision_violations.to(q.device, torch.float32)
             + K_COLLISION_COST * self_collision_violations.to(q.device, torch.float32)
         )
-    best_path, best_idx, _ = robot.dp_search(q, q_costs.contiguous())
-    if k <= 256 and int(best_idx[0].item()) < 0:
-        # the single resident launch (k <= 256 where the table form is not the faster one) could not hand its cost rows from workgroup to workgroup
-        # (include/cppflow_hip.h, cppf_dp_search): one launch per waypoint instead
-        robot.debug_set("dp_persistent", 0)
-        try:
-            best_path, best_idx, _ = robot.dp_search(q, q_costs.contiguous())
-        finally:
-            robot.debug_set("dp_persistent")
+    q_costs = q_costs.contiguous()
+    best_path, best_idx, _, ran = robot.dp_search(q, q_costs, return_method=True)
+    # Only the single resident launch can fail this way (its bounded waits expire on a CU-masked / partitioned device: it then
+    # reports best_idx = -1, include/cppflow_hip.h: cppf_dp_search); the table and per-waypoint forms cannot, so they are not asked
+    # (no host synchronisation on their account).  The fall-back is an argument of the repeated CALL -- one launch per waypoint --
+    # not a switch on the robot handle: another thread's searches on the same robot are not affected, and no setting is lost.
+    if ran == "resident" and int(best_idx[0].item()) < 0:
+        best_path, best_idx, _ = robot.dp_search(q, q_costs, method="launches")
     return best_path
 
 

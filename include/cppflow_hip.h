@@ -38,12 +38,13 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 4
+#define CPPF_ABI_VERSION 5
 
 #define CPPF_MAX_DOF 12 /* every ndof in 3..12 is built (the reference's robots have 7 and 8) */
 #define CPPF_MAX_CAPSULES 24
 #define CPPF_MAX_PAIRS 128
 #define CPPF_MAX_OBSTACLES 8
+#define CPPF_MAX_BATCH 16 /* independent problems one batched fused launch can carry (cppf_lm_batch_create) */
 
 #define CPPF_OK 0
 #define CPPF_ERR_INVALID (-1)
@@ -76,7 +77,11 @@ typedef struct cppf_lm_params {
     float lm_lambda;      /* OptimizationParameters.lm_lambda      (ALT_LOSS_V2_1_POSE: 1e-6, :123) */
     float alpha_position; /* OptimizationParameters.alpha_position (3.5,  :125) */
     float alpha_rotation; /* OptimizationParameters.alpha_rotation (0.35, :126) */
-    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration) */
+    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration).  The LAST
+                           * iteration of a launch -- the one that produces x_out -- is always evaluated in the canonical arithmetic
+                           * (the sine / cosine the bit-exact FK uses); the K - 1 iterations before it, whose iterates are not
+                           * outputs, use the hardware's v_sin_f32 / v_cos_f32 (4e-7 absolute) in the row shape.  A K = 1 launch (the
+                           * reference's cadence) and every iteration of an early-out launch are canonical throughout. */
     int32_t clamp;        /* 1: clamp_to_joint_limits after every step (the reference loop); 0: bare step (K must be 1) */
     /* Early-out (0 = off): a row whose residual at the start of an iteration has ||t_target - t|| < tol_pos_m and
      * ||(roll, pitch, yaw)|| < tol_rot_rad is left untouched from then on, and a wavefront whose rows are all below
@@ -93,8 +98,10 @@ typedef struct cppf_lm_params {
      *     and factoring A = J J^T + lambda S^-2, known once y = A^-1 e is) exceeds `solver_gate` redoes the solve in double
      *     precision.  The step is then never farther from the exactly solved one than the reference's own fp32 arithmetic
      *     (torch.linalg.solve on the primal system, cppflow/optimization.py:85-88) gets -- near-singular rows included.
+     *     One exception, inside a clamped launch (clamp = 1): a flagged row whose fp32 step leaves the joint limits keeps the fp32
+     *     step -- where it lands is decided by the clamp, not by the last digits of the solve.
      *   CPPF_SOLVER_F64: every row in double precision (J J^T, its factorisation, the substitutions and J^T y): the exactly
-     *     solved step of the fp32 Jacobian on every row (task-space difference to the fp64 oracle <= 6e-7).  A verification mode: every
+     *     solved step of the fp32 Jacobian on every row, clamped or not (task-space difference to the fp64 oracle <= 6e-7).  A verification mode: every
      *     wavefront runs eight re-solve rounds per iteration (~10x the iteration time).
      *   CPPF_SOLVER_F32: fp32 only, no gate (the round-2 behaviour; up to 6e-2 off in task space on near-singular rows). */
     int32_t solver;
@@ -187,6 +194,32 @@ int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* s
  * cost (cppflow/collision_detection.py:27-69, cppflow/search.py:146-150) of the result evaluated in the same launch. */
 int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* target, int S, int W,
                        const cppf_lm_params* params, const cppf_lm_outputs* out, void* stream);
+
+/* Several INDEPENDENT problems of the same robot in ONE launch of the same kernel (row shape).  The reference's entry point takes one
+ * problem per call (run_lm_optimization, cppflow/optimization.py:376-426; its parallel_count replicates ONE target path); a planner
+ * that serves several requests at once, or a GPU that holds only a shard of the candidate seeds (cppflow/planners.py:231-251 split
+ * over 8 GPUs leaves 128 seeds = half a wavefront per SIMD on each), cannot fill the MI355X with one such launch: four small
+ * launches in flight is all the hardware overlaps, and each costs one wavefront's full latency however few rows it has.  A batch
+ * lays up to CPPF_MAX_BATCH problems end to end in one grid -- every workgroup belongs to exactly one problem, so each problem's
+ * results are bit for bit those of cppf_lm_pose_steps on it alone -- and the launch is full width again.
+ * Each item is what cppf_lm_pose_steps takes: x_in [S*W, d], target [W, 7] (items may have different targets, S and W), and its own
+ * outputs (J_out / e_out / min_self / min_env are not available in a batch; seed_summary as in cppf_lm_pose_steps: in the launch
+ * for W in {64, 128, 256}, else by one reduction launch per such item behind it, which needs the per-row outputs).
+ * cppf_lm_batch_create copies the item descriptors to a device table owned by the batch object (the only allocation; the caller's
+ * buffers stay the caller's, and must stay valid while the batch is used); cppf_lm_batch_launch is then one asynchronous launch on
+ * `stream`, hipGraph-capturable, reading the robot's obstacles / joint-limit padding as they are at launch time.
+ * cppf_lm_params.shape must be CPPF_SHAPE_AUTO or CPPF_SHAPE_ROW (a batch is the throughput shape by construction). */
+typedef struct cppf_lm_batch_item {
+    const float* x_in;   /* [S*W, d] */
+    const float* target; /* [W, 7] */
+    int32_t S, W;
+    cppf_lm_outputs out;
+} cppf_lm_batch_item;
+typedef struct cppf_lm_batch cppf_lm_batch; /* opaque: device table of the items + the marshalled parameters */
+int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_batch_item* items /* HOST */,
+                         const cppf_lm_params* params, cppf_lm_batch** out);
+int cppf_lm_batch_launch(const cppf_lm_batch* batch, void* stream);
+void cppf_lm_batch_destroy(cppf_lm_batch* batch);
 
 /* qpaths_batched_self_collisions / qpaths_batched_env_collisions (cppflow/collision_detection.py:27-69) +
  * joint_limit_almost_violations_3d + q_costs_external (cppflow/search.py:25-52, 146-150) for q [S,W,d]. Outputs [S*W]. */
@@ -313,14 +346,20 @@ int cppf_mjacs(const cppf_robot* robot, const float* q, int k, int T, float pris
  * over the k candidate paths q [k,T,d] with mjacs as in search.py:100-125 (prismatic deltas scaled by `prismatic_scaling`,
  * 5.0 in the reference), then the back-trace.  Outputs best_path [T,d] and best_idx [T] (which candidate each waypoint
  * came from).  The caller supplies the workspace (device): work_qT [T*k*d] floats, work_costsT [T*k] floats (on return:
- * the cost table, time-major), work_memoT [T*k] int32.  For k <= 256 (the reference plans with k = 175) the whole recurrence runs in ONE
- * resident launch (one or four destinations per workgroup; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are their
- * own flags, no grid barrier), else one small launch per waypoint; no host synchronisation either way.  The resident form
- * needs its <= 64 workgroups on the device together; its waits are bounded, and if one expires (a CU-masked / partitioned device)
- * the call still returns CPPF_OK -- it is asynchronous -- but best_idx[*] = -1 and best_path is NaN: repeat it with
- * cppf_debug_set(robot, CPPF_TUNE_DP_PERSISTENT, 0) (cppflow_hip_debug.h), which issues one launch per waypoint. */
+ * the cost table, time-major), work_memoT [T*k] int32.
+ * mode = CPPF_DP_AUTO: for k <= 1024 (the reference plans with k = 175 and re-plans with 300, cppflow/planners.py:47, 253-258; eight
+ *   ranks gather 1024) the whole recurrence runs in ONE resident launch -- one destination per wavefront (k <= 64) or four per
+ *   workgroup, at most 256 workgroups; the cost row of step t-1 is handed from workgroup to workgroup as write-through words that are
+ *   their own flags, no grid barrier -- else one small launch per waypoint; no host synchronisation either way.
+ * mode = CPPF_DP_RESIDENT / CPPF_DP_LAUNCHES force one form for THIS call (no handle state involved).
+ * The resident form needs its <= 256 workgroups on the device together; its waits are bounded, and if one expires (a CU-masked /
+ * partitioned device) the call still returns CPPF_OK -- it is asynchronous -- but best_idx[*] = -1 and best_path is NaN: repeat the
+ * call with CPPF_DP_LAUNCHES (cppflow_amd.search.dp_search does). */
+#define CPPF_DP_AUTO 0
+#define CPPF_DP_RESIDENT 1
+#define CPPF_DP_LAUNCHES 2
 int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cost, int k, int T, float prismatic_scaling,
-                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx,
+                   float* work_qT, float* work_costsT, int32_t* work_memoT, float* best_path, int32_t* best_idx, int mode,
                    void* stream);
 
 /* The same dynamic programme for k <= 256 from a precomputed transition table (the mjacs tensor of search.py:100-125, which

@@ -27,7 +27,7 @@ extern "C" {
 /* CPPF_SHAPE_AUTO runs four lanes per row up to n rows unless a per-seed summary is requested.  Default 16384 = one wavefront
  * of that shape per SIMD, the measured crossover. */
 #define CPPF_TUNE_QUAD_MAX_ROWS 2
-/* 0: cppf_dp_search issues one launch per waypoint instead of the single resident launch (k <= 256).  Default 1. */
+/* 0: cppf_dp_search in CPPF_DP_AUTO mode issues one launch per waypoint instead of the single resident launch (k <= 1024).  Default 1. */
 #define CPPF_TUNE_DP_PERSISTENT 3
 /* 0: cppf_lm_full_step eliminates with one wavefront per trajectory, first waypoint to last (cross-lane reads through the LDS
  * pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the path; d <= 8, beyond
@@ -46,7 +46,11 @@ extern "C" {
  * default) only two of its workgroups fit on one compute unit (12.5 KB static + 42 KB, 160 KB per unit), so that four such launches
  * in flight spread over the chip instead of stacking on the units the dispatcher fills first.  0 = no claim. */
 #define CPPF_TUNE_SPREAD_KB 8
-#define CPPF_TUNE_COUNT 9
+/* log2 of the re-reads after which a wait of the resident cppf_dp_search gives up (default 22: a few seconds).  0 makes every wait
+ * that does not find its word at the first read expire at once: how the tests reach the timeout path (best_idx = -1) and the
+ * caller's fall-back to one launch per waypoint. */
+#define CPPF_TUNE_DP_SPIN_LOG2 9
+#define CPPF_TUNE_COUNT 10
 
 int cppf_debug_set(cppf_robot* robot, int key, int value);
 int cppf_debug_get(const cppf_robot* robot, int key, int* value);
@@ -56,12 +60,12 @@ int cppf_debug_get(const cppf_robot* robot, int key, int* value);
  * without a device and CPPF_OK never -- look for the cache file. */
 int cppf_debug_rtc_compile(const cppf_robot_desc* desc, const char* cache_dir);
 
-/* The proof behind the collision stage's reciprocal (csrc/lmik_device.h: rcp_rn = v_rcp_f32 + one Newton step): compares it with
- * the correctly rounded 1 / x on `count` consecutive fp32 BIT PATTERNS starting at `first` and adds, per biased exponent of x
- * (0..255), the number of patterns on which the two differ in bits to mismatches[256] (DEVICE pointer, uint64, caller-zeroed).
- * NaN results on both sides count as equal.  device = the GPU to run on.  The oracle spells rcp_rn as `1 / x`, so the masks are
- * bit-exact across the two only if this stays 0 over the range the kernels use (2^-100 <= |x| < 2^126). */
-int cppf_debug_rcp_sweep(int device, uint64_t first, uint64_t count, uint64_t* mismatches, void* stream);
+/* offsetof(FusedArgs, single) as the DEVICE code was compiled with it: the fused kernel reads the problem of a plain launch at this
+ * offset from its kernel-argument segment (csrc/kernels_fused.h: fused_item).  tests/test_abi.py holds it against the offset the
+ * code object's own metadata gives the kernel's fourth argument. */
+int cppf_debug_fused_single_offset(void);
+
+/* (Test-only KERNELS are not in this library: tests/native/ holds them as a translation unit of its own.) */
 
 #ifdef __cplusplus
 }

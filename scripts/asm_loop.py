@@ -89,7 +89,7 @@ def main():
                     loops.append((pos[tgt], i))
         c = stats(items)
         print(f"  whole kernel : {c['n']} instr, VALU {c['valu']}")
-        for a, b in sorted(loops, key=lambda t: t[0] - t[1])[:4]:
+        for a, b in sorted(loops, key=lambda t: t[0] - t[1])[: int(sys.argv[3]) if len(sys.argv) > 3 else 4]:
             c = stats(items[a : b + 1])
             print(f"  loop [{a}..{b}]: {c['n']} instr: VALU {c['valu']} (FMA {c['fma']}, mul/add {c['muladd']}, trans {c['trans']}, DPP {c['dpp']}, "
                   f"mov {c['mov']}, cndmask {c['cnd']}, cmp {c['cmp']}), MFMA {c['mfma']}, SALU {c['salu']} (s_nop {c['nop']}), LDS {c['lds']}, VMEM {c['vmem']}; "

@@ -9,25 +9,25 @@ from cppflow_amd.robots import get_robot
 dev = torch.device("cuda:0")
 for name in ("panda", "fetch", "chain12"):
     rb = get_robot(name)
-    for k, T in ((175, 256), (64, 256), (96, 256), (128, 256), (175, 64), (256, 256), (1024, 256)):
+    for k, T in ((175, 256), (64, 256), (96, 256), (128, 256), (175, 64), (256, 256), (300, 256), (512, 256), (1024, 256), (1024, 64)):
         q = torch.rand((k, T, rb.ndof), device=dev)
         ext = torch.zeros((k, T), device=dev)
         qT = torch.empty((T, k, rb.ndof), device=dev); cT = torch.empty((T, k), device=dev); mT = torch.empty((T, k), dtype=torch.int32, device=dev)
         bp = torch.empty((T, rb.ndof), device=dev); bi = torch.empty(T, dtype=torch.int32, device=dev)
         h = rb._handle(dev)
-        def call():
-            _hip.check(_hip.lib().cppf_dp_search(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), bp.data_ptr(), bi.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        def call(mode):
+            _hip.check(_hip.lib().cppf_dp_search(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), bp.data_ptr(), bi.data_ptr(), mode, torch.cuda.current_stream(dev).cuda_stream))
         out = []
-        for mode in (1, 0):
-            rb.debug_set("dp_persistent", mode)
-            for _ in range(5): call()
+        for mode in (_hip.DP_RESIDENT, _hip.DP_LAUNCHES):
+            call_m = lambda: call(mode)
+            for _ in range(5): call_m()
             torch.cuda.synchronize()
             ts = []
             for _ in range(15):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); call(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
+                a.record(); call_m(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
             out.append(np.median(ts))
-        rb.debug_set("dp_persistent", 1)
+        assert int(bi[0].item()) >= 0
         tabled = float("nan")
         if k <= 256:
             import ctypes

@@ -15,4 +15,7 @@ constexpr int kBlock = 256;
 #include "kernels_fused.h"
 }
 using namespace dev;
-template __global__ void dev::lm_fused_kernel<StaRobot<gen::Panda>, 1>(const ChainK, const CollK, const LmK, const BatchItemK, const void*);
+#ifndef DEV_D
+#define DEV_D 7
+#endif
+template __global__ void dev::lm_fused_kernel<DynRobot<DEV_D>, 1>(const ChainK, const CollK, const LmK, const BatchItemK, const void*);

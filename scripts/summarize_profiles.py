@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 databases of scripts/record_pass.sh (gpurun_out/rec/) into the small summaries kept under profiles/.
 
-    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r3]
+    python scripts/summarize_profiles.py [gpurun_out/rec] [profiles] [r4] [counters|copy|all]
+
+"counters" needs only the profiler passes (it runs BEFORE the bench records of a pass, on the GPU box, so that every bench.py record
+of the pass finds the executed-instruction counters of its own launch shape and library build under profiles/); "copy" copies the
+text / JSON outputs of the pass; "all" (default) does both.
 
 Writes  <tag>_fused_kernel_stats.csv (rocprofv3's own kernel_stats), <tag>_pmc_summary.json (kernel-trace duration of the bench
 launch, FETCH / WRITE_SIZE, and per labelled variant of scripts/pmc_probe.py every SQ counter of the four counter passes with the
@@ -17,7 +21,8 @@ import sys
 
 REC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/rec"
 OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-TAG = sys.argv[3] if len(sys.argv) > 3 else "r3"
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r4"
+MODE = sys.argv[4] if len(sys.argv) > 4 else "all"
 FUSED = "lm_fused_kernel"
 PROBE_KERNELS = ("lm_fused_kernel", "lm_quad_kernel", "collision_kernel")
 
@@ -55,24 +60,42 @@ def probe_dispatches(rel, n_variants):
     return [by_id[k] for k in sorted(by_id)][-n_variants:]
 
 
-ROWS = {"A": 262144, "B": 262144, "C": 262144, "D": 262144, "E": 262144, "F": 262144, "G": 8192, "H": 8192, "I": 8192, "J": 16384,
-        "K": 16384, "L": 16384, "M": 131072, "N": 2097152}  # fmt: skip
-ITERS = {"A": 10, "B": 20, "C": 10, "D": 0, "E": 10, "F": 10, "G": 10, "H": 10, "I": 10, "J": 20, "K": 20, "L": 20, "M": 10, "N": 10}
-ISSUE_KEYS = {  # variant -> key of bench.py's workload_key()
+ROWS = {"A": 262144, "B": 262144, "C": 262144, "D": 262144, "E": 262144, "F": 262144, "G": 131072, "H": 8192, "I": 8192, "J": 16384,
+        "K": 16384, "L": 16384, "M": 262144, "N": 2097152, "O": 262144, "P": 262144, "Q": 262144, "R": 8192}  # fmt: skip
+ITERS = {"A": 10, "B": 20, "C": 10, "D": 0, "E": 10, "F": 10, "G": 10, "H": 10, "I": 10, "J": 20, "K": 20, "L": 20, "M": 10, "N": 10,
+         "O": 10, "P": 10, "Q": 10, "R": 10}  # fmt: skip
+ISSUE_KEYS = {  # variant -> key of bench.py's workload_key(robot, S, W, K, collide, inputs [+ "_b<steps per launch>"])
     "E": "panda_S1024_W256_K10_coll1",
     "C": "panda_S1024_W256_K10_coll1_random",
-    "G": "panda_S128_W64_K10_coll0",
-    "M": "fetch_S512_W256_K10_coll1",
+    "G": "panda_S128_W64_K10_coll0_problem_b16",
+    "M": "fetch_S512_W256_K10_coll1_problem_b2",
     "N": "chain12_S4096_W512_K10_coll1",
+    "O": "panda_S128_W256_K10_coll1_problem_b8",
+    "P": "panda_S256_W256_K10_coll1_problem_b4",
+    "Q": "panda_S512_W256_K10_coll1_problem_b2",
 }
+
+
+def copy_outputs():
+    os.makedirs(OUT, exist_ok=True)
+    for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_solver_f32.json", "bench_random_solver_f32.json", "gate_census_problem.txt", "gate_census_random.txt", "bench_C2.json", "bench_C3.json",
+                "bench_C5.json", "shard_streams.txt", "hwq_sweep.txt", "shard_bench.txt", "shard_bench_mfma.txt", "mfma_chain12.txt", "ksweep.txt", "dp_bench.txt", "coupled_bench.txt", "coupled_dp_kernels.txt", "lone_wave_micro.txt", "kbench.txt",
+                "kbench_small.txt", "launch_model.txt", "rtc_bench.txt", "pytest_gpu.txt", "valu_issue_rate_calibration.txt", "bench_driverflags.json", "bench_shard128_driverflags.json",
+                "bench_shard128_2000steps.json", "bench_2ranks_driverflags.json", "bench_2000steps.json"):  # fmt: skip
+        if os.path.exists(os.path.join(REC, src)):
+            shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{src}"))
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    bench = json.load(open(os.path.join(REC, "bench.json")))
-    cfg = bench["config"]
+    # the headline workload (BASELINE config 4) and the library build every record of this pass is keyed by
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cppflow_amd import build as hip_build
+
+    cfg = {"robot": "panda", "seeds_per_gpu": 1024, "waypoints": 256, "lm_iterations_per_step": 10, "collision_fused": True, "ndof": 7}
     grid = cfg["seeds_per_gpu"] * cfg["waypoints"]
-    build_id = bench["roofline"]["library_build_id"]  # every record of this pass is keyed by the library build it was taken with
+    build_id = hip_build.built_id()
+    assert build_id == hip_build.source_hash(), "the library on disk is not the one these sources produce"
     summary = {"library_build_id": build_id, "kernel_trace": kernel_stats(grid, build_id)}
     fetch = counter("pmc_fetch/pmc_counter_collection.csv", "FETCH_SIZE", grid)
     write = counter("pmc_write/pmc_counter_collection.csv", "WRITE_SIZE", grid)
@@ -164,11 +187,6 @@ def main():
     }
     with open(os.path.join(OUT, f"{TAG}_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=2)
-    for src in ("bench.json", "bench_dist1.json", "bench_2ranks_rehearsal.json", "bench_solver_f64.json", "bench_solver_f32.json", "bench_random_solver_f32.json", "gate_census_problem.txt", "gate_census_random.txt", "bench_C2.json", "bench_C3.json",
-                "bench_C5.json", "shard_streams.txt", "hwq_sweep.txt", "shard_bench.txt", "shard_bench_mfma.txt", "mfma_chain12.txt", "ksweep.txt", "dp_bench.txt", "coupled_bench.txt", "coupled_dp_kernels.txt", "lone_wave_micro.txt", "kbench.txt",
-                "kbench_small.txt", "launch_model.txt", "rtc_bench.txt", "pytest_gpu.txt", "valu_issue_rate_calibration.txt"):  # fmt: skip
-        if os.path.exists(os.path.join(REC, src)):
-            shutil.copy(os.path.join(REC, src), os.path.join(OUT, f"{TAG}_{src}"))
     print(json.dumps({k: v for k, v in summary.items() if k != "sq_counters_scripts_pmc_probe_last_round"}, indent=1))
     for d in disp:
         print(d["variant"][:60].ljust(62), {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()
@@ -176,4 +194,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if MODE in ("counters", "all"):
+        main()
+    if MODE in ("copy", "all"):
+        copy_outputs()

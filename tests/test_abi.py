@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_hip.SIGNATURES), set(names) ^ set(_hip.SIGNATURES)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.cppf_abi_version() == 4
+    assert lib.cppf_abi_version() == 5
 
 
 def test_debug_header_holds_every_hook_and_nothing_of_the_boundary():
@@ -74,7 +74,7 @@ def test_debug_header_holds_every_hook_and_nothing_of_the_boundary():
     assert not [n for n in public if n.startswith("cppf_debug_")]
     assert debug and all(n.startswith("cppf_debug_") for n in debug), debug
     text = open(DEBUG_HEADER).read()
-    keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define CPPF_TUNE_([A-Z_]+) (\d+)\n", text)}
+    keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define CPPF_TUNE_([A-Z_0-9]+) (\d+)\n", text)}
     count = keys.pop("count")
     assert keys == _hip.TUNE_KEYS and count == len(keys)
     assert re.search(r"int cppf_debug_set\(cppf_robot\* robot, int key, int value\);", text)
@@ -98,6 +98,63 @@ def test_struct_layouts_match_header_constants():
     assert ctypes.sizeof(_hip.LmParams) == 40
     assert ctypes.sizeof(_hip.LmOutputs) == 13 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(_hip.Constraints) == 24
+
+
+def test_batch_item_layout_and_fused_argument_offset(lib):
+    """cppf_lm_batch_item as ctypes sees it equals the C struct (two pointers, S, W, the 13 output pointers), and the fused kernel's
+    view of its own kernel-argument segment is right: the device code reads the problem of a plain launch at offsetof(FusedArgs,
+    single) from the segment's base (csrc/kernels_fused.h: fused_item) -- the code object's metadata must place the kernel's fourth
+    argument exactly there, for a shipped table (the second translation unit) and a generic instantiation (the first)."""
+    import os
+    import subprocess
+    import sys
+
+    from cppflow_amd import _hip, build
+
+    assert ctypes.sizeof(_hip.LmBatchItem) == 8 + 8 + 4 + 4 + 13 * 8
+    text = open(HEADER).read()
+    assert int(re.search(r"#define CPPF_MAX_BATCH (\d+)", text).group(1)) == _hip.MAX_BATCH
+    want = lib.cppf_debug_fused_single_offset()
+    assert want > 0 and want % 8 == 0
+    sys.path.insert(0, os.path.join(os.path.dirname(build.CSRC), "..", "scripts"))
+    import kernel_resources as kr
+
+    co = os.path.join(os.environ.get("TMPDIR", "/tmp"), "cppf_abi_test.co")
+    notes = ""
+    for path in kr.extract_code_objects(build.OUT, co):
+        notes += subprocess.run([f"{kr.LLVM}/llvm-readelf", "--notes", path], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for blk in notes.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "lm_fused_kernel" not in name:
+            continue
+        # the explicit arguments come first, in order: ChainK, CollK, LmK, BatchItemK single, table
+        offs = [int(m.group(1)) for m in re.finditer(r"- \.offset:\s+(\d+)\n\s+\.size:\s+\d+\n\s+\.value_kind:\s+by_value", blk)]
+        sizes = [int(m.group(1)) for m in re.finditer(r"- \.offset:\s+\d+\n\s+\.size:\s+(\d+)\n\s+\.value_kind:\s+by_value", blk)]
+        assert len(offs) >= 4 and offs[3] == want and sizes[3] == 128, (name, offs[:5], sizes[:5], want)
+        seen += 1
+    assert seen >= 12 * 3, seen  # every shipped table x COLL and every generic ndof x COLL
+
+
+def test_no_test_kernel_ships_in_the_product_library(lib):
+    """a test-only kernel (the exhaustive reciprocal sweep) lived in libcppflow_hip.so.  Test kernels are a translation
+    unit of their own (tests/native/, built by build_test_kernels into its own shared object); the product library exports no
+    cppf_test_* / *_sweep symbol and holds no such kernel."""
+    import os
+    import subprocess
+    import sys
+
+    from cppflow_amd import build
+
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(build.CSRC), "..", "scripts", "kernel_resources.py")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "lm_fused_kernel" in out and "sweep" not in out and "test" not in out.lower().replace("latest", ""), [ln for ln in out.splitlines() if "sweep" in ln or "test" in ln.lower()]
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.OUT], capture_output=True, text=True, check=True).stdout
+    assert "cppf_lm_batch_launch" in syms and "rcp_sweep" not in syms and "cppf_test_" not in syms
+    assert os.path.exists(build.TEST_SRC)
+    build.build_test_kernels()
+    tk = subprocess.run(["nm", "-D", "--defined-only", build.TEST_OUT], capture_output=True, text=True, check=True).stdout
+    assert "cppf_test_rcp_sweep" in tk
 
 
 def test_invalid_descriptions_are_rejected_without_a_gpu(lib):

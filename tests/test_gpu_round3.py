@@ -29,12 +29,21 @@ def test_fast_reciprocal_is_correctly_rounded():
     three instructions ARE the correctly rounded reciprocal.  All 2^32 bit patterns, on the GPU itself, against hipcc's IEEE
     division: no mismatch for any x with |x| < 2^126 (biased exponent <= 252: zero, denormals -- both sides 0 -- and every
     normal number up to there); beyond, where 1 / x is denormal, the two may differ (nothing geometric lives there)."""
-    from cppflow_amd import _hip
+    import os
 
+    from cppflow_amd import _hip, build as hip_build
+
+    _hip.lib()  # (torch's HIP runtime first, as for the product library)
+    # the sweep kernel is a TEST translation unit (tests/native/rcp_sweep.hip, built by __graft_entry__.build()): it includes the
+    # product's lmik_device.h, so the function under test is the product's rcp_rn, but no test kernel ships in libcppflow_hip.so
+    assert os.path.exists(hip_build.TEST_OUT), "tests/native/libcppf_testkernels.so is missing: run __graft_entry__.build()"
+    tk = ctypes.CDLL(hip_build.TEST_OUT)
+    tk.cppf_test_rcp_sweep.restype = ctypes.c_int
+    tk.cppf_test_rcp_sweep.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
     mism = torch.zeros(256, dtype=torch.int64, device=DEV)
     chunk = 1 << 30
     for first in range(0, 1 << 32, chunk):
-        _hip.check(_hip.lib().cppf_debug_rcp_sweep(0, first, chunk, mism.data_ptr(), None))
+        assert tk.cppf_test_rcp_sweep(0, first, chunk, mism.data_ptr(), None) == 0
     torch.cuda.synchronize()
     m = mism.cpu().numpy()
     assert m[:253].sum() == 0, {int(e): int(v) for e, v in enumerate(m) if v}
