@@ -211,13 +211,38 @@ def make_inputs_problem(robot, S, W, device, seed):
         what = "target path = FK of a smooth random walk (q*_{t+1} = clamp(q*_t + 0.02 randn))"
     lo_d, hi_d = lo.to(device), hi.to(device)
     branch = torch.empty((S, W, d), dtype=torch.float32, device=device)
+    # Fetch: the lift joint is a pure z translation at the root of the chain (torso_lift_link is unrotated w.r.t. the world,
+    # cppflow/data_type_utils.py:65-73), so a seed is a lift height -- drawn once per seed from the middle 80 % of its range, as a
+    # sampler of whole-body configurations would -- and an ARM branch tracking the path lowered by that height (the 7-joint chain of
+    # fetch_arm).  Tracking the path with the pose-only LM step on all 8 joints instead lets the lift joint, whose Jacobian column
+    # is a whole metre per unit, take every vertical motion: the branches drift onto its limits, the clamp of
+    # cppflow/optimization.py:259 pins them there, and half the rows of a batch built that way can no longer converge (round 3's
+    # C3 inputs: 55 %) -- a property of those inputs, not of any kernel.
+    ik_robot, lift = robot, None
+    if robot.name == "fetch":
+        from cppflow_amd.robots import get_robot as _get_robot
+
+        ik_robot = _get_robot("fetch_arm")
+        lift = (lo[0] + (hi[0] - lo[0]) * (0.1 + 0.8 * torch.rand(S, generator=g))).to(device)
+    d_ik = ik_robot.ndof
+    lo_ik = torch.tensor([l for l, _ in ik_robot.actuated_joints_limits], dtype=torch.float32)
+    hi_ik = torch.tensor([u for _, u in ik_robot.actuated_joints_limits], dtype=torch.float32)
+
+    def seeds_target(w):
+        """[S, 7]: waypoint w as every seed's IK problem sees it (row r of a launch with W = n uses target row r)"""
+        t = target[w : w + 1].repeat(S, 1)
+        if lift is not None:
+            t[:, 2] -= lift
+        return t.contiguous()
+
     # waypoint 0: damped LM from random starts, re-drawing the seeds that did not reach the pose (up to 12 rounds)
-    x = torch.empty((S, d), dtype=torch.float32, device=device)
+    x = torch.empty((S, d_ik), dtype=torch.float32, device=device)
     todo = torch.ones(S, dtype=torch.bool, device=device)
+    t0 = seeds_target(0)
     for _ in range(12):
-        start = (lo + (hi - lo) * (0.1 + 0.8 * torch.rand((S, d), generator=g))).to(device).contiguous()
-        r = robot.lm_pose_steps(start, target[0:1], 1e-2, 3.5, 0.35, n_steps=60)
-        r = robot.lm_pose_steps(r["x"], target[0:1], 1e-6, 3.5, 0.35, n_steps=10, want_errors=True)
+        start = (lo_ik + (hi_ik - lo_ik) * (0.1 + 0.8 * torch.rand((S, d_ik), generator=g))).to(device).contiguous()
+        r = ik_robot.lm_pose_steps(start, t0, 1e-2, 3.5, 0.35, n_steps=60)
+        r = ik_robot.lm_pose_steps(r["x"], t0, 1e-6, 3.5, 0.35, n_steps=10, want_errors=True)
         ok = (r["pos_err_m"] < 1e-4) & (r["rot_err_rad"] < 1.75e-3)
         take = todo & ok
         x[take] = r["x"][take]
@@ -228,15 +253,17 @@ def make_inputs_problem(robot, S, W, device, seed):
     x = x.contiguous()
     gd = torch.Generator(device=device).manual_seed(seed + 17)
     for w in range(W):
-        r = robot.lm_pose_steps(x, target[w : w + 1].contiguous(), 1e-6, 3.5, 0.35, n_steps=8, want_errors=True)
+        r = ik_robot.lm_pose_steps(x, seeds_target(w), 1e-6, 3.5, 0.35, n_steps=8, want_errors=True)
         x = r["x"]
-        # a branch that loses the path (runs into a joint limit) continues on a branch that did not
+        # a branch that loses the path (runs into a joint limit) continues on a branch that did not (with the donor's lift height)
         ok = (r["pos_err_m"] < 1e-4) & (r["rot_err_rad"] < 1.75e-3)
         donors = torch.nonzero(ok).reshape(-1)
         if 0 < donors.numel() < S:
             pick = donors[torch.randint(donors.numel(), (S,), generator=gd, device=device)]
             x = torch.where(ok[:, None], x, x[pick]).contiguous()
-        branch[:, w] = x
+            if lift is not None:
+                lift = torch.where(ok, lift, lift[pick]).contiguous()
+        branch[:, w] = x if lift is None else torch.cat([lift[:, None], x], dim=1)
     noise = 0.1 * torch.randn((S, W, d), generator=g)
     x0 = torch.minimum(torch.maximum(branch + noise.to(device), lo_d), hi_d).reshape(S * W, d).contiguous()
     return x0, target, what + "; seeds = per-seed IK branch tracking the path + 0.1 randn"
@@ -987,7 +1014,9 @@ def main():
     # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket; never more than the
     # timed region holds (at the driver's --steps 20 at least one FULL exchange must lie inside the region), a multiple of the batch
     G_req = args.gather_every if args.gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
-    G = max(batch, (min(G_req, max(args.steps, 1)) // batch) * batch)
+    # (a region of K steps holds at least two full buckets when it can: at the driver's --steps 20 and 8 steps per launch that is one
+    # exchange behind every launch -- two launches on two streams in flight -- instead of one bucket that serialises two launches)
+    G = max(batch, (min(G_req, max(args.steps // 2, 1)) // batch) * batch)
     # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
     n_streams = args.streams if args.streams > 0 else (4 if rows_launch <= 131072 else 2)
 
@@ -1065,7 +1094,7 @@ def main():
         xs, tg, _ = inputs_for(S_local, mode, kind)
         b2 = max(1, min(_hip.MAX_BATCH, FULL_WIDTH_ROWS // max(xs.shape[0], 1))) if args.batch <= 0 else args.batch
         b2 = 1 if shape == _hip.SHAPE_QUAD else b2
-        G2 = max(b2, (min(G_req, max(steps, 1)) // b2) * b2)
+        G2 = max(b2, (min(G_req, max(steps // 2, 1)) // b2) * b2)
         r2 = Runner(robot, xs, tg, K, collide, streams, G2, transport, world, shape, device, solver, batch=b2)
         el = float(np.median([max_over_ranks(t) for t in r2.timed(steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), barrier, 3,
                                                                     closing_barrier if dist is not None else None)[0]]))

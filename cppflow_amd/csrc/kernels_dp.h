@@ -296,8 +296,7 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
 // gather 8 x 128 = 1024): FOUR destinations per 512-lane workgroup again -- at most 256 workgroups, one per compute unit, all
 // resident -- but every lane now owns NS = 1 or 2 SOURCES (tid, tid + 512) and meets all four destinations with them, so that each
 // cost word of step t - 1 is polled by exactly ONE lane of a workgroup (k x k / 4 flag reads per step chip-wide: at k = 1024 one
-// megabyte per polling round, where one wavefront per destination would read four).  The four destinations are the same for every
-// lane: their configurations and external costs are wave-uniform (scalar loads).  Per step: the cost-independent part (NS x 4 wrapped
+// megabyte per polling round, where one wavefront per destination would read four).  Per step: the cost-independent part (NS x 4 wrapped
 // joint changes per lane) and the operand loads of step t + 1 come BEFORE the wait; then each lane waits for its NS words, forms its
 // four (value, index) keys, one 64-bit minimum per destination over its own sources, and the workgroup reduces the four columns of
 // the 512-entry LDS image (wavefront i takes destination i: 8 entries per lane, then DPP); the image is double-buffered by the
@@ -309,7 +308,13 @@ __global__ __launch_bounds__(512) void dp_resident_kernel(const float* __restric
                                                           int32_t* __restrict__ memoT, uint32_t spin_budget) {
     constexpr int BP = 4;
     __shared__ unsigned long long keys[2][BP][512];
-    const int b0 = blockIdx.x * BP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the destinations' operands are the same for every lane, and the compiler would fetch them with scalar loads -- which count on
+    // lgkmcnt like the LDS accesses: the barrier's wait then exposes their latency in EVERY step; fetched as vector loads they are
+    // older than the polling loads and have returned when those do.  An opaque zero keeps the index per-lane for the compiler.)
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    const int b0 = blockIdx.x * BP + lane_zero;
     float qa[NS][D], qb[BP][D], eb[BP];
     auto load_operands = [&](int t, float (&qa_)[NS][D], float (&qb_)[BP][D], float (&eb_)[BP]) {
         const float* q_prev = qT + (size_t)(t - 1) * k * D;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(512) void dp_resident_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < BP; ++u) {
-            const int b = min(b0 + u, k - 1);  // wave-uniform
+            const int b = min(b0 + u, k - 1);
             eb_[u] = ext[(size_t)b * T + t];
 #pragma unroll
             for (int j = 0; j < D; ++j) qb_[u][j] = q_cur[(size_t)b * D + j];

@@ -136,6 +136,9 @@ __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_i
 // outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration in the canonical arithmetic: the LAST
 // iteration of every launch -- so x_out is always one canonical LM step from its predecessor, and a K = 1 launch (the reference's
 // cadence) is canonical throughout -- and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
+#ifndef CPPF_LEAD_HW_SINCOS
+#define CPPF_LEAD_HW_SINCOS 1  // 0: the leading iterations use the canonical sine / cosine too (the A/B build of scripts/make_variant_build.py)
+#endif
 template <class RB, bool LEAD>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
                                                const float (&Rt)[9], const float (&tt)[3], float* __restrict__ gate_lds,
@@ -145,7 +148,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
     bool conv = false;
     {
         float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6];
-        fk_ee_axes<RB, LEAD>(rb, q, R, p, ax, og);
+        fk_ee_axes<RB, LEAD && (CPPF_LEAD_HW_SINCOS != 0)>(rb, q, R, p, ax, og);
         pose_error(Rt, tt, R, p, e);
         if constexpr (!LEAD) {
             if (prm.tol_pos2 > 0.f) {  // wave-uniform
@@ -200,7 +203,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
                         float R2[9], p2[3], ax2[D][3], og2[D][3], J2[6][D], e2[6];
 #pragma unroll
                         for (int j = 0; j < D; ++j) asm volatile("" : "+v"(q[j]));  // (unchanged, but the compiler must not know)
-                        fk_ee_axes<RB, LEAD>(rb, q, R2, p2, ax2, og2);
+                        fk_ee_axes<RB, LEAD && (CPPF_LEAD_HW_SINCOS != 0)>(rb, q, R2, p2, ax2, og2);
                         pose_error(Rt, tt, R2, p2, e2);
                         jacobian_from_axes<RB>(rb, p2, ax2, og2, J2);
                         rank = lm_gate_hand_over<D>(J2, e2, todo, gate_lds, flag);

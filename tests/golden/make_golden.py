@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Generate the committed golden fixtures (run in the build container, where /root/reference is mounted):
 
+  reference_problems.npz  all 18 problems of the reference's problem set (robot, offset target path, cuboid obstacles): data only
   reference_paths.npz   target paths of BASELINE.json configs C1-C4, produced by cppflow_amd.data_type_utils from the
                         reference's own problem yaml / path csv DATA files (no reference source is read or copied)
   lm_golden_<robot>.npz 64 seeded rows per robot: x, target, and what the fp64 oracle (oracle/lmik_oracle.c, reference
@@ -40,6 +41,28 @@ def reference_paths():
     )
 
 
+def reference_problems():
+    """every problem of the reference's problem set (cppflow/problems/*.yaml, 18 files): robot, target path with its offset applied by
+    this build's loader, cuboid obstacles [O, 6] = (x, y, z, size_x, size_y, size_z) -- DATA only (scripts/problem_plausibility.py and
+    tests/test_problem_plausibility.py read it; /root/reference does not exist on the GPU box)"""
+    import glob
+
+    import yaml
+
+    kw = dict(problems_dir=os.path.join(REF, "problems"), paths_dir=os.path.join(REF, "paths"), device="cpu")
+    out, names = {}, []
+    for f in sorted(glob.glob(os.path.join(REF, "problems", "*.yaml"))):
+        name = os.path.splitext(os.path.basename(f))[0]
+        pr = problem_from_filename(None, name, **kw)
+        d = yaml.load(open(f), Loader=yaml.FullLoader)
+        obs = [[o["x"], o["y"], o["z"], o["size_x"], o["size_y"], o["size_z"]] for o in pr.obstacles]  # (offset applied by the loader)
+        names.append(name)
+        out[name + "__robot"] = np.array(d["robot"])
+        out[name + "__target_path"] = pr.target_path.numpy().astype(np.float32)
+        out[name + "__obstacles"] = np.array(obs, dtype=np.float64).reshape(-1, 6)
+    np.savez_compressed(os.path.join(HERE, "reference_problems.npz"), names=np.array(names), **out)
+
+
 def lm_golden(name):
     S, W, K = 4, 16, 10
     x0, target = H.lm_problem(name, S, W, seed=100)
@@ -68,6 +91,7 @@ if __name__ == "__main__":
     oracle.build()
     if os.path.isdir(REF):
         reference_paths()
+        reference_problems()
     for n in ("panda", "fetch", "fetch_arm", "chain12"):
         lm_golden(n)
     print("golden fixtures written to", HERE)

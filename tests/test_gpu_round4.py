@@ -277,7 +277,7 @@ def test_leading_iterations_do_not_move_the_fixed_point():
         xo = o64.lm_steps(x0, tgt, K, solver=0, **LM)
         pe_o, re_o = o64.pose_metrics_exact(xo, tgt)
         pe_p, re_p, pe_c, re_c = host(plain["pos_err_m"]), host(plain["rot_err_rad"]), host(canon["pos_err_m"]), host(canon["rot_err_rad"])
-        conv = (pe_o < 1e-5) & (re_o < 1e-4) & (pe_c < 1e-5)
+        conv = (pe_o < 1e-5) & (re_o < 1e-3) & (pe_c < 1e-5) & (re_c < 1e-3)  # (the rotation metric is floored at 8.94e-4, data_types.py:408-411)
         assert conv.mean() > 0.6, (name, conv.mean())
         assert np.abs(pe_p - pe_c)[conv].max() < 2e-6 and np.abs(re_p - re_c)[conv].max() < 5e-6, (name, np.abs(pe_p - pe_c)[conv].max())
         assert np.abs(pe_p - pe_o)[conv].max() < 1e-5 and np.abs(re_p - np.maximum(re_o, 8.94427191e-4))[conv].max() < 1e-5
