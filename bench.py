@@ -722,25 +722,42 @@ class Runner:
 
     def run_steps(self, n):
         """`n` steps = floor(n / B) launches of B steps and one of n mod B; whole buckets go out as one graph replay each when
-        graphs are on.  A bucket's exchange step follows its last launch."""
+        graphs are on.  A bucket's exchange step follows its last launch ON ITS STREAM; the host issues it one launch late -- after
+        the next bucket's first launch has gone to ITS stream -- so that the second stream's kernels are not held back by the
+        ~10 us of host time the collective and the selection launch take (a 20-step region of a 32 768-row shard is ~100 us)."""
         B, G = self.B, self.G
+        pending = None  # a complete bucket whose exchange step has not been issued yet
+
+        def flush():
+            nonlocal pending
+            if pending is not None:
+                self.exchange(pending)
+                pending = None
+
         while n > 0:
             b = self.step_no % self.NBUF
             if self.graphs is not None and b % G == 0 and n >= G:
                 bucket = b // G
+                if pending == bucket:
+                    flush()
                 with torch.cuda.stream(self.streams[bucket]):
                     self.graphs[bucket].replay()
                 self.step_no += G
                 n -= G
+                flush()
                 if self.transport is not None:
-                    self.exchange(bucket)
+                    pending = bucket
                 continue
             c = min(B, n)
+            if pending is not None and self.buckets and pending == b // G:
+                flush()  # (a one-bucket ring: the launch below would overwrite the summaries still to be gathered)
             self.launches[b // B][c - 1].launch_on(self.stream_of(b))
             self.step_no += B  # (a shorter launch leaves the rest of its group unused: the ring moves on to the next group)
             n -= c
+            flush()
             if self.buckets and self.transport is not None and (b + B) % G == 0:
-                self.exchange(b // G)  # the bucket is complete: gather its G summaries from every rank and consume them
+                pending = b // G  # the bucket is complete: gather its G summaries from every rank and consume them
+        flush()
 
     def exchange(self, bucket):
         G = self.G

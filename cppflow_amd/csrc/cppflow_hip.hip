@@ -258,6 +258,9 @@ constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP
 // two-ended row-per-lane kernels at d <= 7 (x 0.5 at d = 8): 512 trajectories x 256 waypoints with the state in LDS (W <= 256: one
 // workgroup per compute unit, so the time steps up at every multiple of 256 trajectories), 192 x 256 with the state in the workspace
 constexpr int kPcrMaxRowsLds = 131072, kPcrMaxRowsGlobal = 49152;
+// the split form of the LDS-resident reduction (two wavefront-uniform halves per waypoint) up to this many joints: measured -6 % at
+// d = 7; at d = 8 it was +9 % while it spilled 300 B per lane (round 3) -- spill-free since round 4, see profiles/r4_pcr_ab.txt
+constexpr int kPcrSplitMaxD = 7;
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -1149,7 +1152,7 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
     hipStream_t st = (hipStream_t)stream;
 #define CPPF_BODY                                                                                                     \
     if (n >= 131072)                                                                                                  \
-        hipLaunchKernelGGL((full_blocks_kernel<RB, (RB::D <= 8)>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, \
+        hipLaunchKernelGGL((full_blocks_kernel<RB, full_blocks_occ<RB>()>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, \
                            robot->chain, robot->coll, prm, x_in, target, virtual_configs, work_blocks, w2next);      \
     else                                                                                                              \
         hipLaunchKernelGGL((full_blocks_kernel<RB>), dim3(grid_for(n)), dim3(kBlock), robot->lds_bytes, st, robot->chain, \
@@ -1175,7 +1178,7 @@ int cppf_lm_full_step(const cppf_robot* robot, const float* x_in, const float* t
             constexpr size_t kState = 256 * (size_t)((DD * (DD + 1) / 2 + DD + DD * DD) | 1) * sizeof(float);           \
             CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_solve_pcr_kernel<DD, 256, true>),         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kState));                    \
-            if (g_pcr_split && DD <= 7) { /* measured: -6 % at d = 7, +9 % at d = 8 (register pressure) */              \
+            if (g_pcr_split && (DD <= kPcrSplitMaxD || t_pcr_lds == 3)) { /* see kPcrSplitMaxD; 3 forces the split form */ \
                 CPPF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_solve_pcr_kernel<DD, 512, true, true>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kState));                \
                 hipLaunchKernelGGL((full_solve_pcr_kernel<DD, 512, true, true>), dim3((unsigned)S), dim3(512), kState, st, \

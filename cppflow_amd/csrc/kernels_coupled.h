@@ -258,8 +258,25 @@ __device__ __forceinline__ void full_block_store(const RB& rb, const FullK& prm,
 // 262 144-row launch are resident.  Small launches use the unconstrained build: a lone wavefront pays a memory round trip per
 // scratch access (one trajectory x 256 waypoints: 68 -> 66.6 us Panda, 95.7 -> 91.3 Fetch) and a scratch-using launch
 // dispatches more slowly.
-template <class RB, bool OCC4 = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC4 ? 4 : 1, OCC4 ? 4 : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
+// Wavefronts per SIMD of the large-launch build (OCC != 0; n >= 131 072 rows, where residency is what hides the capsule stage's
+// latency): four where the kernel fits 128 registers without scratch (Panda, Fetch, generic chains up to 6 joints), three (168
+// registers) for FetchArm and the generic 7- / 8-joint kernels, which needed 20 / 48 / 144 B of scratch per lane at four.
+template <class RB>
+struct full_blocks_fits_128 {
+    static constexpr bool value = true;
+};
+template <>
+struct full_blocks_fits_128<StaRobot<gen::FetchArm>> {
+    static constexpr bool value = false;
+};
+template <class RB>
+constexpr int full_blocks_occ() {
+    if (RB::D > 8) return 0;
+    if (RB::kStatic) return full_blocks_fits_128<RB>::value ? 4 : 3;
+    return RB::D <= 6 ? 4 : 3;
+}
+template <class RB, int OCC = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(OCC ? OCC : 1, OCC ? OCC : 8))) void full_blocks_kernel(const ChainK ch, const CollK co, const FullK prm,
                                                              const float* __restrict__ x,
                                                              const float* __restrict__ target,
                                                              const float* __restrict__ xv, float* __restrict__ blocks,
@@ -1065,6 +1082,26 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
 // a second write phase (two more barriers per level; the critical path of a level drops from inverse + both sides to inverse +
 // the longer side).  Same-process A/B (scripts/pcr_ab.py): one trajectory 66.1 -> 61.6 us, 512 trajectories 121 -> 114 us at
 // d = 7; slower at d = 8 (96 -> 105 us at 256 trajectories: register pressure), where the host keeps one lane per waypoint.
+// index of element (i, j) in the packed upper triangle (row-major, D(D+1)/2 entries) of a symmetric D x D matrix
+template <int D>
+__device__ __forceinline__ constexpr int sym_index(int i, int j) {
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    return a * D - a * (a - 1) / 2 + (b - a);
+}
+
+#ifndef CPPF_PCR_FENCE
+#define CPPF_PCR_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef CPPF_PCR_LEAN
+#define CPPF_PCR_LEAN(D, BS, kLds, kSplit) ((D) >= 8)
+#endif
+// a pointer the compiler knows nothing about: loads through it are not merged with earlier loads of the same address (which would
+// keep a whole coupling block in registers between its two uses instead of reading it again where it is needed)
+__device__ __forceinline__ const float* opaque(const float* p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 template <int D, int BS, bool kLds = false, bool kSplit = false>
 __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, const FullK prm, const float* __restrict__ x,
                                                             const float* __restrict__ xv, float* blocks, float* workL,
@@ -1074,6 +1111,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
     extern __shared__ float pcr_state[];
     static_assert(!kSplit || (kLds && BS == 512), "the split form keeps its state in LDS and runs 512 lanes");
     constexpr int TW = kSplit ? BS / 2 : BS;  // waypoints per workgroup
+    constexpr bool kLean = CPPF_PCR_LEAN(D, BS, kLds, kSplit);  // which form of the general level (below)
     const int s = blockIdx.x, t = kSplit ? (int)(threadIdx.x & (TW - 1)) : (int)threadIdx.x, T = prm.W;
     const int h = kSplit ? (int)(threadIdx.x / TW) : 0;  // wavefront-uniform
     const bool act = t < T;
@@ -1195,31 +1233,32 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
         __syncthreads();
         if (act) {
             const float* own = st_blk(t);
-            if (h == 0) {
-                load_sym(own, nD);
+            // (h == 1, the t + s side of the split form, accumulates from zero)
 #pragma unroll
-                for (int j = 0; j < D; ++j) ny[j] = own[NT + j];
-            } else {  // the t + s side accumulates from zero
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) nD[i][j] = 0.f;
-#pragma unroll
-                for (int j = 0; j < D; ++j) ny[j] = 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
+            for (int j = 0; j < D; ++j) ny[j] = h == 0 ? own[NT + j] : 0.f;
             const bool do_m = !kSplit || h == 0, do_p = !kSplit || h == 1;
             const int tm = do_m ? t - st : -1, tp = do_p ? t + st : T;
             if (st == 1) {
+                if (h == 0) {
+                    load_sym(own, nD);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) nD[i][j] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
                 // First level: every coupling block is still the diagonal E = -diag(a^2) the assembly wrote (0 above waypoint
                 // 0), so each matrix product below collapses to a row / column scaling.  The results are bit-identical to the
                 // general branch (its other terms are exact zeros): ~250 instead of ~1 800 multiply-adds for this level.
                 float lt[D], lm[D];
+                int t1 = t;  // (opaque: these sixteen selects are otherwise hoisted out of the level loop and held in registers across it)
+                asm volatile("" : "+v"(t1));
 #pragma unroll
-                for (int j = 0; j < D; ++j) lt[j] = t > 0 ? -a2[j] : 0.f, lm[j] = tm > 0 ? -a2[j] : 0.f;
+                for (int j = 0; j < D; ++j) lt[j] = t1 > 0 ? -a2[j] : 0.f, lm[j] = t1 > 1 && tm >= 0 ? -a2[j] : 0.f;
                 if (tm >= 0) {
                     float P[D][D];
                     const float* nb = st_blk(tm);
@@ -1256,6 +1295,172 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
                     }
                 }
             } else {
+                if constexpr (kLean) {
+                // General level, laid out for registers (the row-by-row form held P, L_t, L_{t-s} and all three
+                // results at once -- 300+ values at d = 8, 372 B of scratch per lane at 512 lanes): first alpha = -L_t P_{t-s} and
+                // gamma = -L_{t+s}^T P_{t+s} as whole matrices (the inverses are dead after that), then D_t and y_t column by
+                // column with the coupling blocks streamed from the state (LDS or L2) as they are used, then -- gamma dead, D_t
+                // folded to its packed symmetric form -- L_t.  Every sum is formed in the order of the row-by-row form.
+                // A side a lane does not have (t - s < 0, t + s >= T) runs on the lane's own row with alpha / gamma set to zero --
+                // its terms are exact zeros -- and is skipped when no lane of the wavefront has it (the last levels: half the
+                // wavefronts have one side only).  Every array is assigned on every path: a conditionally assigned one is a
+                // loop-carried value to the compiler (64 registers held across the whole level for each).
+                float A[D][D], G[D][D];
+                const bool m_on = tm >= 0, p_on = tp < T;
+                const bool m_any = __builtin_amdgcn_ballot_w64(m_on) != 0ull, p_any = __builtin_amdgcn_ballot_w64(p_on) != 0ull;
+                const int um = m_on ? tm : t, up = p_on ? tp : t;
+                if (m_any) {
+                    float P[D][D];
+                    load_inv(um, P);
+                    const float* Ltp = opaque(st_L(t));
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        CPPF_PCR_FENCE();
+                        float lt[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) lt[k] = Ltp[i * D + k];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) acc = CPPF_FMA(lt[k], P[k][j], acc);
+                            A[i][j] = m_on ? -acc : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) A[i][j] = 0.f;
+                }
+                if (p_any) {
+                    float P[D][D];
+                    load_inv(up, P);
+                    const float* Lpp = opaque(st_L(up));
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        CPPF_PCR_FENCE();
+                        float lp[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) lp[k] = Lpp[k * D + i];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) acc = CPPF_FMA(lp[k], P[k][j], acc);  // L_{t+s}^T D_{t+s}^-1
+                            G[i][j] = p_on ? -acc : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) G[i][j] = 0.f;
+                }
+                {
+                    const float *Ltp = st_L(t), *Lpp = st_L(up);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        CPPF_PCR_FENCE();
+#pragma unroll
+                        for (int i = 0; i < D; ++i) nD[i][j] = h == 0 ? own[sym_index<D>(i, j)] : 0.f;
+                        if (m_any) {
+                            float lt[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) lt[k] = Ltp[j * D + k];
+#pragma unroll
+                            for (int i = 0; i < D; ++i) {
+                                float accD = nD[i][j];
+#pragma unroll
+                                for (int k = 0; k < D; ++k) accD = CPPF_FMA(A[i][k], lt[k], accD);  // alpha L_t^T
+                                nD[i][j] = accD;
+                            }
+                        }
+                        CPPF_PCR_FENCE();
+                        if (p_any) {
+                            float lp[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) lp[k] = Lpp[k * D + j];
+#pragma unroll
+                            for (int i = 0; i < D; ++i) {
+                                float accD = nD[i][j];
+#pragma unroll
+                                for (int k = 0; k < D; ++k) accD = CPPF_FMA(G[i][k], lp[k], accD);  // gamma L_{t+s}
+                                nD[i][j] = accD;
+                            }
+                        }
+                    }
+                    CPPF_PCR_FENCE();
+                    if (m_any) {
+                        const float* nb = st_blk(um);
+                        float ym[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) ym[k] = nb[NT + k];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            float accy = ny[i];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) accy = CPPF_FMA(A[i][k], ym[k], accy);
+                            ny[i] = accy;
+                        }
+                    }
+                    if (p_any) {
+                        const float* nb = st_blk(up);
+                        float yp[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) yp[k] = nb[NT + k];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            float accy = ny[i];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) accy = CPPF_FMA(G[i][k], yp[k], accy);
+                            ny[i] = accy;
+                        }
+                    }
+                }
+                CPPF_PCR_FENCE();
+                // D_t to its packed symmetric form (what the write phase stores): gamma and half of D_t are dead from here
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = i; j < D; ++j) nD[i][j] = 0.5f * (nD[i][j] + nD[j][i]), nD[j][i] = nD[i][j];
+                if (m_any) {
+                    const float* Lmp = st_L(um);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        CPPF_PCR_FENCE();
+                        float lm[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) lm[k] = Lmp[k * D + j];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            float accL = 0.f;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) accL = CPPF_FMA(A[i][k], lm[k], accL);  // alpha L_{t-s}
+                            nL[i][j] = accL;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
+                }
+                } else {
+                    // the row-by-row form (faster where its 280 registers are there: one lane per waypoint at <= 7 joints -- 61 vs 73 us
+                    // for one Panda trajectory, profiles/r4_pcr_ab.txt): the own block first, nothing assigned conditionally
+                    if (h == 0) {
+                        load_sym(own, nD);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) nD[i][j] = 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) nL[i][j] = 0.f;
             if (tm >= 0) {
                 float P[D][D], Lt[D][D], Lm[D][D], ym[D];
                 const float* nb = st_blk(tm);
@@ -1331,6 +1536,7 @@ __global__ __launch_bounds__(BS) void full_solve_pcr_kernel(const ChainK ch, con
                     ny[i] = accy;
                 }
             }
+                }
             }  // st > 1
         }
         __syncthreads();  // every lane has read its neighbours' old state

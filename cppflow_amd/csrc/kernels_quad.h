@@ -346,8 +346,15 @@ __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const
 // component writes) 8 floats per capsule: P0 (3) pad, P1 (3) pad.
 __host__ __device__ __forceinline__ int quad_row_stride(int ncaps) { return ncaps * 8 + 4; }
 
+// Registers: two wavefronts per SIMD (256 registers) hold every chain up to 10 joints; at 11 and 12 joints that took 12 ... 148 B of
+// scratch per lane, so those instantiations are built for one wavefront per SIMD -- all this shape ever has resident anyway: it
+// serves launches of at most 16 384 rows = 1 024 wavefronts, one per SIMD of the chip.
+template <class RB>
+constexpr int quad_min_waves() {
+    return RB::D >= 11 ? 1 : 2;
+}
 template <class RB, int COLL, bool MFMA>
-__global__ __launch_bounds__(kBlock, 2) void lm_quad_kernel(const ChainK ch, const CollK co, const LmK prm,
+__global__ __launch_bounds__(kBlock, quad_min_waves<RB>()) void lm_quad_kernel(const ChainK ch, const CollK co, const LmK prm,
                                                             const float* __restrict__ x_in, const float* __restrict__ target,
                                                             const cppf_lm_outputs out, const uint4* __restrict__ tables) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Same-process A/B of the parallel-in-time elimination's forms (CPPF_TUNE_PCR_LDS: 0 workspace, 1 LDS, 2 LDS + split)."""
+"""Same-process A/B of the parallel-in-time elimination's forms (CPPF_TUNE_PCR_LDS: 0 workspace, 1 LDS, 2 LDS + split where the
+library uses it by default (up to kPcrSplitMaxD joints), 3 LDS + split forced)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,9 +19,9 @@ for name in ("panda", "fetch"):
         x0, target, _ = make_inputs_problem(rb, S, 256, dev, 0)
         fn = lambda: rb.lm_full_step(x0, target, ALT_LOSS_V2_1_DIFF)
         rb.debug_set("pcr_max_rows", 1 << 30)
-        res = {0: [], 1: [], 2: []}
+        res = {0: [], 1: [], 2: [], 3: []}
         for rnd in range(5):
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 rb.debug_set("pcr_lds", mode)
                 fn(); torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,4 +30,4 @@ for name in ("panda", "fetch"):
                 b.record(); torch.cuda.synchronize()
                 res[mode].append(a.elapsed_time(b) / 10 * 1e3)
         rb.debug_set("pcr_lds", 2); rb.debug_set("pcr_max_rows", -1)
-        print(f"{name:6s} S={S:4d} T=256: workspace {np.median(res[0]):7.1f}   LDS {np.median(res[1]):7.1f}   LDS + split {np.median(res[2]):7.1f} us", flush=True)
+        print(f"{name:6s} S={S:4d} T=256: workspace {np.median(res[0]):7.1f}   LDS {np.median(res[1]):7.1f}   LDS + split (default rule) {np.median(res[2]):7.1f}   LDS + split (forced) {np.median(res[3]):7.1f} us", flush=True)

@@ -16,7 +16,12 @@ constexpr int kBlock = 256;
 #include "kernels_quad.h"
 }  // namespace dev
 using namespace dev;
+
 template __global__ void dev::lm_quad_kernel<StaRobot<gen::Panda>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
-template __global__ void dev::lm_quad_kernel<StaRobot<gen::Panda>, 1, true>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
-template __global__ void dev::lm_quad_kernel<StaRobot<gen::Panda>, 0, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
-template __global__ void dev::lm_fused_kernel<StaRobot<gen::Panda>, 1>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs);
+template __global__ void dev::lm_quad_kernel<StaRobot<gen::Chain12>, 1, true>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<StaRobot<gen::Chain12>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<StaRobot<gen::Chain12>, 0, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<DynRobot<11>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<DynRobot<12>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<DynRobot<12>, 0, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);
+template __global__ void dev::lm_quad_kernel<DynRobot<10>, 1, false>(const ChainK, const CollK, const LmK, const float*, const float*, const cppf_lm_outputs, const uint4*);

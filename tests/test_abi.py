@@ -286,3 +286,22 @@ def test_build_id_covers_every_translation_unit_and_its_flags(monkeypatch):
     assert len(line) == 1, out
     vgpr, scratch = int(line[0].split()[1]), int(line[0].split()[7])
     assert vgpr <= 128 and scratch == 0, line[0]  # four wavefronts per SIMD, nothing spilled
+
+
+def test_no_kernel_of_the_library_touches_scratch(lib):
+    """the coupled step's parallel-in-time elimination at 8 joints (300 - 372 B per lane), the large-launch block kernel
+    of FetchArm and the generic 7- / 8-joint chains, and the four-lanes-per-row kernel at 11 / 12 joints spilled registers to scratch
+    memory.  Round 4: the elimination streams its coupling blocks instead of holding them, the other two are built for the
+    occupancy their registers allow.  Every kernel of the shipped code objects must report private_segment_fixed_size 0."""
+    import os
+    import subprocess
+    import sys
+
+    from cppflow_amd import build
+
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(build.CSRC), "..", "scripts", "kernel_resources.py")],
+                         capture_output=True, text=True, check=True).stdout
+    rows = [ln.split() for ln in out.splitlines() if ln.startswith("vgpr")]
+    assert len(rows) > 300, len(rows)  # every instantiation of both translation units
+    spilled = [" ".join(r[:10] + r[10:14]) for r in rows if int(r[7]) != 0]
+    assert not spilled, spilled
