@@ -258,9 +258,10 @@ constexpr int kNoDevice = -12345;  // cppf_robot_create's host-only mode (no HIP
 // two-ended row-per-lane kernels at d <= 7 (x 0.5 at d = 8): 512 trajectories x 256 waypoints with the state in LDS (W <= 256: one
 // workgroup per compute unit, so the time steps up at every multiple of 256 trajectories), 192 x 256 with the state in the workspace
 constexpr int kPcrMaxRowsLds = 131072, kPcrMaxRowsGlobal = 49152;
-// the split form of the LDS-resident reduction (two wavefront-uniform halves per waypoint) up to this many joints: measured -6 % at
-// d = 7; at d = 8 it was +9 % while it spilled 300 B per lane (round 3) -- spill-free since round 4, see profiles/r4_pcr_ab.txt
-constexpr int kPcrSplitMaxD = 7;
+// the split form of the LDS-resident reduction (two wavefront-uniform halves per waypoint) up to this many joints: -6 ... -8 % at
+// d = 7 (one Panda trajectory 64.4 -> 59.1 us), -5 % at d = 8 (Fetch 85.6 -> 81.4 us) since round 4 -- in round 3 it spilled 300 B
+// per lane there and lost 9 %; profiles/r4_pcr_ab.txt
+constexpr int kPcrSplitMaxD = 8;
 
 // dispatch on ndof: the light kernels are instantiated for the degrees of freedom of the shipped robots
 #define CPPF_DISPATCH_D(d, ...)                                                                               \
@@ -1300,17 +1301,20 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
             CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost,
                                                  k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT, spin));
         } else if (k <= 256) {
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D, 256>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
                                                  work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
                                                  work_memoT, spin));
-        } else if (k <= 512) {  // one source per lane, <= 128 workgroups
+        } else if (k <= 512 && tune(robot, CPPF_TUNE_DP_PERSISTENT) != 2) {  // the same form on 1 024 lanes, <= 128 workgroups
+            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D, 512>), dim3((unsigned)((k + 3) / 4)), dim3(1024), 0, st,
+                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
+                                                 work_memoT, spin));
+        } else if (k <= 512) {  // (CPPF_TUNE_DP_PERSISTENT = 2: the A/B) one source per lane and four destinations, <= 128 workgroups
             CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_resident_kernel<D, 1>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
                                                  work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
                                                  work_memoT, spin));
         } else {  // two sources per lane, <= 256 workgroups: one per compute unit
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_resident_kernel<D, 2>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
-                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
-                                                 work_memoT, spin));
+            CPPF_DISPATCH_D(d, dp_launch_two_sources<D>(tune(robot, CPPF_TUNE_DP_PERSISTENT) != 2, st, work_qT, ext_cost, k, T,
+                                                        robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT, spin));
         }
         hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
                        dp_stage_bytes(k, T) != 0, best_idx,

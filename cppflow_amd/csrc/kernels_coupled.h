@@ -1080,8 +1080,12 @@ __global__ __launch_bounds__(64) void full_rows_substitute_kernel(const FullK pr
 // kSplit (with kLds, BS = 512, T <= 256): TWO wavefront-uniform halves of the workgroup per waypoint -- lanes 0..255 do the
 // inverse and the t - s side of a level, lanes 256..511 the t + s side into a zero accumulator, which is added to the state in
 // a second write phase (two more barriers per level; the critical path of a level drops from inverse + both sides to inverse +
-// the longer side).  Same-process A/B (scripts/pcr_ab.py): one trajectory 66.1 -> 61.6 us, 512 trajectories 121 -> 114 us at
-// d = 7; slower at d = 8 (96 -> 105 us at 256 trajectories: register pressure), where the host keeps one lane per waypoint.
+// the longer side).  Same-process A/B (scripts/pcr_ab.py, profiles/r4_pcr_ab.txt): one trajectory 64.4 -> 59.1 us, 512 trajectories
+// 117 -> 108 us at d = 7; 85.6 -> 81.4 and 171 -> 160 us at d = 8.
+// Two forms of the general level (CPPF_PCR_LEAN): up to 7 joints the row-by-row form, which holds the inverse and both coupling
+// blocks in registers (250 of them); at 8 joints that form needs 340 and spilled 300 - 372 B per lane in the 512-lane
+// instantiations, so there the blocks are streamed from the state as they are used (236 - 250 registers, nothing spilled; at 7
+// joints the streamed form is 20 % slower than the row form -- 73 vs 59 us -- its loads sit in front of their uses).
 // index of element (i, j) in the packed upper triangle (row-major, D(D+1)/2 entries) of a symmetric D x D matrix
 template <int D>
 __device__ __forceinline__ constexpr int sym_index(int i, int j) {

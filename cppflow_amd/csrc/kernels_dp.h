@@ -216,27 +216,35 @@ __global__ __launch_bounds__(64) void dp_persistent_kernel(const float* __restri
 // The same recurrence with FOUR destinations per workgroup: half of the polling traffic of the one-wavefront-per-destination
 // form (k^2 / 2 instead of k^2 flag reads per step, which is what bounds that form from k ~ 64 up), at the price of one LDS
 // transpose + barrier per step (wavefront i reduces destination i by DPP; the image is double-buffered by the parity of t).
-template <int D>
-__global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
-                                                             int T, uint32_t pris_mask, float pscale, float* costsT,
-                                                             int32_t* __restrict__ memoT, uint32_t spin_budget) {
-    // 512 lanes: lane (h, a) = (tid >> 8, tid & 255) handles source a for destinations 2h and 2h + 1 of the workgroup's four, so
-    // the cost-independent part is two (source, destination) pairs per lane on two wavefronts per SIMD -- short enough to finish
-    // inside the hand-off latency for every ndof -- while each cost word is still polled by only two lanes per workgroup.
+// SRC = sources per half-workgroup = the most candidates the instantiation takes: 256 (512 lanes, k <= 256) or 512 (1 024 lanes,
+// 257 <= k <= 512, and with NS = 2 sources per lane 513 <= k <= 1024 up to 8 joints: sixteen wavefronts, four per SIMD -- the
+// cost-independent part of a step is 2 NS (source, destination) pairs per lane where dp_resident_kernel's 512 lanes meet four
+// destinations with NS sources each, twice as many).
+template <int D, int SRC, int NS = 1>
+__global__ __launch_bounds__(2 * SRC) void dp_persistent4_kernel(const float* __restrict__ qT, const float* __restrict__ ext, int k,
+                                                                 int T, uint32_t pris_mask, float pscale, float* costsT,
+                                                                 int32_t* __restrict__ memoT, uint32_t spin_budget) {
+    // 2 SRC lanes: lane (h, a) = (tid / SRC, tid % SRC) handles sources a (and a + SRC: NS = 2, 513 <= k <= 1024) for destinations 2h
+    // and 2h + 1 of the workgroup's four, so the cost-independent part is 2 NS (source, destination) pairs per lane -- short enough
+    // to finish inside the hand-off latency -- while each cost word is still polled by only two lanes per workgroup.
     constexpr int BP = 4;
-    __shared__ unsigned long long keys[2][BP][256];
+    static_assert(SRC == 256 || SRC == 512, "256 or 512 lanes per half-workgroup");
+    __shared__ unsigned long long keys[2][BP][SRC];
     const int b0 = blockIdx.x * BP, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = tid >> 8, a = tid & 255;  // k <= 256: one source per lane
-    const int asrc = min(a, k - 1);
-    // The operands of a step (this lane's source configuration at t - 1, its two destinations' at t, their external costs) depend
+    const int h = tid / SRC, a = tid & (SRC - 1);  // k <= NS SRC
+    // The operands of a step (this lane's source configurations at t - 1, its two destinations' at t, their external costs) depend
     // on nothing: they are loaded ONE STEP AHEAD, behind the arithmetic of the current step and in front of its wait, so that their
     // latency lies under the hand-off instead of in front of the next one (k = 175, T = 256: 491 -> measured in DESIGN.md 8.1).
-    float qa[D], qb[2][D], eb[2];
-    auto load_operands = [&](int t, float (&qa_)[D], float (&qb_)[2][D], float (&eb_)[2]) {
+    float qa[NS][D], qb[2][D], eb[2];
+    auto load_operands = [&](int t, float (&qa_)[NS][D], float (&qb_)[2][D], float (&eb_)[2]) {
         const float* q_prev = qT + (size_t)(t - 1) * k * D;
         const float* q_cur = qT + (size_t)t * k * D;
 #pragma unroll
-        for (int j = 0; j < D; ++j) qa_[j] = q_prev[(size_t)asrc * D + j];
+        for (int s = 0; s < NS; ++s) {
+            const int asrc = min(a + SRC * s, k - 1);
+#pragma unroll
+            for (int j = 0; j < D; ++j) qa_[s][j] = q_prev[(size_t)asrc * D + j];
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int b = min(b0 + 2 * h + u, k - 1);
@@ -249,37 +257,49 @@ __global__ __launch_bounds__(512) void dp_persistent4_kernel(const float* __rest
     for (int t = 1; t < T; ++t) {
         const float* cost_prev = costsT + (size_t)(t - 1) * k;
         // ---- independent of the costs ----
-        float m[2], e_now[2];
+        float m[NS][2], e_now[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            e_now[u] = eb[u];
-            float dq[D];
+        for (int u = 0; u < 2; ++u) e_now[u] = eb[u];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                dq[j] = qb[u][j] - qa[j];
-                if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
-            }
-            m[u] = max_wrapped_change<D>(dq);
-        }
-        if (t + 1 < T) load_operands(t + 1, qa, qb, eb);  // (in flight during the wait below)
-        // ---- dependent: wait for exactly the cost this lane reads ----
-        unsigned long long (*img)[256] = keys[t & 1];
-        {
-            float c = INFINITY;
-            if (a < k) c = dp_wait_cost(cost_prev + a, memoT, spin_budget);
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float v = fmaxf(m[u], c) + e_now[u];  // search.py:157-158
-                // lanes beyond k carry (+inf, 0), like the idle lanes of the per-waypoint kernel
-                img[2 * h + u][a] = a < k ? dp_key(v < INFINITY ? v : INFINITY, v < INFINITY ? a : 0) : dp_key(INFINITY, 0);
+                float dq[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    dq[j] = qb[u][j] - qa[s][j];
+                    if ((pris_mask >> j) & 1u) dq[j] *= pscale;  // search.py:119-121
+                }
+                m[s][u] = max_wrapped_change<D>(dq);
             }
+        if (t + 1 < T) load_operands(t + 1, qa, qb, eb);  // (in flight during the wait below)
+        // ---- dependent: wait for exactly the costs this lane reads ----
+        unsigned long long (*img)[SRC] = keys[t & 1];
+        {
+            // lanes / sources beyond k carry (+inf, 0), like the idle lanes of the per-waypoint kernel
+            unsigned long long best[2] = {dp_key(INFINITY, 0), dp_key(INFINITY, 0)};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int as = a + SRC * s;
+                if (as < k) {
+                    const float c = dp_wait_cost(cost_prev + as, memoT, spin_budget);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float v = fmaxf(m[s][u], c) + e_now[u];  // search.py:157-158
+                        const unsigned long long key = dp_key(v < INFINITY ? v : INFINITY, v < INFINITY ? as : 0);
+                        best[u] = NS == 1 || key < best[u] ? key : best[u];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) img[2 * h + u][a] = best[u];
         }
         __syncthreads();
         if (wave < BP) {
             const int i = wave;
             unsigned long long key = img[i][lane];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < SRC / 64; ++w) {
                 const unsigned long long o = img[i][lane + 64 * w];
                 key = o < key ? o : key;
             }
@@ -389,6 +409,22 @@ __global__ __launch_bounds__(512) void dp_resident_kernel(const float* __restric
             }
         }
     }
+}
+
+// 513 ... 1024 candidates in one resident launch: the 1 024-lane form of dp_persistent4_kernel with two sources per lane where its
+// registers allow four wavefronts per SIMD (up to 9 joints: 128 VGPRs without scratch), dp_resident_kernel (512 lanes, four
+// destinations x two sources per lane) beyond -- and as the A/B (`wide` = false: CPPF_TUNE_DP_PERSISTENT = 2)
+template <int D>
+inline void dp_launch_two_sources(bool wide, hipStream_t st, const float* qT, const float* ext, int k, int T, uint32_t pris_mask,
+                                  float pscale, float* costsT, int32_t* memoT, uint32_t spin) {
+    const dim3 grid((unsigned)((k + 3) / 4));
+    if constexpr (D <= 9) {
+        if (wide) {
+            hipLaunchKernelGGL((dp_persistent4_kernel<D, 512, 2>), grid, dim3(1024), 0, st, qT, ext, k, T, pris_mask, pscale, costsT, memoT, spin);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((dp_resident_kernel<D, 2>), grid, dim3(512), 0, st, qT, ext, k, T, pris_mask, pscale, costsT, memoT, spin);
 }
 
 // ---- the recurrence on ONE compute unit, from a precomputed transition table (k <= 256) -------------------------------------------

@@ -132,12 +132,17 @@ __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_i
 // promises; so does the single bare step (clamp = 0, the reference's own cadence).
 //
 // Two instantiations per kernel.  LEAD = true is a LEADING iteration of a plain K-step launch (iterations 0 .. K-2, the hot loop):
-// the hardware's sine / cosine (sincos_hw: 3 instructions per joint instead of 23, 4e-7 absolute), no early-out tests, no J / e
-// outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration in the canonical arithmetic: the LAST
-// iteration of every launch -- so x_out is always one canonical LM step from its predecessor, and a K = 1 launch (the reference's
-// cadence) is canonical throughout -- and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
+// no early-out tests, no J / e outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration: the LAST
+// iteration of every launch, and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
+// CPPF_LEAD_HW_SINCOS = 1 lets the leading iterations evaluate sine / cosine with v_sin_f32 / v_cos_f32 (sincos_hw: 3 instructions per
+// joint instead of 23, 4e-7 absolute; the last iteration stays canonical, so x_out is one canonical LM step from its predecessor).
+// OFF by default: measured on one box, alternating builds (profiles/r4_ab_hw_sincos.txt), the C4 step takes 37.45 - 37.51 us with it
+// against 36.33 - 36.44 us without -- 140 fewer VALU instructions per iteration (-23 % executed) and 3 % MORE time: the fourteen
+// transcendental operations per iteration serialise the four wavefronts of a SIMD on the one quarter-rate unit, where the polynomial
+// form is plain multiply-adds that any wavefront can issue.  (Round 3 had measured -2.6 % for it on an isolated launch, where that
+// unit has no second taker; at the step rate, two launches in flight, it is the other way round.)
 #ifndef CPPF_LEAD_HW_SINCOS
-#define CPPF_LEAD_HW_SINCOS 1  // 0: the leading iterations use the canonical sine / cosine too (the A/B build of scripts/make_variant_build.py)
+#define CPPF_LEAD_HW_SINCOS 0  // 1: hardware sine / cosine in the leading iterations (the A/B build of scripts/make_variant_build.py)
 #endif
 template <class RB, bool LEAD>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,

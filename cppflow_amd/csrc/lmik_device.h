@@ -184,9 +184,9 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
 }
 
 // The hardware's own sine / cosine (v_sin_f32 / v_cos_f32 take REVOLUTIONS, valid for |x| <= 256 of them; joint angles are bounded by
-// the joint limits): 3 instructions instead of 23, 4e-7 of absolute error (scripts/ubench/hw_sincos.hip).  Used ONLY by the leading
-// iterations of a fused K-step launch, whose iterates nobody sees: the last iteration -- the one that decides x_out -- every iteration
-// of an early-out launch, and everything in the bit-exact set (FK, capsules, metrics, masks) use sincos_cw.
+// the joint limits): 3 instructions instead of 23, 4e-7 of absolute error (scripts/ubench/hw_sincos.hip).  Only an A/B build uses it
+// (CPPF_LEAD_HW_SINCOS, kernels_fused.h: in the leading iterations of a fused K-step launch it costs 3 % at the step rate); the shipped
+// kernels and everything in the bit-exact set (FK, capsules, metrics, masks) use sincos_cw.
 __device__ __forceinline__ void sincos_hw(float x, float& s, float& c) {
     const float r = x * 0.15915494309189535f;
     s = __builtin_amdgcn_sinf(r);

@@ -77,11 +77,8 @@ typedef struct cppf_lm_params {
     float lm_lambda;      /* OptimizationParameters.lm_lambda      (ALT_LOSS_V2_1_POSE: 1e-6, :123) */
     float alpha_position; /* OptimizationParameters.alpha_position (3.5,  :125) */
     float alpha_rotation; /* OptimizationParameters.alpha_rotation (0.35, :126) */
-    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration).  The LAST
-                           * iteration of a launch -- the one that produces x_out -- is always evaluated in the canonical arithmetic
-                           * (the sine / cosine the bit-exact FK uses); the K - 1 iterations before it, whose iterates are not
-                           * outputs, use the hardware's v_sin_f32 / v_cos_f32 (4e-7 absolute) in the row shape.  A K = 1 launch (the
-                           * reference's cadence) and every iteration of an early-out launch are canonical throughout. */
+    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration), every one of
+                           * them in the canonical arithmetic (the sine / cosine the bit-exact FK uses). */
     int32_t clamp;        /* 1: clamp_to_joint_limits after every step (the reference loop); 0: bare step (K must be 1) */
     /* Early-out (0 = off): a row whose residual at the start of an iteration has ||t_target - t|| < tol_pos_m and
      * ||(roll, pitch, yaw)|| < tol_rot_rad is left untouched from then on, and a wavefront whose rows are all below

@@ -27,7 +27,9 @@ extern "C" {
 /* CPPF_SHAPE_AUTO runs four lanes per row up to n rows unless a per-seed summary is requested.  Default 16384 = one wavefront
  * of that shape per SIMD, the measured crossover. */
 #define CPPF_TUNE_QUAD_MAX_ROWS 2
-/* 0: cppf_dp_search in CPPF_DP_AUTO mode issues one launch per waypoint instead of the single resident launch (k <= 1024).  Default 1. */
+/* 0: cppf_dp_search in CPPF_DP_AUTO mode issues one launch per waypoint instead of the single resident launch (k <= 1024); 2: the
+ * resident launch for 257 ... 512 candidates is dp_resident_kernel (512 lanes, four destinations per lane) instead of the 1 024-lane
+ * form of dp_persistent4_kernel (the A/B of scripts/dp_bench.py).  Default 1. */
 #define CPPF_TUNE_DP_PERSISTENT 3
 /* 0: cppf_lm_full_step eliminates with one wavefront per trajectory, first waypoint to last (cross-lane reads through the LDS
  * pipe), instead of eight trajectories per wavefront, one block row per lane (DPP), from both ends of the path; d <= 8, beyond

@@ -18,8 +18,11 @@ for name in ("panda", "fetch", "chain12"):
         def call(mode):
             _hip.check(_hip.lib().cppf_dp_search(h, q.data_ptr(), ext.data_ptr(), k, T, 5.0, qT.data_ptr(), cT.data_ptr(), mT.data_ptr(), bp.data_ptr(), bi.data_ptr(), mode, torch.cuda.current_stream(dev).cuda_stream))
         out = []
-        for mode in (_hip.DP_RESIDENT, _hip.DP_LAUNCHES):
-            call_m = lambda: call(mode)
+        for mode in (_hip.DP_RESIDENT, _hip.DP_LAUNCHES) + ((-_hip.DP_RESIDENT,) if k > 256 else ()):
+            # (a negative mode: the resident launch in its 512-lane form beyond 256 candidates, CPPF_TUNE_DP_PERSISTENT = 2 -- the A/B
+            # of the 1 024-lane form that is the default since round 4)
+            rb.debug_set("dp_persistent", 2 if mode < 0 else 1)
+            call_m = lambda: call(abs(mode))
             for _ in range(5): call_m()
             torch.cuda.synchronize()
             ts = []
@@ -27,6 +30,7 @@ for name in ("panda", "fetch", "chain12"):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); call_m(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
             out.append(np.median(ts))
+        rb.debug_set("dp_persistent", 1)
         assert int(bi[0].item()) >= 0
         tabled = float("nan")
         if k <= 256:
@@ -43,4 +47,4 @@ for name in ("panda", "fetch", "chain12"):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(); call_t(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
             tabled = np.median(ts)
-        print(f"{name:8s} dp_search k={k:5d} T={T:4d}   table + one compute unit {tabled:8.1f} us   resident single launch {out[0]:8.1f} us   per-waypoint launches {out[1]:8.1f} us", flush=True)
+        print(f"{name:8s} dp_search k={k:5d} T={T:4d}   table + one compute unit {tabled:8.1f} us   resident single launch {out[0]:8.1f} us   per-waypoint launches {out[1]:8.1f} us" + (f"   resident, 512-lane form {out[2]:8.1f} us" if len(out) > 2 else ""), flush=True)

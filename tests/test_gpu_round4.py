@@ -255,13 +255,13 @@ def test_f64_mode_re_solves_rows_that_leave_the_joint_limits(name):
 
 
 def test_leading_iterations_do_not_move_the_fixed_point():
-    """cppf_lm_params.n_steps: the K - 1 leading iterations of a plain fused launch evaluate sine / cosine with v_sin_f32 / v_cos_f32
-    (4e-7 absolute), the LAST iteration -- the one that produces x_out -- in the canonical arithmetic.  So: (1) a K = 1 launch is
+    """cppf_lm_params.n_steps: the K - 1 leading iterations of a plain fused launch run a leaner instantiation of the iteration (no
+    early-out tests, no J / e outputs; in the CPPF_LEAD_HW_SINCOS = 1 A/B build also v_sin_f32 / v_cos_f32, 4e-7 absolute), the LAST
+    iteration -- the one that produces x_out -- the general one.  So, whichever build: (1) a K = 1 launch is
     canonical (bit for bit the early-out launch that freezes nothing); (2) after K = 10 steps the converged rows sit at the same pose
-    error as an all-canonical launch (an early-out launch whose tolerances nothing meets) and as the fp64 oracle's own iteration, to
-    1e-5 -- the metric's bar -- and to 2e-6 against the all-canonical launch: the approximation moves intermediate iterates, not the
-    point the iteration converges to; (3) masks and cost are evaluated at x_out in the canonical arithmetic either way: bit-exact
-    against the fp32 oracle at the launch's own x."""
+    error as an all-general launch (an early-out launch whose tolerances nothing meets) and as the fp64 oracle's own iteration, to
+    1e-5 -- the metric's bar -- and to 2e-6 against the all-general launch; (3) masks and cost are evaluated at x_out in the canonical
+    arithmetic either way: bit-exact against the fp32 oracle at the launch's own x."""
     from cppflow_amd.robots import get_robot
 
     for name in ("panda", "fetch", "chain12"):
@@ -292,8 +292,9 @@ def test_leading_iterations_do_not_move_the_fixed_point():
 @pytest.mark.parametrize("name,k,T", [("panda", 257, 40), ("panda", 300, 256), ("panda", 512, 33), ("panda", 513, 33), ("panda", 1024, 64),
                                       ("panda", 1000, 17), ("fetch", 300, 64), ("chain12", 300, 48), ("chain12", 1024, 12)])
 def test_resident_dp_search_beyond_256_candidates(name, k, T):
-    """cppf_dp_search in ONE resident launch up to k = 1024 (dp_resident_kernel: four destinations per workgroup, at most 256
-    workgroups, one or two sources per lane): the reference's rerun searches 300 candidates (cppflow/planners.py:47, 253-258), eight
+    """cppf_dp_search in ONE resident launch up to k = 1024 (four destinations per workgroup, at most 256 workgroups, one or two
+    sources per lane; dp_persistent4_kernel on 1 024 lanes, dp_resident_kernel on 512 for 513+ candidates of chains of 10+ joints and
+    as the A/B): the reference's rerun searches 300 candidates (cppflow/planners.py:47, 253-258), eight
     ranks gather 1024.  Cost table, argmins (the whole memo table) and path bit for bit against one launch per waypoint and against
     the fp32 oracle restatement of cppflow/search.py:128-191, with ties, +inf columns and candidates that share configurations."""
     from cppflow_amd.robots import get_robot
@@ -317,6 +318,16 @@ def test_resident_dp_search_beyond_256_candidates(name, k, T):
         assert np.array_equal(a, b), ("resident vs per-waypoint launches", i)
     auto = rb.dp_search(dev(q), dev(ext), return_method=True)
     assert auto[-1] == "resident" and np.array_equal(auto[1].cpu().numpy(), got["launches"][1])
+    # the other resident form of this size (CPPF_TUNE_DP_PERSISTENT = 2: dp_resident_kernel, 512 lanes x four destinations, instead of
+    # the 1 024-lane form of dp_persistent4_kernel that is the default up to 9 joints)
+    rb.debug_set("dp_persistent", 2)
+    try:
+        path2, idx2, costs2, memo2, ran2 = rb.dp_search(dev(q), dev(ext), method="resident", return_memo=True, return_method=True)
+    finally:
+        rb.debug_set("dp_persistent")
+    assert ran2 == "resident"
+    for i, (a, b) in enumerate(zip((host(path2), idx2.cpu().numpy(), host(costs2), memo2.cpu().numpy()), got["launches"])):
+        assert np.array_equal(a, b), ("resident (512-lane form) vs per-waypoint launches", i)
     want_idx, want_costs = H.oracle32(name).dp_search(q, ext)
     assert np.array_equal(got["resident"][2].T, want_costs) and np.array_equal(got["resident"][1], want_idx)
     assert np.array_equal(got["resident"][0], q[want_idx, np.arange(T)])
