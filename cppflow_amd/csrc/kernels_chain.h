@@ -44,9 +44,9 @@ __device__ __forceinline__ void fk_ee(const RB& rb, const float (&q)[RB::D], flo
     fk_fixed_ee(rb, R, p);
 }
 
-// FK keeping every joint's world axis and origin (for the Jacobian).  FAST: the hardware's sine / cosine (sincos_hw) -- the leading
+// FK keeping every joint's world axis and origin (for the Jacobian).  SC != 0: a cheaper sine / cosine (fk_joint) -- the leading
 // iterations of a fused K-step launch only.
-template <class RB, bool FAST = false>
+template <class RB, int SC = 0>
 __device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D], float (&R)[9], float (&p)[3],
                                            float (&ax)[RB::D][3], float (&og)[RB::D][3]) {
     frame_identity(R, p);
@@ -58,7 +58,7 @@ __device__ __forceinline__ void fk_ee_axes(const RB& rb, const float (&q)[RB::D]
             ax[j][i] = R[3 * i + 2];
             og[j][i] = p[i];
         }
-        fk_joint<FAST>(R, p, rb.pris(j), q[j]);
+        fk_joint<SC>(R, p, rb.pris(j), q[j], rb.lo(j), rb.hi(j));
     }
     fk_fixed_ee(rb, R, p);
 }

@@ -185,12 +185,46 @@ __device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
 
 // The hardware's own sine / cosine (v_sin_f32 / v_cos_f32 take REVOLUTIONS, valid for |x| <= 256 of them; joint angles are bounded by
 // the joint limits): 3 instructions instead of 23, 4e-7 of absolute error (scripts/ubench/hw_sincos.hip).  Only an A/B build uses it
-// (CPPF_LEAD_HW_SINCOS, kernels_fused.h: in the leading iterations of a fused K-step launch it costs 3 % at the step rate); the shipped
+// (CPPF_LEAD_SINCOS = 1, kernels_fused.h: in the leading iterations of a fused K-step launch it costs 3 % at the step rate); the shipped
 // kernels and everything in the bit-exact set (FK, capsules, metrics, masks) use sincos_cw.
 __device__ __forceinline__ void sincos_hw(float x, float& s, float& c) {
     const float r = x * 0.15915494309189535f;
     s = __builtin_amdgcn_sinf(r);
     c = __builtin_amdgcn_cosf(r);
+}
+
+// Sine / cosine of an angle inside the joint limits WITHOUT a quadrant reduction: one polynomial each on [-pi, pi] in u = r^2
+// (sin r = r P5(u), cos r = Q6(u); least-squares on Chebyshev nodes, 4.9e-7 / 3.8e-7 of absolute error evaluated in fp32 -- the
+// rounding of the alternating terms near +-pi, not the truncation), 13 multiply-adds where sincos_cw takes 23 instructions of which
+// eight are the integer quadrant logic.  FOLD says how the argument gets into [-pi, pi]: 0 it is there (the joint's limits say so:
+// every joint of the shipped robots but Panda's sixth), +1 / -1 one conditional turn down / up (limits within [-pi, 3 pi] /
+// [-3 pi, pi]), 2 the general reduction by whole turns.  Like sincos_hw only for the leading iterations of a fused K-step launch
+// (CPPF_LEAD_SINCOS = 2, kernels_fused.h), whose iterates nobody sees; never in the bit-exact set.
+constexpr float kPiF = 3.14159274101257324f, kTwoPiF = 6.28318548202514648f;
+template <int FOLD>
+__device__ __forceinline__ void sincos_pi(float x, float& s, float& c) {
+    float r = x;
+    if constexpr (FOLD == 1) r = x > kPiF ? x - kTwoPiF : x;
+    if constexpr (FOLD == -1) r = x < -kPiF ? x + kTwoPiF : x;
+    if constexpr (FOLD == 2) {
+        const float magic = 12582912.0f;
+        const float k = CPPF_FMA(x, 0.15915494309189535f, magic) - magic;  // whole turns, round to nearest
+        r = CPPF_FMA(-k, 1.9353071795864769e-3f, CPPF_FMA(-k, 6.28125f, x));
+    }
+    const float u = r * r;
+    float ps = -2.0696598213e-08f, pc = 1.7243808603e-09f;
+    ps = CPPF_FMA(ps, u, 2.7087969556e-06f);
+    pc = CPPF_FMA(pc, u, -2.7078681342e-07f);
+    ps = CPPF_FMA(ps, u, -1.9817604334e-04f);
+    pc = CPPF_FMA(pc, u, 2.4769848096e-05f);
+    ps = CPPF_FMA(ps, u, 8.3327908069e-03f);
+    pc = CPPF_FMA(pc, u, -1.3887801906e-03f);
+    ps = CPPF_FMA(ps, u, -1.6666620970e-01f);
+    pc = CPPF_FMA(pc, u, 4.1666489094e-02f);
+    ps = CPPF_FMA(ps, u, 9.9999994040e-01f);
+    pc = CPPF_FMA(pc, u, -4.9999988079e-01f);
+    s = ps * r;
+    c = CPPF_FMA(pc, u, 1.0f);
 }
 
 // ---- canonical FK steps ---------------------------------------------------------------------------------------------------
@@ -227,14 +261,26 @@ __device__ __forceinline__ void fk_fixed_ee(const RB& rb, float (&R)[9], float (
 }
 
 // frame <- frame * M_z(q): rotation about (revolute) or translation along (prismatic) the local z axis
-template <bool FAST = false>
-__device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool prismatic, float q) {
+// SC: 0 the canonical sine / cosine (sincos_cw: everything in the bit-exact set), 1 the hardware's (sincos_hw), 2 the full-range
+// polynomials (sincos_pi; `lo`, `hi` = the joint's limits, compile-time constants in the robot-specialised kernels, pick the fold)
+template <int SC = 0>
+__device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool prismatic, float q, float lo = 0.f, float hi = 0.f) {
     if (!prismatic) {
         float s, c;
-        if constexpr (FAST)
+        if constexpr (SC == 1) {
             sincos_hw(q, s, c);
-        else
+        } else if constexpr (SC == 2) {
+            if (lo >= -kPiF && hi <= kPiF)
+                sincos_pi<0>(q, s, c);
+            else if (lo >= -kPiF && hi <= 3.f * kPiF)
+                sincos_pi<1>(q, s, c);
+            else if (lo >= -3.f * kPiF && hi <= kPiF)
+                sincos_pi<-1>(q, s, c);
+            else
+                sincos_pi<2>(q, s, c);
+        } else {
             sincos_cw(q, s, c);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             // a0, a1 are literals for the first joint of a specialised chain (R = F_0): cmul / cfma fold the 0 / +-1 cases

@@ -3,7 +3,7 @@
 headline unit (csrc/fused_static.hip: the row-shape fused kernel of the shipped robots, ~1 minute), with --unit cppflow_hip.hip the
 rest of the library (~3.5 minutes); that unit is recompiled with the extra defines and linked with the in-tree object of the other.
 
-    python scripts/make_variant_build.py build_var/lib_canon.so -DCPPF_LEAD_HW_SINCOS=0
+    python scripts/make_variant_build.py build_var/lib_canon.so -DCPPF_LEAD_SINCOS=0
     python scripts/make_variant_build.py --unit cppflow_hip.hip build_var/lib_x.so '-DCPPF_PCR_FENCE()=((void)0)'
 
 Use with CPPFLOW_HIP_LIB=<that file> (scripts/lib_ab.sh alternates libraries on one box)."""

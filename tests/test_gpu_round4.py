@@ -256,7 +256,7 @@ def test_f64_mode_re_solves_rows_that_leave_the_joint_limits(name):
 
 def test_leading_iterations_do_not_move_the_fixed_point():
     """cppf_lm_params.n_steps: the K - 1 leading iterations of a plain fused launch run a leaner instantiation of the iteration (no
-    early-out tests, no J / e outputs; in the CPPF_LEAD_HW_SINCOS = 1 A/B build also v_sin_f32 / v_cos_f32, 4e-7 absolute), the LAST
+    early-out tests, no J / e outputs; and a cheaper sine / cosine valid inside the joint limits -- CPPF_LEAD_SINCOS, kernels_fused.h: 5e-7 absolute), the LAST
     iteration -- the one that produces x_out -- the general one.  So, whichever build: (1) a K = 1 launch is
     canonical (bit for bit the early-out launch that freezes nothing); (2) after K = 10 steps the converged rows sit at the same pose
     error as an all-general launch (an early-out launch whose tolerances nothing meets) and as the fp64 oracle's own iteration, to
@@ -287,6 +287,43 @@ def test_leading_iterations_do_not_move_the_fixed_point():
         assert np.abs(pe_p - pe_x).max() < 1e-5 and np.abs(re_p - np.maximum(re_x, 8.94427191e-4)).max() < 1e-5
         m = o32.masks(x, None, None, None, None)
         assert np.array_equal(plain["self_mask"].cpu().numpy(), m["self_mask"])
+
+
+def test_rows_outside_the_joint_limits_and_their_wavefront_neighbours():
+    """The inner iterations of a fused K-step launch evaluate sine / cosine with polynomials that are valid inside the joint limits
+    (CPPF_LEAD_SINCOS, kernels_fused.h).  The launch's own input need not be: the reference steps from wherever the seed is and clamps
+    afterwards (cppflow/optimization.py:258-259).  So (1) rows that start OUTSIDE their limits -- by a little, by several turns -- must
+    end where the fp64 oracle's iteration ends (pose error within 1e-5 on the rows it converges), and (2) the rows that share a
+    wavefront with them must come out bit for bit as in a launch where those neighbours are ordinary rows: the choice of arithmetic
+    is made per iteration, never per wavefront."""
+    from cppflow_amd.robots import get_robot
+
+    for name in ("panda", "fetch"):
+        rb, ch, o64 = get_robot(name), H.chain(name), H.oracle64(name)
+        S, W, K = 4, 64, 10
+        x0, target = H.lm_problem(name, S, W, seed=5)
+        tgt = H.stacked(target, S)
+        rng = np.random.RandomState(3)
+        rev = np.array([j for j in range(ch.ndof) if ch.jtype[j] == 0])
+        x_out_of = x0.copy()
+        rows = rng.choice(S * W, size=24, replace=False)
+        for n, r in enumerate(rows):
+            j = rev[n % len(rev)]
+            x_out_of[r, j] = (ch.hi[j] + 0.3) if n % 3 == 0 else ((ch.lo[j] - 0.7) if n % 3 == 1 else x0[r, j] + 2 * np.pi * (1 + n % 2))
+        x_out_of = H.f32(x_out_of)
+        a = rb.lm_pose_steps(dev(x_out_of), dev(target), n_steps=K, want_errors=True, **LM)
+        b = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, **LM)
+        others = np.setdiff1d(np.arange(S * W), rows)
+        assert np.array_equal(host(a["x"])[others], host(b["x"])[others]), name
+        xo = o64.lm_steps(x_out_of, tgt, K, solver=0, **LM)
+        pe_o, re_o = o64.pose_metrics_exact(xo, tgt)
+        pe, re = host(a["pos_err_m"]), host(a["rot_err_rad"])
+        conv = (pe_o < 1e-5) & (re_o < 1e-3)
+        assert conv[rows].mean() > 0.4, (name, conv[rows].mean())
+        sel = rows[conv[rows]]
+        assert np.abs(pe[sel] - pe_o[sel]).max() < 1e-5 and np.abs(re[sel] - np.maximum(re_o[sel], 8.94427191e-4)).max() < 1e-5, name
+        lo, hi = H.f32(ch.lo), H.f32(ch.hi)
+        assert (host(a["x"]) >= lo).all() and (host(a["x"]) <= hi).all()
 
 
 @pytest.mark.parametrize("name,k,T", [("panda", 257, 40), ("panda", 300, 256), ("panda", 512, 33), ("panda", 513, 33), ("panda", 1024, 64),
