@@ -236,7 +236,7 @@ def test_validity_flags_agree_with_reference_order_fp32_formula(robots, name):
     print(f"{name}: {n_band} of {S * W} rows inside the acos quantisation band, {n_disagree} flag disagreements, all inside it")
 
 
-CONV_FLOOR = {"C2": 0.95, "C3": 0.5, "C4": 0.95}  # measured 0.980 / 0.553 (Fetch: the prismatic torso runs into its limits) / 0.980
+CONV_FLOOR = {"C2": 0.95, "C3": 0.9, "C4": 0.95}  # measured 0.980 / 0.99 (0.553 in round 3, when a Fetch seed drew a lift height per waypoint: DESIGN.md section 2) / 0.980
 
 CONFIGS = {
     "C2": ("panda", "panda__1cube_first64", 128, []),
