@@ -131,9 +131,9 @@ __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_i
 // 2 us per iteration behind the others).  CPPF_SOLVER_F64 (gate_thr = -inf) re-solves EVERY row, clamped or not, as the header
 // promises; so does the single bare step (clamp = 0, the reference's own cadence).
 //
-// Two instantiations per kernel.  LEAD = true is an INNER iteration of a plain K-step launch (iterations 1 .. K-2, the hot loop):
-// no early-out tests, no J / e outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration: the first
-// and the LAST iteration of every launch, and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
+// LEAD = true is a lean iteration of a plain K-step launch (iterations 0 .. K-2; FIRST = the launch's first one; 1 .. K-2 the hot
+// loop): no early-out tests, no J / e outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration:
+// the LAST iteration of every launch, and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
 // CPPF_LEAD_SINCOS: which sine / cosine the leading iterations use -- in the robot-specialised AND the generic kernels alike (the
 // generic ones pick a joint's fold from its limits with a scalar branch where the specialised ones know it at compile time: the same
 // arithmetic either way, so the two stay bit-identical, tests/test_gpu_parity.py).
@@ -145,18 +145,22 @@ __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_i
 //      needed by the very next instructions of the serial FK chain.  (Round 3 had measured -2.6 % for it on an isolated launch.)
 //   2  (default) the full-range polynomials (sincos_pi: 13 plain multiply-adds per joint, no quadrant logic, 5e-7 absolute; one
 //      conditional turn for a joint whose limits reach beyond +-pi).  Valid INSIDE the joint limits, which every iterate after the
-//      first clamp is; the launch's own input need not be, which is why the FIRST iteration of a launch is the general one too.
+//      first clamp is; the launch's own input need not be, which is why the FIRST iteration of a launch reduces by whole turns first
+//      (mode 3 of fk_joint: 17 multiply-adds per joint, any finite angle).
 //      Measured like 1 (profiles/r4_ab_sincos_poly.txt): 34.96 - 35.14 us against 36.35 - 36.49 us per C4 step (-3.8 %; -5.6 % with K - 1
 //      lean iterations, which needed a per-wavefront decision on the input).
-// Whatever the mode, the first and the LAST iteration are canonical: x_out is one canonical LM step from its predecessor.
+// Whatever the mode, the LAST iteration is canonical: x_out is one canonical LM step from its predecessor.
 #ifndef CPPF_LEAD_SINCOS
 #define CPPF_LEAD_SINCOS 2
 #endif
-template <class RB, bool LEAD>
+#ifndef CPPF_FIRST_LEAN
+#define CPPF_FIRST_LEAN 1  // the first iteration of a plain launch: 1 lean with the any-angle form of the polynomials, 0 general
+#endif
+template <class RB, bool LEAD, bool FIRST = false>
 constexpr int lead_sincos() {
-    return LEAD ? CPPF_LEAD_SINCOS : 0;
+    return LEAD ? (FIRST && CPPF_LEAD_SINCOS == 2 ? 3 : CPPF_LEAD_SINCOS) : 0;
 }
-template <class RB, bool LEAD>
+template <class RB, bool LEAD, bool FIRST = false>
 __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, const cppf_lm_outputs& out, size_t row, bool last,
                                                const float (&Rt)[9], const float (&tt)[3], float* __restrict__ gate_lds,
                                                float (&q)[RB::D]) {
@@ -165,7 +169,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
     bool conv = false;
     {
         float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6];
-        fk_ee_axes<RB, lead_sincos<RB, LEAD>()>(rb, q, R, p, ax, og);
+        fk_ee_axes<RB, lead_sincos<RB, LEAD, FIRST>()>(rb, q, R, p, ax, og);
         pose_error(Rt, tt, R, p, e);
         if constexpr (!LEAD) {
             if (prm.tol_pos2 > 0.f) {  // wave-uniform
@@ -220,7 +224,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
                         float R2[9], p2[3], ax2[D][3], og2[D][3], J2[6][D], e2[6];
 #pragma unroll
                         for (int j = 0; j < D; ++j) asm volatile("" : "+v"(q[j]));  // (unchanged, but the compiler must not know)
-                        fk_ee_axes<RB, lead_sincos<RB, LEAD>()>(rb, q, R2, p2, ax2, og2);
+                        fk_ee_axes<RB, lead_sincos<RB, LEAD, FIRST>()>(rb, q, R2, p2, ax2, og2);
                         pose_error(Rt, tt, R2, p2, e2);
                         jacobian_from_axes<RB>(rb, p2, ax2, og2, J2);
                         rank = lm_gate_hand_over<D>(J2, e2, todo, gate_lds, flag);
@@ -399,16 +403,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
         asm volatile("" : "+s"(bad_mask));
         float* const gate_lds = s_gate[__builtin_amdgcn_readfirstlane(tid >> 6)];  // wave-uniform: a scalar base
         int iters = 0, it = 0;
-        // A plain launch: the FIRST iteration general (the launch's own input need not lie inside the joint limits, which the lean
-        // iteration's sine / cosine assumes, CPPF_LEAD_SINCOS = 2; every later iterate has been through the clamp -- K > 1 implies
-        // clamp = 1), then the hot loop: K - 2 lean iterations (lm_row_iterate<LEAD = true>), then -- below -- the last one, general
-        // again.  Decided per ITERATION, never per wavefront: a row's result does not depend on which rows share its wavefront.
-        // Three straight-line regions, the general body twice in the code (+800 instructions): with ONE copy of each body -- both in
-        // one loop behind a branch, or an outer loop of two passes -- the same arithmetic ran 6 % slower (36.6 against 34.3 us per C4
-        // step) or spilled 40 B per lane.
+        // A plain launch: the FIRST iteration lean too, but with the polynomials behind a reduction by whole turns (the launch's own
+        // input need not lie inside the joint limits, which the plain lean iteration's sine / cosine assumes, CPPF_LEAD_SINCOS = 2;
+        // every later iterate has been through the clamp -- K > 1 implies clamp = 1), then the hot loop: K - 2 lean iterations, then
+        // -- below -- the last one, general and canonical.  Decided per ITERATION, never per wavefront: a row's result does not depend
+        // on which rows share its wavefront.  Three straight-line regions: with ONE copy of each body -- both in one loop behind a
+        // branch, or an outer loop of two passes -- the same arithmetic ran 6 % slower (36.6 against 34.3 us per C4 step) or spilled
+        // 40 B per lane.  (CPPF_FIRST_LEAN = 0 makes the first iteration a general one: +0.6 %, profiles/r4_ab_first_lean.txt.)
         if (!(prm.tol_pos2 > 0.f)) {  // wave-uniform
             if (prm.n_steps >= 2) {
-                (void)lm_row_iterate<RB, false>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
+                (void)lm_row_iterate<RB, CPPF_FIRST_LEAN != 0, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
                 it = 1;
             }
             for (; it < prm.n_steps - 1; ++it) (void)lm_row_iterate<RB, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);

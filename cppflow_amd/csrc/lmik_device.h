@@ -262,13 +262,16 @@ __device__ __forceinline__ void fk_fixed_ee(const RB& rb, float (&R)[9], float (
 
 // frame <- frame * M_z(q): rotation about (revolute) or translation along (prismatic) the local z axis
 // SC: 0 the canonical sine / cosine (sincos_cw: everything in the bit-exact set), 1 the hardware's (sincos_hw), 2 the full-range
-// polynomials (sincos_pi; `lo`, `hi` = the joint's limits, compile-time constants in the robot-specialised kernels, pick the fold)
+// polynomials (sincos_pi; `lo`, `hi` = the joint's limits, compile-time constants in the robot-specialised kernels, pick the fold),
+// 3 the same polynomials behind the reduction by whole turns (valid for any finite angle)
 template <int SC = 0>
 __device__ __forceinline__ void fk_joint(float (&R)[9], float (&p)[3], bool prismatic, float q, float lo = 0.f, float hi = 0.f) {
     if (!prismatic) {
         float s, c;
         if constexpr (SC == 1) {
             sincos_hw(q, s, c);
+        } else if constexpr (SC == 3) {  // the polynomials behind the general reduction: any finite angle (a launch's own input)
+            sincos_pi<2>(q, s, c);
         } else if constexpr (SC == 2) {
             if (lo >= -kPiF && hi <= kPiF)
                 sincos_pi<0>(q, s, c);

@@ -77,11 +77,12 @@ typedef struct cppf_lm_params {
     float lm_lambda;      /* OptimizationParameters.lm_lambda      (ALT_LOSS_V2_1_POSE: 1e-6, :123) */
     float alpha_position; /* OptimizationParameters.alpha_position (3.5,  :125) */
     float alpha_rotation; /* OptimizationParameters.alpha_rotation (0.35, :126) */
-    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration).  The first and
-                           * the LAST iteration of a launch -- the one that produces x_out -- are evaluated in the canonical arithmetic
-                           * (the sine / cosine the bit-exact FK uses); the K - 2 iterations between them, whose iterates are not
-                           * outputs and lie inside the joint limits (they have been through the clamp), use a cheaper sine / cosine
-                           * in the row shape (polynomials on [-pi, pi], 5e-7 absolute).  K <= 2 launches (K = 1 is the reference's
+    int32_t n_steps;      /* K >= 1 fused { step ; clamp } iterations (cppflow/optimization.py:258-259 per iteration).  The LAST
+                           * iteration of a launch -- the one that produces x_out -- is evaluated in the canonical arithmetic (the
+                           * sine / cosine the bit-exact FK uses); the K - 1 iterations before it, whose iterates are not outputs,
+                           * use a cheaper sine / cosine in the row shape (polynomials on [-pi, pi], 5e-7 absolute; the first
+                           * iteration behind a reduction by whole turns -- the input need not lie inside the joint limits --
+                           * the others directly: their iterates have been through the clamp).  A K = 1 launch (the reference's
                            * cadence) and every iteration of an early-out launch are canonical throughout. */
     int32_t clamp;        /* 1: clamp_to_joint_limits after every step (the reference loop); 0: bare step (K must be 1) */
     /* Early-out (0 = off): a row whose residual at the start of an iteration has ||t_target - t|| < tol_pos_m and
