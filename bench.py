@@ -973,6 +973,8 @@ def main():
     obstacles = obstacle_arrays(PANDA_2CUBES_OBSTACLES) if (collide and args.config != "C3") else []
     robot.set_obstacles([c for c, _ in obstacles], [T for _, T in obstacles])
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
+    if os.environ.get("CPPF_BENCH_GATE_REL_PPM"):  # developer sweep of the lean iterations' relative gate (cppflow_hip_debug.h)
+        robot.debug_set("gate_rel_ppm", int(os.environ["CPPF_BENCH_GATE_REL_PPM"]))
     if os.environ.get("CPPF_BENCH_SPREAD_KB"):  # developer sweep of the residency claim of small launches (cppflow_hip_debug.h)
         robot.debug_set("spread_kb", int(os.environ["CPPF_BENCH_SPREAD_KB"]))
     shape = {"auto": _hip.SHAPE_AUTO, "row": _hip.SHAPE_ROW, "quad": _hip.SHAPE_QUAD}[args.shape]

@@ -111,7 +111,7 @@ namespace {
 constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
     /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
     /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
-    /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,
+    /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,    /* GATE_REL_PPM */ (int)(kGateRel * 1e6f + 0.5f),
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
 
@@ -628,7 +628,7 @@ int cppf_clamp_to_joint_limits(const cppf_robot* robot, float* x, int n, void* s
 namespace {
 
 // cppf_lm_params -> the kernels' LmK (validation included); n / W are the caller's to fill
-int make_lm_kernel_params(const cppf_lm_params* params, LmK& prm) {
+int make_lm_kernel_params(const cppf_robot* robot, const cppf_lm_params* params, LmK& prm) {
     CPPF_REQUIRE(params, "params is NULL");
     CPPF_REQUIRE(params->n_steps >= 1, "n_steps must be >= 1");
     CPPF_REQUIRE(params->clamp == 1 || params->n_steps == 1, "clamp = 0 is only defined for a single step");
@@ -653,12 +653,17 @@ int make_lm_kernel_params(const cppf_lm_params* params, LmK& prm) {
     const float tau = params->solver_gate > 0.f ? params->solver_gate : CPPF_SOLVER_GATE_DEFAULT;
     const float a_max = std::fmax(params->alpha_position, params->alpha_rotation);
     prm.gate_thr = params->solver == CPPF_SOLVER_F32 ? INFINITY : params->solver == CPPF_SOLVER_F64 ? -INFINITY : tau / (6e-8f * a_max);
+    // ... and, in the lean iterations of a fused launch, only when that estimate is also more than kGateRel of the residual the step
+    // reduces (kernels_fused.h: an intermediate iterate needs a step that is accurate RELATIVE to its residual)
+    const float rel = 1e-6f * (float)tune(robot, CPPF_TUNE_GATE_REL_PPM) / (6e-8f * a_max);  // (kGateRel unless a test changed it)
+    prm.gate_rel2 = rel * rel;
     prm.n_steps = params->n_steps;
     prm.clamp = params->clamp;
     prm.n = 0;
     prm.W = 0;
-    prm.tol_pos2 = params->tol_pos_m * params->tol_pos_m;
-    prm.tol_rot2 = params->tol_rot_rad * params->tol_rot_rad;
+    // (squared tolerances; a positive tolerance whose square underflows still means "early-out on": the smallest normal float)
+    prm.tol_pos2 = params->tol_pos_m > 0.f ? std::fmax(params->tol_pos_m * params->tol_pos_m, 1.17549435e-38f) : 0.f;
+    prm.tol_rot2 = params->tol_rot_rad > 0.f ? std::fmax(params->tol_rot_rad * params->tol_rot_rad, 1.17549435e-38f) : 0.f;
     return CPPF_OK;
 }
 
@@ -731,7 +736,7 @@ int cppf_lm_pose_steps(const cppf_robot* robot, const float* x_in, const float* 
     CPPF_REQUIRE(params && out, "params / out is NULL");
     CPPF_REQUIRE(S >= 0 && W >= 0, "S / W < 0");
     LmK prm;
-    if (int rc = make_lm_kernel_params(params, prm)) return rc;
+    if (int rc = make_lm_kernel_params(robot, params, prm)) return rc;
     const size_t n = (size_t)S * W;
     if (n == 0) return CPPF_OK;
     CPPF_REQUIRE(n <= 0x7fffffffu, "S*W exceeds 2^31-1 rows");
@@ -833,7 +838,7 @@ int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_bat
     *out = nullptr;
     CPPF_REQUIRE(items && n_items >= 1 && n_items <= CPPF_MAX_BATCH, "n_items must be in 1 .. CPPF_MAX_BATCH");
     LmK prm;
-    if (int rc = make_lm_kernel_params(params, prm)) return rc;
+    if (int rc = make_lm_kernel_params(robot, params, prm)) return rc;
     CPPF_REQUIRE(params->shape != CPPF_SHAPE_QUAD, "a batched launch is the row shape (CPPF_SHAPE_AUTO or CPPF_SHAPE_ROW)");
     std::vector<unsigned char> host(sizeof(BatchHeadK) + (size_t)n_items * sizeof(BatchItemK));
     BatchHeadK* head = reinterpret_cast<BatchHeadK*>(host.data());

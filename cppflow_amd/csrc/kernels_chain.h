@@ -367,6 +367,9 @@ __device__ __forceinline__ void lm_primal_solve(const float (&J)[6][D], const fl
 // order.  On a planner's inputs 17 % of the wavefronts take the detour in the first iteration and <= 3 % later (bench.py's C4
 // workload, scripts/gate_census.py); independent random configurations (13 % of the rows flagged at first) are the worst case.
 constexpr int kGateSlots = 8;
+// lean iterations of a fused launch re-solve a flagged row only when the estimated step error also exceeds this fraction of the
+// (scaled) residual norm (kernels_fused.h: lm_row_iterate<LEAD = true>)
+constexpr float kGateRel = 1e-3f;
 // floats of LDS per wavefront (also what the host sizes the residency claim of small launches by, cppflow_hip.hip)
 constexpr int gate_lds_floats(int d) { return (6 * d + 6 + 2 * (21 + 6)) * kGateSlots; }
 // Upper bound of a fused kernel's STATIC LDS (bytes): the gate's slots of its kBlock / 64 wavefronts (declared for every ndof) + the per-seed

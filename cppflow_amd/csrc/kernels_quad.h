@@ -186,7 +186,7 @@ __device__ __forceinline__ void chol6_solve(const float (&A)[6][6], const float 
 // below the early-out tolerances (then it is left untouched), like lm_row_iterate.
 template <class RB, bool MFMA>
 __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const QuadLane& k, const float (&Rt)[9], float tt_own,
-                                             float lam_r, float lam_p, float (&q)[RB::D]) {
+                                             float lam_r, float lam_p, float (&q)[RB::D], bool lean) {
     constexpr int D = RB::D;
     static_assert(D >= 6, "the quad shape solves the dual 6x6 system (ndof >= 6)");
     float sn[D], cs[D];
@@ -310,6 +310,14 @@ __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const
                 }
                 flag = flag && !cut;
             }
+            // ... and in an iteration in front of the last one of a plain launch (`lean`, wave-uniform) only when the estimate also
+            // exceeds kGateRel of the residual norm the step reduces -- the row shape's rule again (lm_row_iterate<LEAD = true>)
+            if (lean && prm.gate_thr > -INFINITY) {
+                const float es2 = CPPF_FMA(prm.a_pos * prm.a_pos, dot3(e[3], e[4], e[5], e[3], e[4], e[5]),
+                                           prm.a_rot * prm.a_rot * dot3(e[0], e[1], e[2], e[0], e[1], e[2]));
+                flag = flag && (dmax * ymax) * (dmax * ymax) > prm.gate_rel2 * es2;
+            }
+            if (__builtin_amdgcn_ballot_w64(flag) != 0ull) {
             float Jf[6][D], d64[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -325,6 +333,7 @@ __device__ __forceinline__ bool quad_iterate(const RB& rb, const LmK& prm, const
             lm_dual_solve_f64<D>(Jf, e, prm.lam_r_d, prm.lam_p_d, d64);
 #pragma unroll
             for (int j = 0; j < D; ++j) delta[j] = flag ? d64[j] : delta[j];
+            }
         }
     }
     if (prm.tol_pos2 > 0.f) {
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(kBlock, quad_min_waves<RB>()) void lm_quad_kernel(c
     const float lam_r = prm.lam_r, lam_p = prm.lam_p;
     int iters = 0;
     for (int it = 0; it < prm.n_steps; ++it) {
-        const bool conv = quad_iterate<RB, MFMA>(rb, prm, k, Rt, tt_own, lam_r, lam_p, q);
+        const bool conv = quad_iterate<RB, MFMA>(rb, prm, k, Rt, tt_own, lam_r, lam_p, q, !(prm.tol_pos2 > 0.f) && it < prm.n_steps - 1);
         iters += conv ? 0 : 1;
         if (prm.tol_pos2 > 0.f && __builtin_amdgcn_ballot_w64(!conv) == 0ull) break;
     }

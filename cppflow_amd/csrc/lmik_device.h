@@ -65,6 +65,7 @@ struct LmK {
     float tol_pos2, tol_rot2;  // early-out (cppf_lm_params.tol_*), squared; 0 = off
     float gate_thr;            // conditioning gate of the damped solve: a row whose  max diag(A) * max |y|  exceeds this redoes the
                                // solve in double precision (lm_solve_gated); +inf = never (pure fp32), -inf = always (pure fp64)
+    float gate_rel2;           // lean iterations only (kernels_fused.h): ... and exceeds sqrt(gate_rel2) x the scaled residual norm
 };
 
 // One problem of a fused launch: what cppf_lm_pose_steps takes as (x_in, target, S * W, W, outputs).  The same layout sits in the

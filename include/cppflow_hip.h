@@ -100,8 +100,11 @@ typedef struct cppf_lm_params {
      *     and factoring A = J J^T + lambda S^-2, known once y = A^-1 e is) exceeds `solver_gate` redoes the solve in double
      *     precision.  The step is then never farther from the exactly solved one than the reference's own fp32 arithmetic
      *     (torch.linalg.solve on the primal system, cppflow/optimization.py:85-88) gets -- near-singular rows included.
-     *     One exception, inside a clamped launch (clamp = 1): a flagged row whose fp32 step leaves the joint limits keeps the fp32
-     *     step -- where it lands is decided by the clamp, not by the last digits of the solve.
+     *     Two exceptions, both inside a clamped launch (clamp = 1): a flagged row whose fp32 step leaves the joint limits keeps the
+     *     fp32 step -- where it lands is decided by the clamp, not by the last digits of the solve; and in the K - 1 iterations in
+     *     front of the LAST one (whose iterates are intermediates; both kernel shapes) a flagged row is re-solved only when the estimate also
+     *     exceeds a thousandth of the residual norm the step reduces -- an intermediate step has to be accurate relative to its
+     *     residual; the last iteration, a K = 1 launch and every iteration of an early-out launch keep the absolute bar.
      *   CPPF_SOLVER_F64: every row in double precision (J J^T, its factorisation, the substitutions and J^T y): the exactly
      *     solved step of the fp32 Jacobian on every row, clamped or not (task-space difference to the fp64 oracle <= 6e-7).  A verification mode: every
      *     wavefront runs eight re-solve rounds per iteration (~10x the iteration time).

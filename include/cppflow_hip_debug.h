@@ -52,7 +52,12 @@ extern "C" {
  * that does not find its word at the first read expire at once: how the tests reach the timeout path (best_idx = -1) and the
  * caller's fall-back to one launch per waypoint. */
 #define CPPF_TUNE_DP_SPIN_LOG2 9
-#define CPPF_TUNE_COUNT 10
+/* parts per million of the (scaled) residual norm that the estimated error of a LEAN iteration's fp32 step must exceed, besides the
+ * absolute gate, before the row is re-solved in double precision (CPPF_SOLVER_AUTO, both kernel shapes; the last iteration of a launch, the
+ * early-out iterations and a K = 1 launch keep the absolute gate alone).  Default 1000 (kGateRel, csrc/kernels_chain.h); 0 = the
+ * absolute gate in every iteration. */
+#define CPPF_TUNE_GATE_REL_PPM 10
+#define CPPF_TUNE_COUNT 11
 
 int cppf_debug_set(cppf_robot* robot, int key, int value);
 int cppf_debug_get(const cppf_robot* robot, int key, int* value);

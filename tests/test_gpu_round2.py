@@ -92,13 +92,13 @@ def test_early_out_freezes_converged_rows_and_counts_iterations(panda):
     it = early["n_iters"].cpu().numpy()
     assert it.min() >= 1 and it.max() <= K and (it < K).mean() > 0.8, (it.min(), it.max(), (it < K).mean())
     # a row frozen after k steps equals the k-step result of a launch that freezes nothing, bit for bit.  (An early-out launch runs
-    # EVERY iteration in the canonical arithmetic -- its frozen iterates are results; a plain K-step launch evaluates the sine /
-    # cosine of its K - 1 leading iterations with the hardware instructions, include/cppflow_hip.h: cppf_lm_params.n_steps -- so the
-    # comparison launch is an early-out one whose tolerances nothing can meet.)
+    # EVERY iteration in the canonical arithmetic and with the absolute gate -- its frozen iterates are results; a plain K-step launch
+    # runs its K - 1 leading iterations lean, include/cppflow_hip.h: cppf_lm_params.n_steps -- so the comparison launch is an early-out
+    # one whose tolerances nothing can meet: 1e-18, whose SQUARE is still a normal float -- 1e-30 squared is 0 = early-out off.)
     xe = host(early["x"])
     for k in (int(np.median(it)), int(it.min())):
         rows = it == k
-        xk = host(panda.lm_pose_steps(dev(x0), dev(target), n_steps=k, tol_pos_m=1e-30, tol_rot_rad=1e-30, **LM)["x"])
+        xk = host(panda.lm_pose_steps(dev(x0), dev(target), n_steps=k, tol_pos_m=1e-18, tol_rot_rad=1e-18, **LM)["x"])
         assert np.array_equal(xe[rows], xk[rows])
         # and a plain k-step launch has converged on those rows as well (one more step than the frozen rows needed to be below tolerance)
         rp = panda.lm_pose_steps(dev(x0), dev(target), n_steps=k + 1, want_errors=True, **LM)

@@ -154,11 +154,16 @@ def test_a_row_does_not_depend_on_which_rows_share_its_wavefront(name):
     rb = get_robot(name)
     x0, target = H.lm_problem(name, 64, 64, seed=5)
     tg = np.tile(target, (64, 1))  # one target per row: the launch is one "seed" of n waypoints
-    for solver in (_hip.SOLVER_AUTO, _hip.SOLVER_F64):
+    # three regimes: the default (round 4: the lean iterations re-solve a row only when its step error is also large RELATIVE to the
+    # residual -- few rows), the absolute gate in every iteration (cppf_debug_set gate_rel_ppm = 0: a tenth of the rows, more than
+    # eight in some wavefronts, i.e. several rounds), and every row in double precision
+    for solver, ppm in ((_hip.SOLVER_AUTO, None), (_hip.SOLVER_AUTO, 0), (_hip.SOLVER_F64, None)):
+        rb.debug_set("gate_rel_ppm", ppm)  # (None: the default)
         full = rb.lm_pose_steps(dev(x0), dev(tg), n_steps=3, want_errors=True, shape=_hip.SHAPE_ROW, solver=solver, **LM)
         xf, pf = full["x"].cpu(), full["pos_err_m"].cpu()
         flagged = (rb.lm_pose_steps(dev(x0), dev(tg), n_steps=3, shape=_hip.SHAPE_ROW, solver=_hip.SOLVER_F32, **LM)["x"].cpu() != xf).any(dim=1)
-        assert flagged.float().mean() > 0.01, (name, solver, flagged.float().mean())  # the gate is at work on these rows
+        if ppm == 0 or solver == _hip.SOLVER_F64:
+            assert flagged.float().mean() > 0.01, (name, solver, ppm, flagged.float().mean())  # the gate is at work on these rows
         for n in (1, 2, 9, 63, 65, 127, 200, 1000, 4059, 4095):
             r = rb.lm_pose_steps(dev(x0[:n]), dev(tg[:n]), n_steps=3, want_errors=True, shape=_hip.SHAPE_ROW, solver=solver, **LM)
             assert torch.equal(r["x"].cpu(), xf[:n]) and torch.equal(r["pos_err_m"].cpu(), pf[:n]), (name, solver, n)
@@ -168,6 +173,7 @@ def test_a_row_does_not_depend_on_which_rows_share_its_wavefront(name):
         perm = np.random.RandomState(1).permutation(x0.shape[0])
         pr = rb.lm_pose_steps(dev(x0[perm]), dev(tg[perm]), n_steps=3, shape=_hip.SHAPE_ROW, solver=solver, **LM)
         assert torch.equal(pr["x"].cpu(), xf[torch.as_tensor(perm)]), (name, solver, "permuted")
+    rb.debug_set("gate_rel_ppm")
 
 
 def _coupled_case(name, S, T, seed):

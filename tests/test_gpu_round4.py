@@ -172,7 +172,9 @@ def test_batched_launch_is_hip_graph_capturable_and_sees_obstacle_updates():
         st.synchronize()
         eager = [{k: v.clone() for k, v in out.items()} for out in plan.outputs]
         for it, e in zip(items, eager):
-            ref = rb.lm_pose_steps(it["x"], it["target"], n_steps=3, want_collisions=True, **LM)
+            from cppflow_amd import _hip
+
+            ref = rb.lm_pose_steps(it["x"], it["target"], n_steps=3, want_collisions=True, shape=_hip.SHAPE_ROW, **LM)  # (the batch's kernel)
             assert torch.equal(ref["env_mask"], e["env_mask"])
         assert sum(int(e["env_mask"].sum()) for e in eager) > 0
         for out in plan.outputs:
@@ -270,10 +272,10 @@ def test_leading_iterations_do_not_move_the_fixed_point():
         x0, target = H.lm_problem(name, S, W, seed=17)
         tgt = H.stacked(target, S)
         one = rb.lm_pose_steps(dev(x0), dev(target), n_steps=1, **LM)["x"]
-        one_c = rb.lm_pose_steps(dev(x0), dev(target), n_steps=1, tol_pos_m=1e-30, tol_rot_rad=1e-30, **LM)["x"]
+        one_c = rb.lm_pose_steps(dev(x0), dev(target), n_steps=1, tol_pos_m=1e-18, tol_rot_rad=1e-18, **LM)["x"]
         assert torch.equal(one, one_c), name
         plain = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, want_collisions=True, **LM)
-        canon = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, tol_pos_m=1e-30, tol_rot_rad=1e-30, **LM)
+        canon = rb.lm_pose_steps(dev(x0), dev(target), n_steps=K, want_errors=True, tol_pos_m=1e-18, tol_rot_rad=1e-18, **LM)
         xo = o64.lm_steps(x0, tgt, K, solver=0, **LM)
         pe_o, re_o = o64.pose_metrics_exact(xo, tgt)
         pe_p, re_p, pe_c, re_c = host(plain["pos_err_m"]), host(plain["rot_err_rad"]), host(canon["pos_err_m"]), host(canon["rot_err_rad"])
