@@ -34,7 +34,7 @@ exactly K steps: barrier + synchronize, clock, the K steps (+ the exchange of a 
 clock; the maximum over ranks is reported.  The group's CLOSING barrier comes after the clock has stopped (its cost is recorded in
 config.timed_region.closing_barrier_us): at the driver's `--steps 20` a sharded region is ~100 us long, and an 8-rank barrier
 inside it would be most of what is timed.  The region is measured `--repeats` (5) times back to back and the MEDIAN is reported; a
-region shorter than 1 ms `--short-region-repeats` (16) more times -- every repetition exactly K steps (all of them in
+region shorter than 0.4 ms `--short-region-repeats` (16) more times (behind a pre-warm and warm-up of their own) -- every repetition exactly K steps (all of them in
 config.timed_region.ms_per_step_all).  Consecutive steps are independent batches (a ring of output-buffer sets) alternating
 between `--streams` HIP streams.
 
@@ -383,7 +383,7 @@ def parse_args(argv=None):
                     help="the timed region (exactly --steps steps between barrier + synchronize pairs) is measured this many times "
                     "back to back; value / ms_per_step are the MEDIAN repetition (min and max in config.timed_region)")
     ap.add_argument("--short-region-repeats", type=int, default=16,
-                    help="a timed region shorter than 1 ms is measured this many times more (same exactly---steps regions; the median "
+                    help="a timed region shorter than 0.4 ms is measured this many times more (same exactly---steps regions; the median "
                     "of all repetitions is reported); 0 = never")
     ap.add_argument("--kernel-reps", type=int, default=400,
                     help="isolated launches behind roofline.kernel_ms (median of HIP-event pairs after a pre-warm)")
@@ -693,6 +693,9 @@ class Runner:
         else:
             self.gathered = self.selected = None
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.n_streams)]
+        self.start_bucket = int(os.environ["CPPF_BENCH_START_BUCKET"]) if os.environ.get("CPPF_BENCH_START_BUCKET") else None  # (developer override)
+        self.start_bucket_calibration_us_per_step = None
+        self.region_prewarm = int(os.environ.get("CPPF_BENCH_REGION_PREWARM", "0"))
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream(device))
         self.step_no = 0  # always a multiple of B: the ring position of the next launch
@@ -777,7 +780,7 @@ class Runner:
                 self.exchange((self.step_no % self.NBUF) // self.G)
             self.step_no += self.G - self.step_no % self.G  # the next step starts a fresh bucket
 
-    def timed(self, steps, warmup, prewarm_ms, barrier, repeats=1, closing_barrier=None, warm=True):
+    def timed(self, steps, warmup, prewarm_ms, barrier, repeats=1, closing_barrier=None):
         """`prewarm_ms` of untimed launches (sustained clocks, full pipeline), W untimed warm-up steps, then `repeats` times:
         opening barrier + synchronize, clock, exactly `steps` steps (+ the exchange of a partly filled bucket), THIS RANK's
         synchronize, clock.  The group's closing barrier (`closing_barrier`, N > 1) comes after the clock: the caller takes the
@@ -787,26 +790,55 @@ class Runner:
         # bare full launches round-robin over the groups and streams
         t_pre = time.perf_counter()
         ngroups = self.NBUF // self.B
-        while warm and (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+        while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
             for i in range(max(1, 48 // self.B)):
                 g = i % ngroups
                 self.launches[g][self.B - 1].launch_on(self.stream_of(g * self.B))
             torch.cuda.synchronize()
-        if warm:  # (warm = False: further repetitions of the timed region right behind earlier ones)
-            self.run_steps(warmup)
-            self.drain()
-        out, closing = [], []
-        for _ in range(max(1, repeats)):
+        self.run_steps(warmup)
+        self.drain()
+        # Which stream a region starts on matters when the region is a handful of launches: with two buckets of 8 steps on two
+        # streams, a 20-step region of a 32 768-row shard (launches of 8 / 8 / 4 steps) takes 6.9 us per step when it starts on the
+        # first stream and 6.25 when it starts on the second, every time (profiles/r4_start_bucket.txt; the ring position used to
+        # alternate between repetitions, and the timings with it).  So, once per run and untimed: four regions from each bucket, the
+        # better one is where every timed region starts (the ring may restart anywhere: everything issued before has completed).
+        # Every rank runs the same number of calibration regions -- they contain collectives -- and decides for itself.
+        def region():
+            """one repetition: opening barrier, clock, exactly `steps` steps + drain, this rank's synchronize, clock, closing barrier"""
             barrier()
+            if self.region_prewarm > 0:
+                # the group's barrier leaves the GPU idle for 50 - 150 us and the clocks drop with it: a few bare launches (no
+                # collectives; the same fixed number on every rank) and a synchronize bring them back before the clock starts
+                for i in range(self.region_prewarm):
+                    g = i % ngroups
+                    self.launches[g][self.B - 1].launch_on(self.stream_of(g * self.B))
+                torch.cuda.synchronize()
+            if self.start_bucket is not None:
+                self.step_no = self.start_bucket * self.G
             t0 = time.perf_counter()
             self.run_steps(steps)
             self.drain()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            out.append(t1 - t0)
+            tc = None
             if closing_barrier is not None:
                 closing_barrier()
-                closing.append(time.perf_counter() - t1)
+                tc = time.perf_counter() - t1
+            return t1 - t0, tc
+
+        if self.start_bucket is None and self.buckets and self.transport is not None and self.n_streams >= 2 and steps < self.NBUF * 4:
+            med = []
+            for sb in range(self.n_streams):
+                self.start_bucket = sb
+                med.append(float(np.median([region()[0] for _ in range(4)])))  # (the very repetition that is timed below)
+            self.start_bucket = int(np.argmin(med))
+            self.start_bucket_calibration_us_per_step = [1e6 * m / steps for m in med]
+        out, closing = [], []
+        for _ in range(max(1, repeats)):
+            dt, tc = region()
+            out.append(dt)
+            if tc is not None:
+                closing.append(tc)
         return out, closing
 
     def host_enqueue_us(self):
@@ -1042,6 +1074,12 @@ def main():
     # (a region of K steps holds at least two full buckets when it can: at the driver's --steps 20 and 8 steps per launch that is one
     # exchange behind every launch -- two launches on two streams in flight -- instead of one bucket that serialises two launches)
     G = max(batch, (min(G_req, max(args.steps // 2, 1)) // batch) * batch)
+    # ... and in a region of only a few buckets every launch is followed by its own exchange (one bucket = one launch), so that
+    # consecutive launches alternate between the streams like those of an N = 1 run: with 8-step buckets the driver's 20-step region
+    # of a 512-seed shard (4 + 4 + 2 launches of two steps) put four launches in a row on one stream and ended on two that ran alone
+    # -- 23.9 against 19.4 us per step; 45.1 against 36.8 for 1024 seeds per rank (profiles/r4_short_region_buckets.txt)
+    if args.gather_every <= 0 and args.steps < 4 * G:
+        G = batch
     # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
     n_streams = args.streams if args.streams > 0 else (4 if rows_launch <= 131072 else 2)
 
@@ -1053,12 +1091,15 @@ def main():
     reps_local, closing_local = run.timed(args.steps, args.warmup, args.prewarm_ms, barrier, args.repeats, closing_barrier if dist is not None else None)
     reps_s = [max_over_ranks(t) for t in reps_local]
     closing_us = [1e6 * max_over_ranks(t) for t in closing_local]
-    # A region shorter than a millisecond (the driver's --steps 20: 0.74 ms at N = 1, ~0.12 ms for a 32 768-row shard) is at the mercy
-    # of single host hiccups -- five repetitions of the shard region came out as 6.05, 6.07, 7.53, 7.75 and 9.89 us per step on one
+    # A region of a few hundred microseconds (the driver's --steps 20 is ~0.12 ms for a 32 768-row shard; 0.74 ms at N = 1, which
+    # repeats to within 0.5 % and is left alone) is at the mercy of single host hiccups -- five repetitions of the shard region came out as 6.05, 6.07, 7.53, 7.75 and 9.89 us per step on one
     # box -- so such a run repeats the region `--short-region-repeats` more times (every rank takes the same decision: it is made on
     # the maximum over ranks) and reports the median of all of them; every repetition is still exactly --steps steps.
-    if args.short_region_repeats > 0 and float(np.median(reps_s)) < 1e-3:
-        more_local, more_closing = run.timed(args.steps, 0, 0, barrier, args.short_region_repeats, closing_barrier if dist is not None else None, warm=False)
+    if args.short_region_repeats > 0 and float(np.median(reps_s)) < 0.4e-3:
+        # (behind its own pre-warm and warm-up steps: the decision above cost the GPU an idle gap, and the first launches after one
+        # run at lower clocks -- without it the extra repetitions of an N = 1 region came out 15 - 30 % long)
+        more_local, more_closing = run.timed(args.steps, args.warmup, args.prewarm_ms, barrier, args.short_region_repeats,
+                                             closing_barrier if dist is not None else None)
         reps_s += [max_over_ranks(t) for t in more_local]
         closing_us += [1e6 * max_over_ranks(t) for t in more_closing]
     elapsed = float(np.median(reps_s))
@@ -1279,7 +1320,9 @@ def main():
                                  "ms_per_step_all": [1e3 * t / args.steps for t in reps_s],
                                  "clock": "opening barrier + synchronize | K steps (+ the exchange of a partly filled bucket) | this rank's "
                                           "synchronize; maximum over ranks.  The group's closing barrier follows the clock.",
-                                 "closing_barrier_us": closing_us if closing_us else None},
+                                 "closing_barrier_us": closing_us if closing_us else None,
+                                 "region_start_bucket": run.start_bucket,
+                                 "region_start_bucket_calibration_us_per_step": run.start_bucket_calibration_us_per_step},
                 "steps_per_launch": run.B,
                 "launches_per_region": f"{args.steps // run.B} x {run.B} steps" + (f" + 1 x {args.steps % run.B} steps" if args.steps % run.B else ""),
                 "rows_per_launch": run.n * run.B,
