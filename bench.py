@@ -1078,8 +1078,10 @@ def main():
     # consecutive launches alternate between the streams like those of an N = 1 run: with 8-step buckets the driver's 20-step region
     # of a 512-seed shard (4 + 4 + 2 launches of two steps) put four launches in a row on one stream and ended on two that ran alone
     # -- 23.9 against 19.4 us per step; 45.1 against 36.8 for 1024 seeds per rank (profiles/r4_short_region_buckets.txt)
+    # (a bucket stays two launches where that is still at most 8 steps of a shard of <= 65 536 rows: 10.65 against 11.5 us per step for
+    # 256 seeds per rank)
     if args.gather_every <= 0 and args.steps < 4 * G:
-        G = batch
+        G = batch if (rows_main > 65536 or 2 * batch > 8) else 2 * batch
     # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
     n_streams = args.streams if args.streams > 0 else (4 if rows_launch <= 131072 else 2)
 
