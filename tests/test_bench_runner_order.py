@@ -1,0 +1,80 @@
+"""bench.Runner.run_steps / drain without a GPU: the ORDER in which a rank issues its launches and exchange steps -- what the N > 1
+line of bench.py rests on and what no one-GPU box can show on RCCL.  The Runner is built around stand-ins (no robot, no streams):
+launches and exchanges only record themselves."""
+
+import pytest
+
+import bench
+
+
+class _Launch:
+    def __init__(self, log, group, steps):
+        self.log, self.group, self.steps = log, group, steps
+
+    def launch_on(self, stream):
+        self.log.append(("launch", self.group, self.steps, stream))
+
+
+def _runner(B, G, n_streams, transport=True):
+    r = object.__new__(bench.Runner)
+    r.B, r.G, r.n_streams = B, G, n_streams
+    r.buckets = transport
+    r.transport = object() if transport else None
+    r.NBUF = n_streams * G if transport else max(4, n_streams) * B
+    r.graphs = None
+    r.step_no = 0
+    r.streams = [f"s{i}" for i in range(n_streams)]
+    r.log = []
+    r.launches = [[_Launch(r.log, g, c + 1) for c in range(B)] for g in range(r.NBUF // B)]
+    r.exchange = lambda bucket: r.log.append(("exchange", bucket))
+    return r
+
+
+def _steps(log):
+    return sum(e[2] for e in log if e[0] == "launch")
+
+
+@pytest.mark.parametrize("B,G,steps", [(8, 8, 20), (4, 8, 20), (2, 2, 20), (1, 1, 20), (8, 64, 2000), (1, 8, 37), (4, 4, 3)])
+def test_exactly_the_requested_steps_and_every_bucket_exchanged_once_behind_its_last_launch(B, G, steps):
+    r = _runner(B, G, 2)
+    r.run_steps(steps)
+    r.drain()
+    assert _steps(r.log) == steps
+    # on each stream the order is: the bucket's launches, then its exchange, then the next use of that bucket
+    last_launch_of = {}
+    open_bucket = None
+    for i, e in enumerate(r.log):
+        if e[0] == "launch":
+            bucket = (e[1] * B) // G
+            assert e[3] == f"s{bucket}"  # a bucket's launches all go to its own stream
+            assert last_launch_of.get(bucket, (None, True))[1], (i, e, "launch into a bucket whose exchange has not been issued")
+            last_launch_of[bucket] = (i, (e[1] * B + B) % G != 0)  # second item: bucket still filling
+            open_bucket = bucket
+        else:
+            assert e[1] in last_launch_of, (i, e)
+            last_launch_of[e[1]] = (last_launch_of[e[1]][0], True)
+    # nothing is left unexchanged when the region ends (the clock stops after the partly filled bucket's exchange too)
+    n_launched_buckets = len({(e[1] * B) // G for e in r.log if e[0] == "launch"})
+    assert len([e for e in r.log if e[0] == "exchange"]) >= n_launched_buckets
+    assert r.log[-1][0] == "exchange"
+    assert r.step_no % G == 0  # the next region starts a fresh bucket
+
+
+def test_an_exchange_is_issued_one_launch_late_but_never_behind_a_launch_into_its_own_bucket():
+    r = _runner(8, 8, 2)
+    r.run_steps(20)  # launches of 8 / 8 / 4 steps: buckets 0, 1, 0
+    kinds = [(e[0], e[1] if e[0] == "exchange" else (e[1] * 8) // 8 % 2) for e in r.log]
+    # bucket 0's exchange comes AFTER bucket 1's launch (the second stream's kernels are not held back by its host calls) and BEFORE
+    # the third launch, which goes into bucket 0 again (it would overwrite the summaries still to be gathered); bucket 1's exchange
+    # in turn waits for that third launch to be out
+    assert kinds == [("launch", 0), ("launch", 1), ("exchange", 0), ("launch", 0), ("exchange", 1), ("exchange", 0)], kinds
+    one = _runner(4, 4, 1)  # a one-bucket ring: every exchange right behind its launch
+    one.run_steps(12)
+    assert [e[0] for e in one.log] == ["launch", "exchange"] * 3
+
+
+def test_without_a_transport_consecutive_launches_alternate_between_the_streams():
+    r = _runner(1, 1, 2, transport=False)
+    r.run_steps(6)
+    r.drain()
+    assert [e[3] for e in r.log] == ["s0", "s1", "s0", "s1", "s0", "s1"] and all(e[0] == "launch" for e in r.log)
