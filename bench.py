@@ -622,6 +622,38 @@ class NoGather:
         out.view((out.shape[0] * inp.shape[0],) + tuple(inp.shape[1:]))[: inp.shape[0]].copy_(inp)
 
 
+FULL_WIDTH_ROWS = 262144  # four wavefronts per SIMD of the row shape: the launch width of the N = 1 workload
+
+
+def launch_plan(rows_main, steps, batch_arg=0, gather_every=0, streams_arg=0, quad=False, max_batch=16):
+    """How a rank issues a region of `steps` steps of `rows_main` rows each -> (steps per launch, steps per collective (bucket), the
+    requested bucket before clamping, launch streams).  Pure host logic (tests/test_bench_runner_order.py holds it to the measured
+    choices for the driver's flags at N = 1 / 2 / 4 / 8)."""
+    # steps per launch: as many of this rank's steps as make one full-width launch (1 at N = 1 / C4; 2 / 4 / 8 for the shards of 2 /
+    # 4 / 8 GPUs), so that every GPU issues launches of the same width at every N
+    batch = batch_arg if batch_arg > 0 else max(1, min(max_batch, FULL_WIDTH_ROWS // max(rows_main, 1)))
+    if quad:
+        batch = 1
+    rows_launch = rows_main * batch
+    # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket; never more than the
+    # timed region holds (at the driver's --steps 20 at least one FULL exchange must lie inside the region), a multiple of the batch
+    G_req = gather_every if gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
+    # (a region of K steps holds at least two full buckets when it can: at the driver's --steps 20 and 8 steps per launch that is one
+    # exchange behind every launch -- two launches on two streams in flight -- instead of one bucket that serialises two launches)
+    G = max(batch, (min(G_req, max(steps // 2, 1)) // batch) * batch)
+    # ... and in a region of only a few buckets every launch is followed by its own exchange (one bucket = one launch), so that
+    # consecutive launches alternate between the streams like those of an N = 1 run: with 8-step buckets the driver's 20-step region
+    # of a 512-seed shard (4 + 4 + 2 launches of two steps) put four launches in a row on one stream and ended on two that ran alone
+    # -- 23.9 against 19.4 us per step; 45.1 against 36.8 for 1024 seeds per rank (profiles/r4_short_region_buckets.txt)
+    # (a bucket stays two launches where that is still at most 8 steps of a shard of <= 65 536 rows: 10.65 against 11.5 us per step for
+    # 256 seeds per rank)
+    if gather_every <= 0 and steps < 4 * G:
+        G = batch if (rows_main > 65536 or 2 * batch > 8) else 2 * batch
+    # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
+    n_streams = streams_arg if streams_arg > 0 else (4 if rows_launch <= 131072 else 2)
+    return batch, G, G_req, n_streams
+
+
 class Runner:
     """One workload (a batch of S seeds x W waypoints on this rank) and the machinery that steps it: a ring of output-buffer
     sets, `n_streams` launch streams, and launches of B consecutive steps each (cppf_lm_batch_*: B independent problems in one grid;
@@ -797,12 +829,13 @@ class Runner:
             torch.cuda.synchronize()
         self.run_steps(warmup)
         self.drain()
-        # Which stream a region starts on matters when the region is a handful of launches: with two buckets of 8 steps on two
-        # streams, a 20-step region of a 32 768-row shard (launches of 8 / 8 / 4 steps) takes 6.9 us per step when it starts on the
-        # first stream and 6.25 when it starts on the second, every time (profiles/r4_start_bucket.txt; the ring position used to
-        # alternate between repetitions, and the timings with it).  So, once per run and untimed: four regions from each bucket, the
-        # better one is where every timed region starts (the ring may restart anywhere: everything issued before has completed).
-        # Every rank runs the same number of calibration regions -- they contain collectives -- and decides for itself.
+        # Which stream a region starts on -- and which streams it uses -- matters when the region is a handful of launches: with two
+        # buckets of 8 steps on two streams, a 20-step region of a 32 768-row shard (launches of 8 / 8 / 4 steps) takes 6.9 us per step
+        # when it starts on the first stream and 5.8 when it starts on the second, every time within one process
+        # (profiles/r4_start_bucket.txt; the ring position used to alternate between repetitions, and the timings with it).  So, once
+        # per run and untimed: three regions per candidate, the best one is how every timed region runs (the ring may restart
+        # anywhere: everything issued before has completed).  Every rank runs the same number of calibration regions -- they contain
+        # collectives -- and decides for itself.
         def region():
             """one repetition: opening barrier, clock, exactly `steps` steps + drain, this rank's synchronize, clock, closing barrier"""
             barrier()
@@ -826,13 +859,28 @@ class Runner:
                 tc = time.perf_counter() - t1
             return t1 - t0, tc
 
-        if self.start_bucket is None and self.buckets and self.transport is not None and self.n_streams >= 2 and steps < self.NBUF * 4:
+        if self.start_bucket is None and self.buckets and self.transport is not None and self.n_streams >= 2 and steps <= 64:
+            # candidates: (streams of the buckets, start bucket).  Two buckets and eager launches: every ORDERED pair out of a pool of
+            # six streams, starting on the first -- which hardware queue a stream lands on, and what else shares it, is decided when
+            # the runtime creates it, and the same 8 / 8 / 4-step region took 5.8 ... 7.0 us per step over three processes on ONE box
+            # with the two streams this Runner happened to get (profiles/r4_start_bucket.txt).  Otherwise: the start bucket only.
+            if self.n_streams == 2 and self.graphs is None:
+                pool = list(self.streams) + [torch.cuda.Stream(device=self.streams[0].device) for _ in range(4)]
+                cands = [((i, j), 0) for i in range(len(pool)) for j in range(len(pool)) if i != j]
+            else:
+                pool = list(self.streams)
+                cands = [(tuple(range(self.n_streams)), sb) for sb in range(self.n_streams)]
             med = []
-            for sb in range(self.n_streams):
+            for idx, sb in cands:
+                self.streams = [pool[i] for i in idx]
                 self.start_bucket = sb
-                med.append(float(np.median([region()[0] for _ in range(4)])))  # (the very repetition that is timed below)
-            self.start_bucket = int(np.argmin(med))
-            self.start_bucket_calibration_us_per_step = [1e6 * m / steps for m in med]
+                med.append(float(np.median([region()[0] for _ in range(3)])))  # (the very repetition that is timed below)
+            best = int(np.argmin(med))
+            self.streams = [pool[i] for i in cands[best][0]]
+            self.start_bucket = cands[best][1]
+            self.start_bucket_calibration_us_per_step = {"candidates": len(cands), "chosen_streams": list(cands[best][0]), "chosen_start_bucket": cands[best][1],
+                                                         "best": 1e6 * med[best] / steps, "median": 1e6 * float(np.median(med)) / steps,
+                                                         "worst": 1e6 * max(med) / steps, "first": 1e6 * med[0] / steps}
         out, closing = [], []
         for _ in range(max(1, repeats)):
             dt, tc = region()
@@ -1061,29 +1109,8 @@ def main():
         return float(t.item())
 
     rows_main = S_main * W
-    FULL_WIDTH_ROWS = 262144  # four wavefronts per SIMD of the row shape: the launch width of the N = 1 workload
-    # steps per launch: as many of this rank's steps as make one full-width launch (1 at N = 1 / C4; 2 / 4 / 8 for the shards of 2 /
-    # 4 / 8 GPUs), so that every GPU issues launches of the same width at every N
-    batch = args.batch if args.batch > 0 else max(1, min(_hip.MAX_BATCH, FULL_WIDTH_ROWS // max(rows_main, 1)))
-    if shape == _hip.SHAPE_QUAD:
-        batch = 1
+    batch, G, G_req, n_streams = launch_plan(rows_main, args.steps, args.batch, args.gather_every, args.streams, shape == _hip.SHAPE_QUAD, _hip.MAX_BATCH)
     rows_launch = rows_main * batch
-    # steps per collective: the all-gather's latency (tens of microseconds across a node) is paid once per bucket; never more than the
-    # timed region holds (at the driver's --steps 20 at least one FULL exchange must lie inside the region), a multiple of the batch
-    G_req = args.gather_every if args.gather_every > 0 else (64 if rows_main <= 32768 else (32 if rows_main <= 65536 else 8))
-    # (a region of K steps holds at least two full buckets when it can: at the driver's --steps 20 and 8 steps per launch that is one
-    # exchange behind every launch -- two launches on two streams in flight -- instead of one bucket that serialises two launches)
-    G = max(batch, (min(G_req, max(args.steps // 2, 1)) // batch) * batch)
-    # ... and in a region of only a few buckets every launch is followed by its own exchange (one bucket = one launch), so that
-    # consecutive launches alternate between the streams like those of an N = 1 run: with 8-step buckets the driver's 20-step region
-    # of a 512-seed shard (4 + 4 + 2 launches of two steps) put four launches in a row on one stream and ended on two that ran alone
-    # -- 23.9 against 19.4 us per step; 45.1 against 36.8 for 1024 seeds per rank (profiles/r4_short_region_buckets.txt)
-    # (a bucket stays two launches where that is still at most 8 steps of a shard of <= 65 536 rows: 10.65 against 11.5 us per step for
-    # 256 seeds per rank)
-    if args.gather_every <= 0 and args.steps < 4 * G:
-        G = batch if (rows_main > 65536 or 2 * batch > 8) else 2 * batch
-    # launches of <= 2 wavefronts per SIMD: two in flight cannot fill the chip, four can (profiles/r2_hwq_sweep.txt)
-    n_streams = args.streams if args.streams > 0 else (4 if rows_launch <= 131072 else 2)
 
     x0, target, inputs_desc = inputs_for(S_main, scaling, args.inputs)
     use_graphs = args.graphs == "on" or (args.graphs == "auto" and rows_launch <= 65536)

@@ -78,3 +78,20 @@ def test_without_a_transport_consecutive_launches_alternate_between_the_streams(
     r.run_steps(6)
     r.drain()
     assert [e[3] for e in r.log] == ["s0", "s1", "s0", "s1", "s0", "s1"] and all(e[0] == "launch" for e in r.log)
+
+
+def test_launch_plan_for_the_driver_s_flags_and_for_long_runs():
+    """bench.launch_plan: steps per launch / per collective / streams.  With the driver's flags (--steps 20) the choices measured on the
+    one-GPU boxes (profiles/r4_short_region_buckets.txt, r4_driverflags_by_shard.txt): every rank issues full-width launches (1 / 2 /
+    4 / 8 steps of its 1024 / 512 / 256 / 128 seeds), one launch per bucket -- two for the 256-seed shard -- on two streams; over
+    2 000 steps a bucket is 8 ... 64 steps.  Explicit arguments win."""
+    W = 256
+    assert [bench.launch_plan(S * W, 20)[:2] + bench.launch_plan(S * W, 20)[3:] for S in (1024, 512, 256, 128)] == [(1, 1, 2), (2, 2, 2), (4, 8, 2), (8, 8, 2)]
+    assert [bench.launch_plan(S * W, 2000)[:2] for S in (1024, 512, 256, 128)] == [(1, 8), (2, 8), (4, 32), (8, 64)]
+    assert bench.launch_plan(128 * 64, 2000)[:2] == (16, 64) and bench.launch_plan(128 * 64, 2000)[3] == 4  # C2: 16 steps per launch, half width
+    assert bench.launch_plan(128 * W, 20, batch_arg=4, gather_every=4, streams_arg=3) == (4, 4, 4, 3)
+    assert bench.launch_plan(128 * 64, 2000, quad=True)[0] == 1  # the quad shape keeps one step per launch
+    for S in (1024, 512, 256, 128, 64, 1):  # a bucket is a whole number of launches, never longer than the region allows
+        for steps in (1, 5, 20, 64, 2000):
+            b, G, _, _ = bench.launch_plan(S * W, steps)
+            assert G % b == 0 and G >= b
