@@ -104,7 +104,12 @@ struct cppf_robot {
     // Test / tuning switches of THIS handle (cppf_debug_set, include/cppflow_hip_debug.h): no process-wide dispatch state, two
     // handles on two threads can hold different settings.  Atomics: a setter may race with a launch on another thread.
     mutable std::atomic<int> tune[CPPF_TUNE_COUNT];
+    // Lifetime (cppflow_hip.h, "Ownership"): the number of live cppf_lm_batch objects bound to this handle, and kRobotDead once
+    // cppf_robot_destroy has been called.  ONE word, so that whoever takes it to { dead, 0 batches } with its single atomic
+    // read-modify-write is the one who frees the handle -- and nobody else touches it afterwards.
+    mutable std::atomic<uint32_t> life;
 };
+constexpr uint32_t kRobotDead = 0x80000000u;
 
 namespace {
 // defaults of the switches (the measured crossovers; see include/cppflow_hip_debug.h)
@@ -312,6 +317,8 @@ struct DeviceGuard {
 
 #define CPPF_ENTER(rb)                                                                                              \
     CPPF_REQUIRE((rb) != nullptr, "robot handle is NULL");                                                          \
+    CPPF_REQUIRE(!((rb)->life.load(std::memory_order_acquire) & kRobotDead),                                         \
+                 "the robot handle was destroyed (cppf_robot_destroy; it is only kept allocated for its live batches)"); \
     DeviceGuard device_guard__((rb)->device);                                                                        \
     if (device_guard__.err != hipSuccess)                                                                            \
         return fail(CPPF_ERR_HIP, std::string("cppflow_hip: selecting the robot's device failed: ") +               \
@@ -382,6 +389,7 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     if (!rb) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
     rb->desc = *desc;
     rb->device = device;
+    rb->life.store(0u, std::memory_order_relaxed);
     for (int k = 0; k < CPPF_TUNE_COUNT; ++k) rb->tune[k].store(kTuneDefaults[k], std::memory_order_relaxed);
     std::memset(&rb->chain, 0, sizeof(ChainK));
     std::memset(&rb->coll, 0, sizeof(CollK));
@@ -455,8 +463,8 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     return CPPF_OK;
 }
 
-void cppf_robot_destroy(cppf_robot* robot) {
-    if (!robot) return;
+namespace {
+void robot_free(cppf_robot* robot) {
     {
         DeviceGuard guard(robot->device);
         if (robot->d_quad) (void)hipFree(robot->d_quad);
@@ -466,6 +474,15 @@ void cppf_robot_destroy(cppf_robot* robot) {
         }
     }
     delete robot;
+}
+}  // namespace
+
+void cppf_robot_destroy(cppf_robot* robot) {
+    if (!robot) return;
+    // Live batches keep the handle allocated (their launches then fail with CPPF_ERR_INVALID instead of reading freed memory); the
+    // last cppf_lm_batch_destroy frees it.  A second destroy of a handle that is only kept for its batches is ignored.
+    const uint32_t before = robot->life.fetch_or(kRobotDead, std::memory_order_acq_rel);
+    if (before == 0u) robot_free(robot);
 }
 
 int cppf_robot_specialize(cppf_robot* robot, const char* cache_dir) {
@@ -719,7 +736,8 @@ int launch_fused_rows(const cppf_robot* robot, int coll, size_t n_rows, unsigned
 
 // A batched fused launch (cppflow_hip.h): the item descriptors live in a device table the batch object owns.
 struct cppf_lm_batch {
-    const cppf_robot* robot;
+    const cppf_robot* robot;  // counted in robot->life from create to destroy: never dangling
+    int device;               // the robot's, copied: destroy does not need the robot for anything but the count
     LmK prm;
     void* d_table;        // { BatchHeadK ; BatchItemK[n_items] }
     int n_items, coll;
@@ -873,7 +891,7 @@ int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_bat
     for (int i = n_items; i < CPPF_MAX_BATCH; ++i) head->block_end[i] = 0xffffffffu;
     cppf_lm_batch* b = new (std::nothrow) cppf_lm_batch();
     if (!b) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
-    b->robot = robot, b->prm = prm, b->d_table = nullptr, b->n_items = n_items, b->coll = coll ? 1 : 0;
+    b->robot = robot, b->device = robot->device, b->prm = prm, b->d_table = nullptr, b->n_items = n_items, b->coll = coll ? 1 : 0;
     b->grid = (unsigned)blocks, b->n_rows = rows;
     b->after = after;
     hipError_t e = hipMalloc(&b->d_table, host.size());
@@ -883,6 +901,7 @@ int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_bat
         delete b;
         return fail(CPPF_ERR_HIP, std::string("cppflow_hip: the batch's device table: ") + hipGetErrorString(e));
     }
+    robot->life.fetch_add(1u, std::memory_order_acq_rel);  // (CPPF_ENTER saw the handle alive; the caller may not destroy it DURING this call)
     *out = b;
     return CPPF_OK;
 }
@@ -905,10 +924,13 @@ int cppf_lm_batch_launch(const cppf_lm_batch* batch, void* stream) {
 void cppf_lm_batch_destroy(cppf_lm_batch* batch) {
     if (!batch) return;
     {
-        DeviceGuard guard(batch->robot->device);
+        DeviceGuard guard(batch->device);
         if (batch->d_table) (void)hipFree(batch->d_table);
     }
+    cppf_robot* robot = const_cast<cppf_robot*>(batch->robot);
     delete batch;
+    // the last batch of a handle that was destroyed meanwhile frees it
+    if (robot->life.fetch_sub(1u, std::memory_order_acq_rel) == (kRobotDead | 1u)) robot_free(robot);
 }
 
 int cppf_collision_masks(const cppf_robot* robot, const float* q, int S, int W, uint8_t* self_mask, uint8_t* env_mask,

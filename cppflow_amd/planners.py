@@ -9,12 +9,19 @@ neither the package nor its weights exist here, so candidates come from a `seed_
 `LmIkSeedProvider` is a plain numerical stand-in built on this package's own LM kernel (random restarts at waypoint 0,
 then warm-started tracking along the path): it is NOT IKFlow, only a way to exercise the pipeline end to end; anything
 that returns a [k,T,d] tensor (an IKFlow wrapper included) can be dropped in.
+
+Seed sharding.  When torch.distributed is initialised with more than one rank (one process per GPU), `_run_pipeline`
+shards the k candidates: every rank asks its seed provider for k / world of them (the provider must return RANK-DISTINCT candidates:
+`LmIkSeedProvider` offsets its generator by the rank), evaluates -- optionally refines, `candidate_lm_steps` -- its own, and
+`cppflow_amd.distributed.sharded_candidate_evaluation` all-gathers the packed per-row outputs and the paths, so that every rank runs
+the same `dp_search` over all k candidates (cppflow/planners.py:231-274, cppflow/search.py:146-151) and returns the same plan.
 """
 
 from time import time
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
+import torch.distributed as dist
 
 from cppflow_amd.collision_detection import qpaths_batched_collisions
 from cppflow_amd.config import OPTIMIZATION_CONVERGENCE_THRESHOLD, SUCCESS_THRESHOLD_initial_q_norm_dist
@@ -48,7 +55,8 @@ class LmIkSeedProvider:
     """k candidate joint-space paths for a problem by numerical IK (stand-in for IKFlow, see module docstring)."""
 
     def __init__(self, seed: int = 0, damping: float = 1e-2, n_restart_steps: int = 40, n_track_steps: int = 6):
-        self._gen = torch.Generator().manual_seed(seed)
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0  # rank-distinct candidates under sharding
+        self._gen = torch.Generator().manual_seed(seed + 7919 * rank)
         self._damping, self._n_restart, self._n_track = damping, n_restart_steps, n_track_steps
 
     def __call__(self, problem: Problem, k: int) -> torch.Tensor:
@@ -67,10 +75,15 @@ class LmIkSeedProvider:
 
 
 class Planner:
-    def __init__(self, settings: PlannerSettings, robot, seed_provider: Optional[SeedProvider] = None):
+    def __init__(self, settings: PlannerSettings, robot, seed_provider: Optional[SeedProvider] = None, process_group=None,
+                 candidate_lm_steps: int = 0):
+        """`process_group` / `candidate_lm_steps`: the sharded candidate stage (module docstring); with `candidate_lm_steps` > 0 every
+        (candidate, waypoint) row takes that many fused pose-only LM iterations before the masks are evaluated (one launch)."""
         self._cfg = settings
         self._robot = robot
         self._seed_provider = seed_provider if seed_provider is not None else LmIkSeedProvider()
+        self._group = process_group
+        self._candidate_lm_steps = int(candidate_lm_steps)
 
     @property
     def robot(self):
@@ -87,15 +100,30 @@ class Planner:
         """Candidates -> collision masks -> dp_search (cppflow/planners.py:191-292)."""
         existing = kwargs.get("rerun_data")
         k = self._cfg.k if existing is None else DEFAULT_RERUN_NEW_K
+        world = dist.get_world_size(self._group) if dist.is_available() and dist.is_initialized() else 1
         t0 = time()
-        qs = self._seed_provider(problem, k)  # [k, T, d]
-        assert qs.dim() == 3 and qs.shape[1:] == (problem.n_timesteps, self.robot.ndof), tuple(qs.shape)
+        if world > 1:
+            from cppflow_amd.distributed import padded_shard_size, sharded_candidate_evaluation
+
+            k_local = padded_shard_size(k, problem.n_timesteps, world)  # (k is rounded up to world * k_local candidates)
+            qs = self._seed_provider(problem, k_local)  # this rank's [k_local, T, d]
+            assert qs.dim() == 3 and tuple(qs.shape) == (k_local, problem.n_timesteps, self.robot.ndof), tuple(qs.shape)
+        else:
+            qs = self._seed_provider(problem, k)  # [k, T, d]
+            assert qs.dim() == 3 and qs.shape[1:] == (problem.n_timesteps, self.robot.ndof), tuple(qs.shape)
         time_seeds = time() - t0
         if self._cfg.return_only_1st_plan:
             return qs[0], False, TimingData(-1, time_seeds, 0.0, 0.0, 0.0, 0.0), {}, (qs[0], None, None)
 
         t0 = time()
-        self_viol, env_viol = qpaths_batched_collisions(problem, qs.contiguous())
+        if world > 1:
+            qs, self_viol, env_viol = sharded_candidate_evaluation(problem, qs, self._candidate_lm_steps, self._group)
+        elif self._candidate_lm_steps > 0:
+            from cppflow_amd.distributed import sharded_candidate_evaluation
+
+            qs, self_viol, env_viol = sharded_candidate_evaluation(problem, qs, self._candidate_lm_steps, None)
+        else:
+            self_viol, env_viol = qpaths_batched_collisions(problem, qs.contiguous())
         for name, v in (("self", self_viol), ("env", env_viol)):
             pct = float(v.float().mean()) * 100
             assert pct < 95.0, f"too many {name} collisions: {pct} %"  # planners.py:237,247
@@ -117,8 +145,8 @@ class Planner:
 class PlannerSearcher(Planner):
     """dp_search over k candidate paths, no optimisation (cppflow/planners.py:301-336)."""
 
-    def __init__(self, settings: PlannerSettings, robot, seed_provider: Optional[SeedProvider] = None):
-        super().__init__(settings, robot, seed_provider)
+    def __init__(self, settings: PlannerSettings, robot, seed_provider: Optional[SeedProvider] = None, **kwargs):
+        super().__init__(settings, robot, seed_provider, **kwargs)
         assert self._cfg.run_dp_search
 
     def generate_plan(self, problem: Problem, **kwargs) -> PlannerResult:

@@ -17,6 +17,19 @@
  *   - return value 0 on success; CPPF_ERR_INVALID (contract / shape violation -> the Python shim raises AssertionError,
  *     mirroring the reference's asserts), CPPF_ERR_HIP (runtime failure -> RuntimeError), CPPF_ERR_UNSUPPORTED.
  *     cppf_last_error() returns a thread-local message for the last failure.
+ *
+ * Ownership and lifetimes (the caller owns all tensors)
+ *   - caller buffers: never allocated, freed or retained by the library beyond the launches that were handed them -- except by a
+ *     cppf_lm_batch, which records its items' pointers: they must stay valid while the batch is launched.
+ *   - cppf_robot: created / destroyed by the caller.  A cppf_lm_batch is bound to the robot it was created from and keeps that
+ *     handle ALLOCATED: cppf_robot_destroy on a robot with live batches marks it destroyed and returns; from then on every entry
+ *     point given the handle or one of its batches (cppf_lm_batch_launch included) returns CPPF_ERR_INVALID without launching
+ *     anything, and the memory is released by the cppf_lm_batch_destroy of its last batch.  So "robot first, then its batches" is
+ *     a legal order of destruction; using a robot handle after cppf_robot_destroy when it has NO live batch is a use after free,
+ *     as for any C handle.  cppf_lm_batch_destroy needs nothing but the batch.
+ *   - cppf_comm: independent of robots and batches.
+ *   - one host thread per handle at a time; handles on different threads are independent (no process-wide mutable state besides
+ *     the RCCL function table).
  */
 #ifndef CPPFLOW_HIP_H
 #define CPPFLOW_HIP_H
@@ -38,7 +51,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define CPPF_ABI_VERSION 5
+#define CPPF_ABI_VERSION 6
 
 #define CPPF_MAX_DOF 12 /* every ndof in 3..12 is built (the reference's robots have 7 and 8) */
 #define CPPF_MAX_CAPSULES 24
@@ -223,8 +236,8 @@ typedef struct cppf_lm_batch_item {
 typedef struct cppf_lm_batch cppf_lm_batch; /* opaque: device table of the items + the marshalled parameters */
 int cppf_lm_batch_create(const cppf_robot* robot, int n_items, const cppf_lm_batch_item* items /* HOST */,
                          const cppf_lm_params* params, cppf_lm_batch** out);
-int cppf_lm_batch_launch(const cppf_lm_batch* batch, void* stream);
-void cppf_lm_batch_destroy(cppf_lm_batch* batch);
+int cppf_lm_batch_launch(const cppf_lm_batch* batch, void* stream); /* CPPF_ERR_INVALID once its robot has been destroyed */
+void cppf_lm_batch_destroy(cppf_lm_batch* batch);                   /* also releases a robot that was destroyed before it (see "Ownership") */
 
 /* qpaths_batched_self_collisions / qpaths_batched_env_collisions (cppflow/collision_detection.py:27-69) +
  * joint_limit_almost_violations_3d + q_costs_external (cppflow/search.py:25-52, 146-150) for q [S,W,d]. Outputs [S*W]. */

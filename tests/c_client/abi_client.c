@@ -178,7 +178,37 @@ int main(int argc, char** argv) {
         printf("allgather ok on %d rank(s)\n", R);
     }
 
-    cppf_robot_destroy(robot);
+    /* ---- lifetimes (cppflow_hip.h, "Ownership"): a batch keeps its robot allocated.  Destroying the robot FIRST is allowed: the
+     * batch's launches then fail with CPPF_ERR_INVALID (no launch, no fault), and destroying the batch releases both. ---- */
+    {
+        cppf_lm_batch_item item;
+        memset(&item, 0, sizeof item);
+        item.x_in = x_in, item.target = target, item.S = S, item.W = W;
+        item.out.x_out = x_out, item.out.pos_err_m = pe, item.out.rot_err_rad = re;
+        prm.n_steps = K;
+        cppf_lm_batch* batch = NULL;
+        CPPF_OK_OR_DIE(cppf_lm_batch_create(robot, 1, &item, &prm, &batch));
+        CPPF_OK_OR_DIE(cppf_lm_batch_launch(batch, stream)); /* alive: a normal launch, same results as above */
+        HIP_OK(hipStreamSynchronize(stream));
+        float* h_chk = (float*)malloc(sizeof(float) * n * d);
+        HIP_OK(hipMemcpy(h_chk, x_out, sizeof(float) * n * d, hipMemcpyDeviceToHost));
+        if (memcmp(h_chk, h_out, sizeof(float) * n * d) != 0) {
+            fprintf(stderr, "batched launch differs from cppf_lm_pose_steps\n");
+            return 7;
+        }
+        free(h_chk);
+        cppf_robot_destroy(robot); /* robot first ... */
+        if (cppf_lm_batch_launch(batch, stream) != CPPF_ERR_INVALID || strlen(cppf_last_error()) == 0) {
+            fprintf(stderr, "a launch on a destroyed robot was not rejected\n");
+            return 8;
+        }
+        if (cppf_forward_kinematics(robot, x_out, (int)n, fk, stream) != CPPF_ERR_INVALID) { /* (still allocated: the batch holds it) */
+            fprintf(stderr, "an entry point on a destroyed robot was not rejected\n");
+            return 8;
+        }
+        cppf_lm_batch_destroy(batch); /* ... then the batch: releases the handle */
+        printf("lifetime ok\n");
+    }
     hipFree(x_in), hipFree(x_out), hipFree(target), hipFree(cost), hipFree(pe), hipFree(re), hipFree(summary), hipFree(fk);
     hipFree(m_self), hipFree(m_env), hipFree(m_jl);
     hipStreamDestroy(stream);

@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(names) == set(_hip.SIGNATURES), set(names) ^ set(_hip.SIGNATURES)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.cppf_abi_version() == 5
+    assert lib.cppf_abi_version() == 6
 
 
 def test_debug_header_holds_every_hook_and_nothing_of_the_boundary():

@@ -47,6 +47,7 @@ def test_c_client_matches_python_mirror(tmp_path, name, S, W):
     run = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=120, env=env)
     assert run.returncode == 0, run.stderr + run.stdout
     assert "allgather ok on 1 rank(s)" in run.stdout, run.stdout  # RCCL through the C ABI (cppf_comm_init_all / cppf_allgather_bytes)
+    assert "lifetime ok" in run.stdout, run.stdout  # robot destroyed before its batch: launch refused, no fault (cppflow_hip.h "Ownership")
     n, d = S * W, rb.ndof
     raw = np.fromfile(fout, dtype=np.uint8)
     off = 0

@@ -1,10 +1,12 @@
-"""bench.Runner.run_steps / drain without a GPU: the ORDER in which a rank issues its launches and exchange steps -- what the N > 1
-line of bench.py rests on and what no one-GPU box can show on RCCL.  The Runner is built around stand-ins (no robot, no streams):
-launches and exchanges only record themselves."""
+"""cppflow_amd.distributed.ShardedRefiner.run_steps / drain without a GPU: the ORDER in which a rank issues its launches and
+exchange steps -- what the N > 1 path rests on and what no one-GPU box can show on RCCL.  The refiner is built around stand-ins (no
+robot, no streams): launches and exchanges only record themselves."""
+
+import contextlib
 
 import pytest
 
-import bench
+from cppflow_amd import distributed as D
 
 
 class _Launch:
@@ -16,13 +18,15 @@ class _Launch:
 
 
 def _runner(B, G, n_streams, transport=True):
-    r = object.__new__(bench.Runner)
+    r = object.__new__(D.ShardedRefiner)
     r.B, r.G, r.n_streams = B, G, n_streams
     r.buckets = transport
     r.transport = object() if transport else None
     r.NBUF = n_streams * G if transport else max(4, n_streams) * B
     r.graphs = None
     r.step_no = 0
+    r.start_bucket = None
+    r._on = lambda stream: contextlib.nullcontext()
     r.streams = [f"s{i}" for i in range(n_streams)]
     r.log = []
     r.launches = [[_Launch(r.log, g, c + 1) for c in range(B)] for g in range(r.NBUF // B)]
@@ -81,17 +85,17 @@ def test_without_a_transport_consecutive_launches_alternate_between_the_streams(
 
 
 def test_launch_plan_for_the_driver_s_flags_and_for_long_runs():
-    """bench.launch_plan: steps per launch / per collective / streams.  With the driver's flags (--steps 20) the choices measured on the
+    """D.launch_plan: steps per launch / per collective / streams.  With the driver's flags (--steps 20) the choices measured on the
     one-GPU boxes (profiles/r4_short_region_buckets.txt, r4_driverflags_by_shard.txt): every rank issues full-width launches (1 / 2 /
     4 / 8 steps of its 1024 / 512 / 256 / 128 seeds), one launch per bucket -- two for the 256-seed shard -- on two streams; over
     2 000 steps a bucket is 8 ... 64 steps.  Explicit arguments win."""
     W = 256
-    assert [bench.launch_plan(S * W, 20)[:2] + bench.launch_plan(S * W, 20)[3:] for S in (1024, 512, 256, 128)] == [(1, 1, 2), (2, 2, 2), (4, 8, 2), (8, 8, 2)]
-    assert [bench.launch_plan(S * W, 2000)[:2] for S in (1024, 512, 256, 128)] == [(1, 8), (2, 8), (4, 32), (8, 64)]
-    assert bench.launch_plan(128 * 64, 2000)[:2] == (16, 64) and bench.launch_plan(128 * 64, 2000)[3] == 4  # C2: 16 steps per launch, half width
-    assert bench.launch_plan(128 * W, 20, batch_arg=4, gather_every=4, streams_arg=3) == (4, 4, 4, 3)
-    assert bench.launch_plan(128 * 64, 2000, quad=True)[0] == 1  # the quad shape keeps one step per launch
+    assert [D.launch_plan(S * W, 20)[:2] + D.launch_plan(S * W, 20)[3:] for S in (1024, 512, 256, 128)] == [(1, 1, 2), (2, 2, 2), (4, 8, 2), (8, 8, 2)]
+    assert [D.launch_plan(S * W, 2000)[:2] for S in (1024, 512, 256, 128)] == [(1, 8), (2, 8), (4, 32), (8, 64)]
+    assert D.launch_plan(128 * 64, 2000)[:2] == (16, 64) and D.launch_plan(128 * 64, 2000)[3] == 4  # C2: 16 steps per launch, half width
+    assert D.launch_plan(128 * W, 20, batch=4, gather_every=4, streams=3) == (4, 4, 4, 3)
+    assert D.launch_plan(128 * 64, 2000, quad=True)[0] == 1  # the quad shape keeps one step per launch
     for S in (1024, 512, 256, 128, 64, 1):  # a bucket is a whole number of launches, never longer than the region allows
         for steps in (1, 5, 20, 64, 2000):
-            b, G, _, _ = bench.launch_plan(S * W, steps)
+            b, G, _, _ = D.launch_plan(S * W, steps)
             assert G % b == 0 and G >= b
