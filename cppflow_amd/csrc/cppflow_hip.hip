@@ -97,6 +97,7 @@ struct cppf_robot {
     ChainK chain;
     CollK coll;
     int device;
+    int cu_count;      // compute units of `device` (0 for the host-only handle): what a resident launch's grid is held against
     int static_id;     // index into robots_gen.h when the description equals a generated table, else -1
     size_t lds_bytes;  // generic path only: capsule end points, 6 floats per capsule per lane
     void* d_quad;      // device: QuadPairRec[CPPF_MAX_PAIRS] then QuadCapRec[CPPF_MAX_CAPSULES] (quad shape's striped collision stage)
@@ -116,7 +117,7 @@ namespace {
 constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
     /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
     /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
-    /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,    /* GATE_REL_PPM */ (int)(kGateRel * 1e6f + 0.5f),
+    /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,    /* GATE_REL_PPM */ (int)(kGateRel * 1e6f + 0.5f), /* CU_COUNT */ -1,
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
 
@@ -389,6 +390,8 @@ int cppf_robot_create(const cppf_robot_desc* desc, int device, cppf_robot** out)
     if (!rb) return fail(CPPF_ERR_HIP, "cppflow_hip: out of host memory");
     rb->desc = *desc;
     rb->device = device;
+    rb->cu_count = 0;
+    if (device != kNoDevice) (void)hipDeviceGetAttribute(&rb->cu_count, hipDeviceAttributeMultiprocessorCount, device);
     rb->life.store(0u, std::memory_order_relaxed);
     for (int k = 0; k < CPPF_TUNE_COUNT; ++k) rb->tune[k].store(kTuneDefaults[k], std::memory_order_relaxed);
     std::memset(&rb->chain, 0, sizeof(ChainK));
@@ -1313,8 +1316,26 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     hipStream_t st = (hipStream_t)stream;
     const int d = robot->desc.ndof;
     const size_t total = (size_t)k * T * d;
-    const bool persistent = T >= 2 && k <= kDpResidentMaxK &&
-                            (mode == CPPF_DP_RESIDENT || (mode == CPPF_DP_AUTO && tune(robot, CPPF_TUNE_DP_PERSISTENT)));
+    bool persistent = T >= 2 && k <= kDpResidentMaxK &&
+                      (mode == CPPF_DP_RESIDENT || (mode == CPPF_DP_AUTO && tune(robot, CPPF_TUNE_DP_PERSISTENT)));
+    DpResidentForm form{nullptr, 0, 0};
+    if (persistent) {
+        // The resident form is only CORRECT while all its workgroups are on the device together (they wait for each other's cost words).
+        // Hold the grid against what this device can hold of this kernel -- occupancy x compute units -- instead of finding out by
+        // spinning 2^22 reads: a partitioned / CU-masked / smaller device takes the per-waypoint launches straight away (AUTO), and a
+        // forced CPPF_DP_RESIDENT is refused.  (Other work on the device -- a second resident search on another stream, a full-width
+        // fused launch -- can still delay workgroups; the bounded waits stay as the safety net for that.)
+        CPPF_DISPATCH_D(d, form = dp_resident_form<D>(k, tune(robot, CPPF_TUNE_DP_PERSISTENT)));
+        int per_cu = 0;
+        CPPF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, form.fn, form.block, 0));
+        const int cus = tune(robot, CPPF_TUNE_CU_COUNT) >= 0 ? tune(robot, CPPF_TUNE_CU_COUNT) : robot->cu_count;  // (the test hook: a smaller device)
+        if ((unsigned long long)per_cu * (unsigned long long)cus < form.grid) {
+            if (mode == CPPF_DP_RESIDENT)
+                return fail(CPPF_ERR_UNSUPPORTED, "cppflow_hip: CPPF_DP_RESIDENT: this device cannot hold the resident launch's workgroups "
+                                                  "together (occupancy x compute units < grid): use CPPF_DP_AUTO or CPPF_DP_LAUNCHES");
+            persistent = false;
+        }
+    }
     if (persistent)  // every cost word starts as "not yet" (kernels_dp.h); 16-byte multiple, from the allocation's start
         CPPF_HIP(hipMemsetAsync(work_costsT, 0xFF, sizeof(float) * (size_t)k * T, st));
     hipLaunchKernelGGL(dp_transpose_kernel, dim3(grid_for(total > (size_t)k ? total : (size_t)k)), dim3(256), 0, st, q,
@@ -1323,26 +1344,12 @@ int cppf_dp_search(const cppf_robot* robot, const float* q, const float* ext_cos
     CPPF_HIP(hipMemsetAsync(work_memoT, 0, sizeof(int32_t) * (size_t)k, st));
     if (persistent) {
         const int spin_log2 = tune(robot, CPPF_TUNE_DP_SPIN_LOG2);
-        const uint32_t spin = spin_log2 <= 0 ? 0u : (1u << (spin_log2 > 30 ? 30 : spin_log2));
-        if (k <= 64) {
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent_kernel<D>), dim3((unsigned)k), dim3(64), 0, st, work_qT, ext_cost,
-                                                 k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT, spin));
-        } else if (k <= 256) {
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D, 256>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
-                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
-                                                 work_memoT, spin));
-        } else if (k <= 512 && tune(robot, CPPF_TUNE_DP_PERSISTENT) != 2) {  // the same form on 1 024 lanes, <= 128 workgroups
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_persistent4_kernel<D, 512>), dim3((unsigned)((k + 3) / 4)), dim3(1024), 0, st,
-                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
-                                                 work_memoT, spin));
-        } else if (k <= 512) {  // (CPPF_TUNE_DP_PERSISTENT = 2: the A/B) one source per lane and four destinations, <= 128 workgroups
-            CPPF_DISPATCH_D(d, hipLaunchKernelGGL((dp_resident_kernel<D, 1>), dim3((unsigned)((k + 3) / 4)), dim3(512), 0, st,
-                                                 work_qT, ext_cost, k, T, robot->chain.pris_mask, prismatic_scaling, work_costsT,
-                                                 work_memoT, spin));
-        } else {  // two sources per lane, <= 256 workgroups: one per compute unit
-            CPPF_DISPATCH_D(d, dp_launch_two_sources<D>(tune(robot, CPPF_TUNE_DP_PERSISTENT) != 2, st, work_qT, ext_cost, k, T,
-                                                        robot->chain.pris_mask, prismatic_scaling, work_costsT, work_memoT, spin));
-        }
+        uint32_t spin = spin_log2 <= 0 ? 0u : (1u << (spin_log2 > 30 ? 30 : spin_log2));
+        uint32_t pris_mask = robot->chain.pris_mask;
+        // (the six resident kernels share one argument list)
+        void* args[] = {(void*)&work_qT, (void*)&ext_cost, (void*)&k, (void*)&T, (void*)&pris_mask, (void*)&prismatic_scaling,
+                        (void*)&work_costsT, (void*)&work_memoT, (void*)&spin};
+        CPPF_HIP(hipLaunchKernel(form.fn, dim3(form.grid), dim3((unsigned)form.block), args, 0, st));
         hipLaunchKernelGGL(dp_backtrace_kernel, dim3(1), dim3(256), dp_stage_bytes(k, T), st, q, work_costsT, work_memoT, k, T, d,
                        dp_stage_bytes(k, T) != 0, best_idx,
                            best_path);

@@ -414,17 +414,25 @@ __global__ __launch_bounds__(512) void dp_resident_kernel(const float* __restric
 // 513 ... 1024 candidates in one resident launch: the 1 024-lane form of dp_persistent4_kernel with two sources per lane where its
 // registers allow four wavefronts per SIMD (up to 9 joints: 128 VGPRs without scratch), dp_resident_kernel (512 lanes, four
 // destinations x two sources per lane) beyond -- and as the A/B (`wide` = false: CPPF_TUNE_DP_PERSISTENT = 2)
+struct DpResidentForm {
+    const void* fn;  // the kernel (all forms share one argument list: qT, ext, k, T, pris_mask, pscale, costsT, memoT, spin)
+    int block;
+    unsigned grid;
+};
 template <int D>
-inline void dp_launch_two_sources(bool wide, hipStream_t st, const float* qT, const float* ext, int k, int T, uint32_t pris_mask,
-                                  float pscale, float* costsT, int32_t* memoT, uint32_t spin) {
-    const dim3 grid((unsigned)((k + 3) / 4));
-    if constexpr (D <= 9) {
-        if (wide) {
-            hipLaunchKernelGGL((dp_persistent4_kernel<D, 512, 2>), grid, dim3(1024), 0, st, qT, ext, k, T, pris_mask, pscale, costsT, memoT, spin);
-            return;
-        }
+inline DpResidentForm dp_resident_form(int k, int tune_persistent) {
+    const unsigned g4 = (unsigned)((k + 3) / 4);
+    if (k <= 64) return {(const void*)dp_persistent_kernel<D>, 64, (unsigned)k};  // one destination per wavefront
+    if (k <= 256) return {(const void*)dp_persistent4_kernel<D, 256>, 512, g4};
+    if (k <= 512) {  // the same form on 1 024 lanes, <= 128 workgroups (tune 2, the A/B: one source per lane and four destinations)
+        if (tune_persistent != 2) return {(const void*)dp_persistent4_kernel<D, 512>, 1024, g4};
+        return {(const void*)dp_resident_kernel<D, 1>, 512, g4};
     }
-    hipLaunchKernelGGL((dp_resident_kernel<D, 2>), grid, dim3(512), 0, st, qT, ext, k, T, pris_mask, pscale, costsT, memoT, spin);
+    // two sources per lane, <= 256 workgroups: one per compute unit
+    if constexpr (D <= 9) {
+        if (tune_persistent != 2) return {(const void*)dp_persistent4_kernel<D, 512, 2>, 1024, g4};
+    }
+    return {(const void*)dp_resident_kernel<D, 2>, 512, g4};
 }
 
 // ---- the recurrence on ONE compute unit, from a precomputed transition table (k <= 256) -------------------------------------------

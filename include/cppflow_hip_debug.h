@@ -57,7 +57,11 @@ extern "C" {
  * early-out iterations and a K = 1 launch keep the absolute gate alone).  Default 1000 (kGateRel, csrc/kernels_chain.h); 0 = the
  * absolute gate in every iteration. */
 #define CPPF_TUNE_GATE_REL_PPM 10
-#define CPPF_TUNE_COUNT 11
+/* >= 0: the number of compute units cppf_dp_search holds its resident launch's grid against (occupancy x compute units >= grid, else
+ * one launch per waypoint in CPPF_DP_AUTO and CPPF_ERR_UNSUPPORTED for a forced CPPF_DP_RESIDENT) instead of the device's own: how
+ * the tests reach that decision on a full MI355X.  Default -1 = the device's. */
+#define CPPF_TUNE_CU_COUNT 11
+#define CPPF_TUNE_COUNT 12
 
 int cppf_debug_set(cppf_robot* robot, int key, int value);
 int cppf_debug_get(const cppf_robot* robot, int key, int* value);

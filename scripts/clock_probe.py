@@ -49,7 +49,9 @@ def main():
     robot.set_joint_limit_padding(DEFAULT_JLIM_SAFETY_PADDING_REVOLUTE, DEFAULT_JLIM_SAFETY_PADDING_PRISMATIC)
     x0, target, _ = bench.make_inputs_problem(robot, S, W, device, seed=0)
     solver = {"auto": _hip.SOLVER_AUTO, "f32": _hip.SOLVER_F32, "f64": _hip.SOLVER_F64}[args.solver]
-    run = bench.Runner(robot, x0, target, K, True, args.streams, 1, None, 1, _hip.SHAPE_AUTO, device, solver)
+    from cppflow_amd.distributed import ShardedRefiner
+
+    run = ShardedRefiner(robot, x0, target, K, n_streams=args.streams, solver=solver)
     probe_stream = torch.cuda.Stream(device=device)
     n_samples, sleeps = 400, 8  # 8 x s_sleep(127) ~ 8 x 8 128 cycles ~ 27 us per sample at 2.4 GHz: ~11 ms per probe launch
 

@@ -4,7 +4,9 @@
 set -eo pipefail
 ROOT="$(pwd)"; OUT="$ROOT/gpurun_out/r5"; mkdir -p "$OUT"; export TMPDIR=/tmp
 echo "== new tests"
-timeout -k 10 900 python -m pytest tests/test_gpu_sharded_refiner.py tests/test_gpu_c_client.py tests/test_gpu_bench_line.py -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/call1_pytest.txt"
+timeout -k 10 900 python -m pytest tests/test_gpu_sharded_refiner.py tests/test_gpu_round5.py tests/test_gpu_c_client.py tests/test_gpu_bench_line.py -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/call1_pytest.txt"
+echo "== lean-iteration parity test (all cases, no -x)"
+timeout -k 10 900 python -m pytest tests/test_gpu_lean_parity.py -m gpu -q -s 2>&1 | tail -60 | tee "$OUT/call1_lean_pytest.txt" || true
 echo "== lean-iteration parity statistics"
 timeout -k 10 600 python scripts/lean_parity_stats.py > "$OUT/lean_parity.txt" 2> "$OUT/lean_parity.err" || { tail -20 "$OUT/lean_parity.err"; exit 1; }
 tail -30 "$OUT/lean_parity.txt"

@@ -47,6 +47,24 @@ def lm_problem(name, S, W, seed=0, noise=0.1):
     return f32(x0), target
 
 
+def collision_free_problem(name, S, W, seed=0, noise=0.005, obstacles=None, bad_seeds=(), bad_noise=0.6):
+    """Like `lm_problem`, but the waypoints' q* are drawn collision-free (self and against `obstacles`) and the seeds sit close to
+    them, so that after a few LM steps most seeds are VALID (x_is_valid's seed selection has something to select); the seeds in
+    `bad_seeds` get `bad_noise` instead and are still far from the target then."""
+    ch = chain(name)
+    rng = np.random.RandomState(seed)
+    cand = f32(rng.uniform(ch.lo + 0.1, ch.hi - 0.1, size=(8 * W, ch.ndof)))
+    lo, hi = box_corners([c for c, _ in obstacles], [T for _, T in obstacles]) if obstacles else (None, None)
+    m = oracle32(name).masks(cand, lo, hi, ch.lo, ch.hi)
+    keep = cand[(m["self_mask"] == 0) & (m["env_mask"] == 0)][:W]
+    assert len(keep) == W
+    target = f32(oracle64(name).fk(keep))
+    sigma = np.full((S, 1, 1), noise)
+    sigma[list(bad_seeds)] = bad_noise
+    x0 = np.clip(keep[None] + sigma * rng.randn(S, W, ch.ndof), ch.lo, ch.hi).reshape(S * W, ch.ndof)
+    return f32(x0), target
+
+
 def stacked(target, S):
     return np.tile(target, (S, 1))
 
