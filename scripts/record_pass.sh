@@ -12,7 +12,7 @@
 set -eo pipefail
 ROOT="$(pwd)"
 OUT="$ROOT/gpurun_out/rec"
-ROUND="${CPPF_ROUND:-r4}"
+ROUND="${CPPF_ROUND:-r5}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 MODE="${1:-full}"
@@ -39,7 +39,12 @@ if want full quick pmc; then
     python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p3/pmc_counter_collection.csv" 18
     timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAIT_ANY --output-format csv -d "$OUT/pmc_p4" -o pmc -- python3 "$ROOT/scripts/pmc_probe.py" panda > /dev/null 2> "$OUT/pmc_p4_stderr.txt"
     python3 "$ROOT/scripts/trim_pmc.py" "$OUT/pmc_p4/pmc_counter_collection.csv" 18
+    echo "== rocprofv3 kernel trace of the DRIVER's command (two streams): the overlap behind ms_per_step < kernel time"
+    timeout -k 10 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/overlap" -o kt -- python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-siblings > "$OUT/overlap_stdout.txt" 2> "$OUT/overlap_stderr.txt"
     cd "$ROOT"
+    mkdir -p "$OUT/profiles"
+    python3 scripts/overlap_summary.py "$OUT/overlap" "$OUT/overlap_stdout.txt" "$OUT/profiles/${ROUND}_overlap.json" 20 | tail -22
+    rm -rf "$OUT/overlap"
     echo "== counters -> profiles/${ROUND}_* (this box's tree: the bench records below read them) and gpurun_out/rec/profiles/"
     mkdir -p "$OUT/profiles"
     python3 scripts/summarize_profiles.py "$OUT" "$OUT/profiles" "$ROUND" counters > "$OUT/summarize.txt" 2>&1 || { tail -20 "$OUT/summarize.txt"; exit 1; }
@@ -53,12 +58,12 @@ if want full quick bench; then
     cat "$OUT/bench.json"
     echo "== bench with the DRIVER's flags (--steps 20 --warmup 5)"
     timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driverflags.json" 2>> "$OUT/bench.err"
-    python3 -c "import json; d=json.load(open('$OUT/bench_driverflags.json')); print('driver flags: us/step %.2f  value %.3e  frac %s' % (d['ms_per_step']*1e3, d['value'], d['roofline']['frac']))"
+    python3 -c "import json; d=json.load(open('$OUT/bench_driverflags.json')); r=d['roofline']; print('driver flags: us/step %.2f  value %.3e  frac %s  kernel %.1f us  overlapped %s  cpu agreement %s' % (d['ms_per_step']*1e3, d['value'], r['frac'], r['kernel_ms']*1e3, r['kernel_ms_overlapped'], d['cpu_baseline']['agreement']['max_abs_pos_err_diff_m']))"
     echo "== one rank's N = 8 shard (128 seeds) with the one-rank RCCL exchange on: driver flags, then 2000 steps"
-    CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --seeds 128 --steps 20 --warmup 5 --no-cpu-baseline --no-siblings > "$OUT/bench_shard128_driverflags.json" 2>> "$OUT/bench.err"
+    CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --seeds 128 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_shard128_driverflags.json" 2>> "$OUT/bench.err"
     CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --seeds 128 --steps 2000 --warmup 100 --no-cpu-baseline --no-siblings > "$OUT/bench_shard128_2000steps.json" 2>> "$OUT/bench.err"
     for f in bench_shard128_driverflags bench_shard128_2000steps; do
-        python3 -c "import json; d=json.load(open('$OUT/$f.json')); c=d['config']; print('$f: us/step %.2f  steps/launch %s  steps/allgather %s  streams %s  frac %s' % (d['ms_per_step']*1e3, c['steps_per_launch'], c['steps_per_allgather'], c['streams'], d['roofline']['frac']))"
+        python3 -c "import json; d=json.load(open('$OUT/$f.json')); c=d['config']; print('$f: us/step %.2f (calibrated streams: %s)  steps/launch %s  steps/allgather %s  streams %s  frac %s  allgather %.1f us' % (d['ms_per_step']*1e3, d.get('ms_per_step_calibrated_streams'), c['steps_per_launch'], c['steps_per_allgather'], c['streams'], d['roofline']['frac'], d['rccl']['allgather_latency_us']))"
     done
     echo "== bench, one-rank RCCL group at full size (collective + seed selection on the dependency path)"
     CPPF_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-siblings > "$OUT/bench_dist1.json" 2>> "$OUT/bench.err"
