@@ -491,7 +491,7 @@ def main():
     # Once per planning call (not per step): ShardedRefiner.gather_and_search -- every rank gets ALL ranks' per-row costs / masks and
     # candidate paths and runs dp_search over them (cppflow/search.py:146-173).  Untimed here, reported beside the headline.
     plan_search = None
-    if collide and not share_gpu:
+    if collide:
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):

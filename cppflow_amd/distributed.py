@@ -40,6 +40,18 @@ LM_POSE = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)  # ALT_L
 
 
 # ---- payloads -------------------------------------------------------------------------------------------------------------------
+def _all_gather_flat(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """`dist.all_gather_into_tensor(out, inp)` -- `out` the concatenation of every rank's `inp` along dim 0 -- staged through the
+    host when the group's backend cannot take device tensors (gloo with HIP tensors: several ranks SHARING one GPU, which RCCL
+    refuses; a rehearsal of the N > 1 path on the hardware there is, exact for semantics and meaningless for timing)."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+        out.copy_(h_out)
+        return None
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+
+
 def allgather_seed_summaries(summary: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
                              out: Optional[torch.Tensor] = None, async_op: bool = False):
     """All-gather the [S_local, 8] per-seed summaries (`Robot.seed_summary`) -> [world * S_local, 8]: 32 bytes per seed,
@@ -51,7 +63,7 @@ def allgather_seed_summaries(summary: torch.Tensor, group: Optional[dist.Process
         return (summary, None) if async_op else summary
     if out is None:
         out = torch.empty((world * summary.shape[0], summary.shape[1]), dtype=summary.dtype, device=summary.device)
-    work = dist.all_gather_into_tensor(out, summary.contiguous(), group=group, async_op=async_op)
+    work = _all_gather_flat(out, summary.contiguous(), group, async_op)
     return (out, work) if async_op else out
 
 
@@ -122,7 +134,7 @@ def allgather_seed_outputs(
     else:
         if out is None:
             out = torch.empty(world * packed.numel(), dtype=torch.uint8, device=packed.device)
-        dist.all_gather_into_tensor(out, packed, group=group)
+        _all_gather_flat(out, packed, group)
         gathered = out.view(world, -1)
     parts = [unpack_rows(gathered[r], n) for r in range(world)]
 
@@ -601,7 +613,7 @@ class ShardedRefiner:
         if self.world > 1 and dist.is_initialized():
             g = allgather_seed_outputs(self.packeds[slot], self.S, self.W, group=self.group)
             q_all = torch.empty((self.world * self.n, d), dtype=torch.float32, device=self.device)  # (the concatenated form: gloo insists on it)
-            dist.all_gather_into_tensor(q_all, self.x_outs[slot], group=self.group)
+            _all_gather_flat(q_all, self.x_outs[slot], self.group)
             return q_all.view(self.world * self.S, self.W, d), g
         cost, pe, re, sm, em, jm = (t.view(self.S, self.W) for t in unpack_rows(self.packeds[slot], self.n))
         g = GatheredSeedOutputs(cost, pe, re, sm.view(torch.bool), em.view(torch.bool), jm.view(torch.bool))
@@ -652,7 +664,7 @@ def sharded_candidate_evaluation(problem, qs_local: torch.Tensor, lm_steps: int 
     g = allgather_seed_outputs(packed, k_local, T, group=group, counts=counts)
     if world > 1:
         q_all = torch.empty((world * n, d), dtype=torch.float32, device=x.device)
-        dist.all_gather_into_tensor(q_all, x.contiguous(), group=group)
+        _all_gather_flat(q_all, x.contiguous(), group)
         q_all = drop_padding(q_all.view(world * k_local, T, d), k_local, counts if counts is not None else [k_local] * world)
     else:
         q_all = x.view(k_local, T, d)
