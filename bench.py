@@ -12,17 +12,14 @@ environment collision masks, joint-limit mask and search cost of the result, and
 N > 1 the summaries of a bucket of steps are all-gathered over RCCL in-stream and CONSUMED: every rank runs x_is_valid's seed
 selection over all ranks' seeds for every step.  value = rows * K * steps / wall-time over all ranks.
 
-THROUGHPUT OVER INDEPENDENT REQUESTS: consecutive steps are independent batches, and under strong scaling a launch carries B steps
-of this rank's shard (B = 262 144 / rows: 2 / 4 / 8 at N = 2 / 4 / 8) = B independent requests in one full-width grid.  The latency of
-ONE request's shard (`latency_one_request`, --batch 1 on one stream) is reported beside it: ~26 us for a 32 768-row shard against
-49 us unsharded -- a single planning call does not get 8x faster on 8 GPUs, a server's request stream does.
+THROUGHPUT OVER INDEPENDENT REQUESTS: under strong scaling a launch carries B steps of this rank's shard (B = 262 144 / rows: 2 / 4 / 8
+at N = 2 / 4 / 8) = B independent requests in one full-width grid.  ONE request's shard (`latency_one_request`: --batch 1, one stream)
+takes ~25 us for 32 768 rows against 49 us unsharded: a single planning call does not get 8x faster on 8 GPUs, a request stream does.
 
-Launching.  `python bench.py --gpus N` with WORLD_SIZE unset starts N fresh rank processes itself -- BEFORE this process touches the
-GPU -- relays rank 0's single JSON line and exits with the children's status; under torch.distributed.run it is one rank.
-
-Scaling.  N = 1: BASELINE.json configs[3] on one GPU (Panda, 1024 seeds x 256 waypoints, the two cuboids of panda__2cubes).  N > 1
-defaults to STRONG scaling ("1024 seeds x 256 waypoints, seed-sharded across 2/4/8 MI355X"); the weak figure (1024 seeds per GPU)
-is the sibling key `weak_scaling`.
+Launching.  `python bench.py --gpus N` with WORLD_SIZE unset starts N fresh rank processes itself (BEFORE this process touches the GPU),
+relays rank 0's single JSON line and exits with the children's status; under torch.distributed.run it is one rank.
+Scaling.  N = 1: BASELINE.json configs[3] on one GPU (Panda, 1024 seeds x 256 waypoints, the two cuboids of panda__2cubes).  N > 1:
+STRONG scaling by default (the same 1024 seeds sharded); the weak figure (1024 seeds per GPU) is the sibling key `weak_scaling`.
 
 Timing.  `--prewarm-ms` of untimed launches, W untimed warm-up steps, then exactly K steps: barrier + synchronize, clock, the K
 steps (+ the exchange of a partly filled bucket), this rank's synchronize, clock; maximum over ranks.  The group's CLOSING barrier
@@ -72,23 +69,18 @@ def algorithmic_flops_per_row_iter(d: int) -> float:
     return 130.0 * (d + 1) + 12 * d + 100 + 6 * (d + 1) + 12 * d * (d + 1) / 2 + 12 * d + d**3 / 3 + 2 * d * d + 3 * d
 
 
-def algorithmic_flops_collision(L: int, P: int, O: int) -> float:
-    """capsule end points 36 L + pairs 90 P_s + capsule-cuboid 150 L O."""
+def algorithmic_flops_collision(L: int, P: int, O: int) -> float:  # capsule end points 36 L + pairs 90 P_s + capsule-cuboid 150 L O
     return 36.0 * L + 90.0 * P + 150.0 * L * O
 
 
-def algorithmic_bytes_per_row(d: int, collide: bool) -> float:
-    """read x 4d + read target 28 + write x 4d (+2 mask bytes + 4 cost bytes when collision is fused)."""
+def algorithmic_bytes_per_row(d: int, collide: bool) -> float:  # read x 4d + target 28 + write x 4d (+ 2 mask bytes + 4 cost bytes)
     return 8.0 * d + 28.0 + (6.0 if collide else 0.0)
 
 
 # ---- committed profiler records (bench.py cannot profile itself): only used when taken with THIS build of the library -------------
 def _profile_json(fname):
     path = os.path.join(ROOT, "profiles", fname)
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f)
+    return json.load(open(path)) if os.path.exists(path) else None
 
 
 def workload_key(robot, S, W, K, collide, inputs="problem"):
@@ -261,20 +253,6 @@ def kernel_ms(run, reps, prewarm=300):
     t = np.array([a.elapsed_time(b) for a, b in kev])
     return {"median": float(np.median(t)), "mean": float(t.mean()), "min": float(t.min()), "p10": float(np.quantile(t, 0.1)),
             "p90": float(np.quantile(t, 0.9)), "max": float(t.max()), "n": int(reps), "launch_steps": run.B}
-
-
-def device_census(dist, rank, dev_index):
-    """[(rank, device ordinal, PCI bus id, name)] of every rank: lets a reader of the JSON check that N ranks sat on N different GPUs."""
-    p = torch.cuda.get_device_properties(dev_index)
-    bus = None
-    if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
-        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
-    mine = {"rank": rank, "device": dev_index, "pci_bus_id": bus, "uuid": str(getattr(p, "uuid", "")) or None, "name": p.name}
-    if dist is None:
-        return [mine]
-    everyone = [None] * dist.get_world_size()
-    dist.all_gather_object(everyone, mine)
-    return everyone
 
 
 def dryrun(args, world, rank):
@@ -565,7 +543,7 @@ def main():
             r["what"] = "latency view: this rank's shard of ONE request per launch on one stream (no batching over requests, no exchange)"
             siblings["latency_one_request"] = r
 
-    census = device_census(dist, rank, dev_index) if not share_gpu else None
+    census = D.device_census(rank, dev_index, dist is not None) if not share_gpu else None
     cpu_legs = {}
     if world == 1 and rank == 0 and not args.no_cpu_baseline and args.inputs == "problem":
         x_h, t_h = x0.cpu(), target.cpu()

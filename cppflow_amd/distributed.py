@@ -310,6 +310,21 @@ def pick_transport(device: torch.device, group=None, prefer: str = "cabi"):
     return t, rec
 
 
+def device_census(rank: int, dev_index: int, gather: bool = True):
+    """[{rank, device ordinal, PCI bus id, uuid, name}] of every rank (gathered through the default process group): lets a reader of a
+    multi-GPU record check that N ranks sat on N different GPUs."""
+    p = torch.cuda.get_device_properties(dev_index)
+    bus = None
+    if all(hasattr(p, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    mine = {"rank": rank, "device": dev_index, "pci_bus_id": bus, "uuid": str(getattr(p, "uuid", "")) or None, "name": p.name}
+    if not (gather and dist.is_initialized()):
+        return [mine]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return everyone
+
+
 # ---- how a rank issues its steps -----------------------------------------------------------------------------------------------
 def launch_plan(rows_step: int, steps_hint: int, batch: int = 0, gather_every: int = 0, streams: int = 0, quad: bool = False,
                 max_batch: int = 16):

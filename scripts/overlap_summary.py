@@ -17,7 +17,8 @@ import sys
 import numpy as np
 
 KERNEL = "lm_fused_kernel"
-GAP_NS = 40_000  # a region ends where no fused dispatch is resident for this long (a synchronize + barrier is >= 100 us of idle)
+GAP_NS = 1_500  # a region ends where NO fused dispatch is resident for this long: inside a timed region two launches are in flight
+# all the time (the host enqueues a step in ~5 us, the GPU takes ~37), between regions the host synchronises and reads its clock
 
 
 def load(d):
@@ -61,6 +62,8 @@ def main():
     d, stdout_path, out_path = sys.argv[1:4]
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
     rows = load(d)
+    with open(out_path.replace(".json", "_dispatches.csv"), "w") as f:  # (kept beside the summary: begin, end, queue of every fused dispatch)
+        f.write("start_ns,end_ns,queue\n" + "".join(f"{s - rows[0][0]},{e - rows[0][0]},{q}\n" for s, e, q, _ in rows))
     cl = clusters(rows)
     line = None
     for ln in open(stdout_path):
@@ -69,14 +72,16 @@ def main():
     # the timed regions: exactly `steps` dispatches, more than one queue (the isolated-launch loop behind roofline.kernel_ms is one queue)
     regions = [region_stats(c) for c in cl if len(c) == steps]
     timed = [r for r in regions if r["max_resident"] >= 2]
-    iso = [e - s for c in cl if len(c) >= 100 for s, e, _, _ in c[len(c) // 2:]]  # the isolated launches (second half: warm clocks)
+    # the isolated launches behind roofline.kernel_ms: dispatches that never share the chip with another fused dispatch (the last 400)
+    alone = [c for c in cl if region_stats(c)["max_resident"] == 1]
+    iso = [e - s for c in alone for s, e, _, _ in c][-400:]
     rec = {
         "what": "rocprofv3 --kernel-trace of `python3 bench.py --gpus 1 --steps %d --warmup 5 --no-cpu-baseline --no-siblings`: every timed region "
                 "(a run of exactly %d overlapped lm_fused_kernel dispatches on two queues)" % (steps, steps),
         "library_build_id": line["roofline"]["library_build_id"] if line else None,
         "bench_ms_per_step_under_profiler": line["ms_per_step"] if line else None,
         "bench_kernel_ms_isolated_under_profiler": line["roofline"]["kernel_ms"] if line else None,
-        "fused_dispatches_total": len(rows), "clusters": len(cl), "timed_regions": len(timed),
+        "fused_dispatches_total": len(rows), "clusters": len(cl), "cluster_sizes": sorted({len(c) for c in cl}), "timed_regions": len(timed),
         "isolated_dispatch_us_mean": float(np.mean(iso)) / 1e3 if iso else None,
     }
     if timed:
