@@ -581,7 +581,7 @@ def main():
             "kernel_profile": kprof if kprof else {"unavailable": kprof_why},
             "drift": (kstats["median"] / kprof["ms"]) if kprof else None,
             # the profiler's view of the two-launch overlap the step rate rests on (scripts/overlap_summary.py -> profiles/r5_overlap.json)
-            "kernel_ms_overlapped": overlap["kernel_ms_overlapped"] if overlap else None,
+            "kernel_ms_overlapped": overlap.get("kernel_ms_overlapped") if overlap else None,
             "overlap_profile": ({k: overlap[k] for k in ("union_busy_us_per_step", "mean_dispatch_us_under_overlap", "two_resident_frac_of_busy_time",
                                                          "bench_ms_per_step_under_profiler", "union_busy_over_bench_ms_per_step") if k in overlap}
                                 if overlap else {"unavailable": overlap_why}),
