@@ -124,8 +124,57 @@ __device__ __forceinline__ float asin_lm(float x) {  // |x| <= 1
     return __builtin_copysignf(r, x);
 }
 
+// The same three angle functions for the LEAN iterations of a fused launch (kernels_fused.h: iterations whose iterate nobody sees,
+// already evaluated with 5e-7 sine / cosine polynomials): roll and yaw share ONE reciprocal -- 1 / (mx1 mx2), then times the other
+// maximum: one transcendental and five multiplies where two Newton-refined reciprocals take two transcendentals and six
+// instructions (a transcendental among multiply-adds costs the SIMD ~12 cycles, profiles/r4_valu_issue_rate_calibration.txt) --
+// without a Newton step (v_rcp_f32 is good to 1 ulp; the quotient then to 3e-7 RELATIVE, which keeps the residual's accuracy
+// towards 0), and shorter minimax polynomials: atan(a) = a + a s P5(s) on [0, 1] (4.0e-7 absolute in fp32; P7: 8e-8),
+// asin(x) = x + x z P3(z) on |x| <= 0.5 (2.9e-8; 6e-8 through the half-angle form beyond).  Measured on one box, alternating builds
+// (profiles/r5_ab_lean_trig.txt): 34.90 against 35.24 us per C4 step over 2 000 steps (-1.0 %), 35.86 against 36.53 with the driver's
+// 20-step regions (-1.8 %); 586 -> 579 VALU and 9 -> 8 transcendentals per lean iteration.  CPPF_LEAN_TRIG = 0: the canonical
+// functions everywhere (the A/B build).
+#ifndef CPPF_LEAN_TRIG
+#define CPPF_LEAN_TRIG 1
+#endif
+__device__ __forceinline__ float atan_lean_fixup(float a, float ax, float ay, float x, float y) {
+    const float s = a * a;
+    float p = 0.007374001666903496f;
+    p = CPPF_FMA(p, s, -0.03551986813545227f);
+    p = CPPF_FMA(p, s, 0.08216774463653564f);
+    p = CPPF_FMA(p, s, -0.13398799300193787f);
+    p = CPPF_FMA(p, s, 0.1986185610294342f);
+    p = CPPF_FMA(p, s, -0.3332539498806f);
+    float r = CPPF_FMA(a * s, p, a);
+    r = ay > ax ? 1.57079632679489661923f - r : r;
+    r = x < 0.f ? 3.14159265358979323846f - r : r;
+    return __builtin_copysignf(r, y);
+}
+__device__ __forceinline__ void atan2_pair_lean(float y1, float x1, float y2, float x2, float& r1, float& r2) {
+    const float ax1 = fabsf(x1), ay1 = fabsf(y1), ax2 = fabsf(x2), ay2 = fabsf(y2);
+    // (floors of 1e-15: the product of the two maxima must not underflow; atan2(0, 0) = 0 as in atan2_lm)
+    const float mx1 = fmaxf(fmaxf(ax1, ay1), 1e-15f), mx2 = fmaxf(fmaxf(ax2, ay2), 1e-15f);
+    const float inv = __builtin_amdgcn_rcpf(mx1 * mx2);
+    r1 = atan_lean_fixup(fminf(ax1, ay1) * (inv * mx2), ax1, ay1, x1, y1);
+    r2 = atan_lean_fixup(fminf(ax2, ay2) * (inv * mx1), ax2, ay2, x2, y2);
+}
+__device__ __forceinline__ float asin_lean(float x) {  // |x| <= 1
+    const float ax = fabsf(x);
+    const bool big = ax > 0.5f;
+    const float z = big ? CPPF_FMA(-0.5f, ax, 0.5f) : x * x;
+    const float t = big ? __builtin_amdgcn_sqrtf(z) : ax;
+    float p = 0.05158697068691254f;
+    p = CPPF_FMA(p, z, 0.03919339179992676f);
+    p = CPPF_FMA(p, z, 0.07554031163454056f);
+    p = CPPF_FMA(p, z, 0.16664926707744598f);
+    float r = CPPF_FMA(t * z, p, t);
+    r = big ? CPPF_FMA(-2.f, r, 1.57079632679489661923f) : r;
+    return __builtin_copysignf(r, x);
+}
+
 // get_6d_pose_errors without the quaternion detour: the five terms quaternion_to_rpy reads from q_target * q_cur^-1 are
-// entries of R_err = R_target * R_cur^T  (cppflow/optimization_utils.py:813-819)
+// entries of R_err = R_target * R_cur^T  (cppflow/optimization_utils.py:813-819).  LEAN: the angle functions above.
+template <bool LEAN = false>
 __device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&tt)[3], const float (&R)[9],
                                            const float (&p)[3], float (&e)[6]) {
     const float e20 = dot3(Rt[6], Rt[7], Rt[8], R[0], R[1], R[2]);
@@ -135,9 +184,14 @@ __device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&t
     const float e00 = dot3(Rt[0], Rt[1], Rt[2], R[0], R[1], R[2]);
     float sp = -e20;
     sp = sp > 1.f ? 1.f : (sp < -1.f ? -1.f : sp);
-    e[0] = atan2_lm(e21, e22);
-    e[1] = asin_lm(sp);
-    e[2] = atan2_lm(e10, e00);
+    if constexpr (LEAN && CPPF_LEAN_TRIG != 0) {
+        atan2_pair_lean(e21, e22, e10, e00, e[0], e[2]);
+        e[1] = asin_lean(sp);
+    } else {
+        e[0] = atan2_lm(e21, e22);
+        e[1] = asin_lm(sp);
+        e[2] = atan2_lm(e10, e00);
+    }
     e[3] = tt[0] - p[0];
     e[4] = tt[1] - p[1];
     e[5] = tt[2] - p[2];
@@ -530,8 +584,15 @@ __device__ __forceinline__ void lm_gate_solve(double lam_r, double lam_p, unsign
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read back before a later round's writes
 }
 
+// clamp_to_joint_limits for one row (cppflow/optimization_utils.py:823-833).  CPPF_CLAMP_MED3 = 1 would make it one v_med3_f32 per
+// joint (for lo <= hi and a non-NaN q the median of (q, lo, hi) IS fmin(fmax(q, lo), hi), value for value): 7 instructions fewer per
+// iteration and 0.4 % MORE time on one box, alternating builds (35.40 against 35.24 us per C4 step, profiles/r5_ab_lean_trig.txt) --
+// one 8-byte VOP3 issues no faster than the two 4-byte VOP2 it replaces.  Not taken.
+#ifndef CPPF_CLAMP_MED3
+#define CPPF_CLAMP_MED3 0
+#endif
 template <class RB>
 __device__ __forceinline__ void clamp_row(const RB& rb, float (&q)[RB::D]) {
 #pragma unroll
-    for (int j = 0; j < RB::D; ++j) q[j] = fminf(fmaxf(q[j], rb.lo(j)), rb.hi(j));
+    for (int j = 0; j < RB::D; ++j) q[j] = CPPF_CLAMP_MED3 != 0 ? clampf(q[j], rb.lo(j), rb.hi(j)) : fminf(fmaxf(q[j], rb.lo(j)), rb.hi(j));
 }

@@ -132,7 +132,8 @@ __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_i
 // promises; so does the single bare step (clamp = 0, the reference's own cadence).
 //
 // LEAD = true is a lean iteration of a plain K-step launch (iterations 0 .. K-2; FIRST = the launch's first one; 1 .. K-2 the hot
-// loop): no early-out tests, no J / e outputs -- its iterate is an intermediate nobody sees.  LEAD = false is the general iteration:
+// loop): no early-out tests, no J / e outputs -- its iterate is an intermediate nobody sees.  Its residual's three angle functions are
+// the lean ones of kernels_chain.h (pose_error<true>: one shared reciprocal, shorter polynomials, CPPF_LEAN_TRIG).  LEAD = false is the general iteration:
 // the LAST iteration of every launch, and every iteration of an early-out launch, whose frozen intermediate iterates ARE results.
 // CPPF_LEAD_SINCOS: which sine / cosine the leading iterations use -- in the robot-specialised AND the generic kernels alike (the
 // generic ones pick a joint's fold from its limits with a scalar branch where the specialised ones know it at compile time: the same
@@ -170,7 +171,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
     {
         float R[9], p[3], ax[D][3], og[D][3], J[6][D], e[6];
         fk_ee_axes<RB, lead_sincos<RB, LEAD, FIRST>()>(rb, q, R, p, ax, og);
-        pose_error(Rt, tt, R, p, e);
+        pose_error<LEAD>(Rt, tt, R, p, e);
         if constexpr (!LEAD) {
             if (prm.tol_pos2 > 0.f) {  // wave-uniform
                 conv = dot3(e[3], e[4], e[5], e[3], e[4], e[5]) < prm.tol_pos2 && dot3(e[0], e[1], e[2], e[0], e[1], e[2]) < prm.tol_rot2;
@@ -237,7 +238,7 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
 #pragma unroll
                         for (int j = 0; j < D; ++j) asm volatile("" : "+v"(q[j]));  // (unchanged, but the compiler must not know)
                         fk_ee_axes<RB, lead_sincos<RB, LEAD, FIRST>()>(rb, q, R2, p2, ax2, og2);
-                        pose_error(Rt, tt, R2, p2, e2);
+                        pose_error<LEAD>(Rt, tt, R2, p2, e2);
                         jacobian_from_axes<RB>(rb, p2, ax2, og2, J2);
                         rank = lm_gate_hand_over<D>(J2, e2, todo, gate_lds, flag);
                         lm_gate_solve<D>(prm.lam_r_d, prm.lam_p_d, todo, rank, gate_lds, flag, delta);
