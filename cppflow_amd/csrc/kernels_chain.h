@@ -158,9 +158,20 @@ __device__ __forceinline__ void atan2_pair_lean(float y1, float x1, float y2, fl
     r1 = atan_lean_fixup(fminf(ax1, ay1) * (inv * mx2), ax1, ay1, x1, y1);
     r2 = atan_lean_fixup(fminf(ax2, ay2) * (inv * mx1), ax2, ay2, x2, y2);
 }
+#ifndef CPPF_LEAN_ASIN_BRANCH
+#define CPPF_LEAN_ASIN_BRANCH 0  // 1: a wavefront none of whose rows has |x| > 0.5 (a pitch error beyond 30 degrees) skips the half-angle form and its v_sqrt_f32 behind ONE scalar branch (the A/B build)
+#endif
 __device__ __forceinline__ float asin_lean(float x) {  // |x| <= 1
     const float ax = fabsf(x);
     const bool big = ax > 0.5f;
+    if (CPPF_LEAN_ASIN_BRANCH != 0 && __builtin_amdgcn_ballot_w64(big) == 0ull) {  // wave-uniform
+        const float z = x * x;
+        float p = 0.05158697068691254f;
+        p = CPPF_FMA(p, z, 0.03919339179992676f);
+        p = CPPF_FMA(p, z, 0.07554031163454056f);
+        p = CPPF_FMA(p, z, 0.16664926707744598f);
+        return CPPF_FMA(x * z, p, x);
+    }
     const float z = big ? CPPF_FMA(-0.5f, ax, 0.5f) : x * x;
     const float t = big ? __builtin_amdgcn_sqrtf(z) : ax;
     float p = 0.05158697068691254f;
@@ -266,6 +277,79 @@ __device__ __forceinline__ void lm_dual_solve_y(const float (&J)[6][D], const fl
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s = CPPF_FMA(-L[k][i], y[k], s);
         y[i] = s * inv[i];
+    }
+    est = dmax * fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))), fmaxf(fabsf(y[4]), fabsf(y[5])));
+}
+
+// The same 6x6 solve for the LEAN iterations of a fused launch: block L D L^T with 2x2 pivot blocks -- each block inverted through its
+// adjugate, ONE v_rcp_f32 of the determinant per block -- i.e. three transcendentals where the Cholesky factorisation above takes six
+// v_rsq_f32 (a transcendental among multiply-adds costs the SIMD ~12 cycles, four times a multiply-add), for three more plain
+// instructions.  Algebraically two steps of the scalar elimination at once; the determinant a c - b^2 = a (c - b^2 / a) is floored at
+// (its row's damping) x a, which is the scalar factorisation's floor on the second pivot; in fp32 its task-space error is 1.2x the
+// Cholesky form's in the median and 1.8x at the 99th percentile (emulation on 1 024 random Panda rows), which an intermediate iterate
+// does not notice (the relative gate's forcing term is 1e-3) -- the LAST iteration, a K = 1 launch and the early-out launches keep
+// the Cholesky form.  Measured on one box, alternating builds (profiles/r5_ab_lean_block_solve.txt): C4 33.30 against 33.85 us per step
+// over 2 000 steps (-1.6 %), 34.76 against 35.38 with the driver's 20-step regions (-1.8 %), C3 (Fetch, 8 joints) 16.05 against 17.44,
+// independent random configurations 47.9 against 49.1; 579 -> 585 VALU and 8 -> 5 transcendentals per lean iteration, 128 -> 124 VGPRs.
+// CPPF_LEAN_BLOCK_SOLVE = 0: the Cholesky form everywhere (the A/B build).
+#ifndef CPPF_LEAN_BLOCK_SOLVE
+#define CPPF_LEAN_BLOCK_SOLVE 1
+#endif
+template <int D>
+__device__ __forceinline__ void lm_dual_solve_y_blk(const float (&J)[6][D], const float (&e)[6], float lam_r, float lam_p,
+                                                    float (&y)[6], float& est) {
+    float A[6][6], dmax = 0.f;  // lower triangle
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            float s = (i == j) ? (i < 3 ? lam_r : lam_p) : 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s = cfma2(J[i][k], J[j][k], s);
+            A[i][j] = s;
+            if (i == j) dmax = fmaxf(dmax, s);
+        }
+    float w0[6][3], w1[6][3], ia[3], ib[3], ic[3];  // W = A21 A11^-1 per pivot block (rows below it), and the blocks' inverses
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = 2 * k;
+        const float a = A[p][p], b = A[p + 1][p], c = A[p + 1][p + 1];
+        const float det = fmaxf(CPPF_FMA(a, c, -(b * b)), (p + 1 < 3 ? lam_r : lam_p) * a);
+        const float r = __builtin_amdgcn_rcpf(det);  // 1 ulp
+        ia[k] = c * r, ib[k] = -(b * r), ic[k] = a * r;
+#pragma unroll
+        for (int i = p + 2; i < 6; ++i) {
+            w0[i][k] = CPPF_FMA(A[i][p + 1], ib[k], A[i][p] * ia[k]);
+            w1[i][k] = CPPF_FMA(A[i][p + 1], ic[k], A[i][p] * ib[k]);
+        }
+#pragma unroll
+        for (int i = p + 2; i < 6; ++i)
+#pragma unroll
+            for (int j = p + 2; j <= i; ++j) A[i][j] = CPPF_FMA(-w1[i][k], A[j][p + 1], CPPF_FMA(-w0[i][k], A[j][p], A[i][j]));
+    }
+    float u[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) u[i] = e[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // forward: u = L^-1 e
+        const int p = 2 * k;
+#pragma unroll
+        for (int i = p + 2; i < 6; ++i) u[i] = CPPF_FMA(-w1[i][k], u[p + 1], CPPF_FMA(-w0[i][k], u[p], u[i]));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // y = D^-1 u
+        const int p = 2 * k;
+        y[p] = CPPF_FMA(ib[k], u[p + 1], ia[k] * u[p]);
+        y[p + 1] = CPPF_FMA(ic[k], u[p + 1], ib[k] * u[p]);
+    }
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {  // backward: y = L^-T y
+        const int p = 2 * k;
+#pragma unroll
+        for (int i = p + 2; i < 6; ++i) {
+            y[p] = CPPF_FMA(-w0[i][k], y[i], y[p]);
+            y[p + 1] = CPPF_FMA(-w1[i][k], y[i], y[p + 1]);
+        }
     }
     est = dmax * fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))), fmaxf(fabsf(y[4]), fabsf(y[5])));
 }

@@ -184,7 +184,10 @@ __device__ __forceinline__ bool lm_row_iterate(const RB& rb, const LmK& prm, con
             lm_primal_solve<D>(J, e, prm.lm_lambda, prm.a_pos, prm.a_rot, delta);
         } else {
             float y[6];
-            lm_dual_solve_y<D>(J, e, prm.lam_r, prm.lam_p, y, est);
+            if constexpr (LEAD && CPPF_LEAN_BLOCK_SOLVE != 0)
+                lm_dual_solve_y_blk<D>(J, e, prm.lam_r, prm.lam_p, y, est);
+            else
+                lm_dual_solve_y<D>(J, e, prm.lam_r, prm.lam_p, y, est);
             lm_dual_apply<D>(J, y, delta);
         }
         if constexpr (!LEAD) {

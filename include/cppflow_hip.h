@@ -94,7 +94,9 @@ typedef struct cppf_lm_params {
                            * iteration of a launch -- the one that produces x_out -- is evaluated in the canonical arithmetic (the
                            * sine / cosine the bit-exact FK uses); the K - 1 iterations before it, whose iterates are not outputs,
                            * use cheaper elementary functions in the row shape: for the residual's roll / pitch / yaw shorter polynomials
-                           * behind ONE shared reciprocal (4e-7 absolute), and a cheaper sine / cosine (polynomials on [-pi, pi], 5e-7 absolute; the first
+                           * behind ONE shared reciprocal (4e-7 absolute), the 6x6 solve as a block L D L^T with 2x2 pivots (three
+                           * reciprocals for six reciprocal square roots; 1.2 - 1.8x the Cholesky form's fp32 rounding error), and a
+                           * cheaper sine / cosine (polynomials on [-pi, pi], 5e-7 absolute; the first
                            * iteration behind a reduction by whole turns -- the input need not lie inside the joint limits --
                            * the others directly: their iterates have been through the clamp).  A K = 1 launch (the reference's
                            * cadence) and every iteration of an early-out launch are canonical throughout.

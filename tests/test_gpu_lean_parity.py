@@ -1,8 +1,9 @@
 """The K-step iterate of a fused launch against the oracle's K-step iterate OFF the fixed point (pytest -m gpu).
 
-Iterations 0 .. K-2 of a plain K-step launch are "lean" (csrc/kernels_fused.h): polynomial sine / cosine (5e-7 absolute) in the row
-shape, and in both shapes a flagged row is re-solved in double precision only when the estimated step error also exceeds 1e-3 of
-the residual.  Every other K > 1 test compares CONVERGED rows after K = 10, where any contraction lands on the same point; here
+Iterations 0 .. K-2 of a plain K-step launch are "lean" (csrc/kernels_fused.h): in the row shape polynomial sine / cosine (5e-7
+absolute), the residual's angle functions behind one shared reciprocal (4e-7) and the 6x6 solve as a 2x2-block L D L^T (three
+reciprocals for six reciprocal square roots), and in both shapes a flagged row is re-solved in double precision only when the
+estimated step error also exceeds 1e-3 of the residual.  Every other K > 1 test compares CONVERGED rows after K = 10, where any contraction lands on the same point; here
 K = 2, 3, 5 -- iterates that are still moving -- are held against `oracle64.lm_steps(x0, K)` (the reference's step,
 cppflow/optimization.py:61-92 + the clamp of :259, reference operation order, fp64):
 
@@ -152,7 +153,8 @@ def test_k_step_iterate_against_the_oracle_off_the_fixed_point(robots, name, sou
     for _ in range(K):
         xc = rb.lm_pose_steps(xc, tgt_d, n_steps=1, shape=_hip.SHAPE_ROW, **LM)["x"]
     tsc = task_space(JK, host(xc) - row_auto)
-    check((tsc / (K * FLOOR32_PER_STEP * amp))[calm].max() <= 1.0, "K canonical launches vs one launch of K: row-wise", (tsc / (K * FLOOR32_PER_STEP * amp))[calm].max())
+    # (two iterates of the default solver against each other: each may sit K eps amp from the exact iterate, so the bar is twice that)
+    check((tsc / (2 * K * FLOOR32_PER_STEP * amp))[calm].max() <= 1.0, "K canonical launches vs one launch of K: row-wise", (tsc / (2 * K * FLOOR32_PER_STEP * amp))[calm].max())
     check(np.quantile(tsc[calm], 0.5) <= K * 2e-6, "K canonical launches vs one launch of K: median", np.quantile(tsc[calm], 0.5))  # the polynomials' 5e-7, through the chain
     # ---- the relative gate: which rows it declines, and what that changes ----
     flagged, declined = np.zeros(n, bool), np.zeros(n, bool)
