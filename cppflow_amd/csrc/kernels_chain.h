@@ -137,7 +137,10 @@ __device__ __forceinline__ float asin_lm(float x) {  // |x| <= 1
 #ifndef CPPF_LEAN_TRIG
 #define CPPF_LEAN_TRIG 1
 #endif
-__device__ __forceinline__ float atan_lean_fixup(float a, float ax, float ay, float x, float y) {
+#ifndef CPPF_LEAN_RPY_FAST
+#define CPPF_LEAN_RPY_FAST 1  // the principal-range fast path of pose_error<LEAN> (0: the A/B build)
+#endif
+__device__ __forceinline__ float atan_lean_poly(float a) {  // atan(a), |a| <= 1: a + a s P5(s), odd in a
     const float s = a * a;
     float p = 0.007374001666903496f;
     p = CPPF_FMA(p, s, -0.03551986813545227f);
@@ -145,7 +148,10 @@ __device__ __forceinline__ float atan_lean_fixup(float a, float ax, float ay, fl
     p = CPPF_FMA(p, s, -0.13398799300193787f);
     p = CPPF_FMA(p, s, 0.1986185610294342f);
     p = CPPF_FMA(p, s, -0.3332539498806f);
-    float r = CPPF_FMA(a * s, p, a);
+    return CPPF_FMA(a * s, p, a);
+}
+__device__ __forceinline__ float atan_lean_fixup(float a, float ax, float ay, float x, float y) {
+    float r = atan_lean_poly(a);
     r = ay > ax ? 1.57079632679489661923f - r : r;
     r = x < 0.f ? 3.14159265358979323846f - r : r;
     return __builtin_copysignf(r, y);
@@ -158,20 +164,10 @@ __device__ __forceinline__ void atan2_pair_lean(float y1, float x1, float y2, fl
     r1 = atan_lean_fixup(fminf(ax1, ay1) * (inv * mx2), ax1, ay1, x1, y1);
     r2 = atan_lean_fixup(fminf(ax2, ay2) * (inv * mx1), ax2, ay2, x2, y2);
 }
-#ifndef CPPF_LEAN_ASIN_BRANCH
-#define CPPF_LEAN_ASIN_BRANCH 0  // 1: a wavefront none of whose rows has |x| > 0.5 (a pitch error beyond 30 degrees) skips the half-angle form and its v_sqrt_f32 behind ONE scalar branch (the A/B build)
-#endif
 __device__ __forceinline__ float asin_lean(float x) {  // |x| <= 1
     const float ax = fabsf(x);
     const bool big = ax > 0.5f;
-    if (CPPF_LEAN_ASIN_BRANCH != 0 && __builtin_amdgcn_ballot_w64(big) == 0ull) {  // wave-uniform
-        const float z = x * x;
-        float p = 0.05158697068691254f;
-        p = CPPF_FMA(p, z, 0.03919339179992676f);
-        p = CPPF_FMA(p, z, 0.07554031163454056f);
-        p = CPPF_FMA(p, z, 0.16664926707744598f);
-        return CPPF_FMA(x * z, p, x);
-    }
+
     const float z = big ? CPPF_FMA(-0.5f, ax, 0.5f) : x * x;
     const float t = big ? __builtin_amdgcn_sqrtf(z) : ax;
     float p = 0.05158697068691254f;
@@ -196,8 +192,29 @@ __device__ __forceinline__ void pose_error(const float (&Rt)[9], const float (&t
     float sp = -e20;
     sp = sp > 1.f ? 1.f : (sp < -1.f ? -1.f : sp);
     if constexpr (LEAN && CPPF_LEAN_TRIG != 0) {
-        atan2_pair_lean(e21, e22, e10, e00, e[0], e[2]);
-        e[1] = asin_lean(sp);
+        // The common case of an LM iteration -- every row of the wavefront has all three error angles in their principal ranges
+        // (|pitch| <= 30 degrees, |roll|, |yaw| <= 45 degrees: true from the first iteration on for seeds within a few tenths of a
+        // radian of the path) -- needs neither the octant / quadrant logic of atan2 nor asin's half-angle form with its square root:
+        // roll = atan(e21 / e22), yaw = atan(e10 / e00), pitch = asin(sp) by the SAME polynomials on the SAME quotients, so a row's
+        // value does not depend on which branch its wavefront took (the fused multiply-adds are odd in their argument; the
+        // reciprocal is of the same product e22 e00 >= 0.37).  One scalar branch; the general lean form stays behind it.
+        // A wave-uniform skip of asin's half-angle form alone measured -0.6 % per step (profiles/r5_ab_lean_asin_branch.txt).
+        const bool general = !(fabsf(sp) <= 0.5f) | !(fabsf(e21) <= e22) | !(fabsf(e10) <= e00);  // (a NaN goes the general way)
+        if (CPPF_LEAN_RPY_FAST != 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(general) == 0ull, 1)) {
+            const float inv = __builtin_amdgcn_rcpf(e22 * e00);
+            const float a1 = e21 * (inv * e00), a2 = e10 * (inv * e22);
+            e[0] = atan_lean_poly(a1);
+            e[2] = atan_lean_poly(a2);
+            const float z = sp * sp;
+            float p = 0.05158697068691254f;
+            p = CPPF_FMA(p, z, 0.03919339179992676f);
+            p = CPPF_FMA(p, z, 0.07554031163454056f);
+            p = CPPF_FMA(p, z, 0.16664926707744598f);
+            e[1] = CPPF_FMA(sp * z, p, sp);
+        } else {
+            atan2_pair_lean(e21, e22, e10, e00, e[0], e[2]);
+            e[1] = asin_lean(sp);
+        }
     } else {
         e[0] = atan2_lm(e21, e22);
         e[1] = asin_lm(sp);

@@ -8,9 +8,10 @@ the flags cppflow_amd/build.py gives csrc/fused_static.hip (5 s) into build_var/
 
 The kernel is cut into REGIONS with LLVM's own loop annotations ("=>This Loop Header: Depth=1", "in Loop: Header=...", "Parent
 Loop ..."): the code in front of the first depth-1 loop (load + the launch's first, lean iteration), every depth-1 loop, the code
-between / behind them (the last, canonical iteration; the finish stage).  Inside a depth-1 loop the HOT BODY is the fall-through
-chain from the loop header -- the straight-line code a wavefront executes when no rare branch (the conditioning gate's re-solve
-rounds, which sit behind `s_cbranch` as nested loops) is taken; the LM iteration is the depth-1 loop with the largest hot body.
+between / behind them (the last, canonical iteration; the finish stage).  Inside a depth-1 loop the HOT BODY is the likely
+path of one trip: from the loop header, falling through every conditional branch (the rare paths -- the conditioning gate's re-solve
+rounds, the general form of the angle functions -- are the taken ones) and following unconditional ones up to the back-edge; the LM
+iteration is the depth-1 loop with the largest hot body.
 
 Per region: VALU instructions by class (fma / mul / add-sub / min-max-med / cmp / cndmask / mov / cvt / bit ops / transcendental /
 DPP / fp64 / other), 4-byte vs 8-byte encodings (VOP2 / VOP1 / VOPC e32 against VOP3 / literal forms: an 8-byte VALU instruction
@@ -135,9 +136,21 @@ def regions(blocks):
             while j < n and blocks[j]["depth"] >= 1:
                 j += 1
             loop = blocks[i:j]
-            # hot body: the header block, then fall-through blocks at depth 1 up to the back-edge, skipping blocks only reached by a
-            # taken branch is not decidable here; the header block alone is the straight-line iteration up to the first rare branch
-            hot = list(loop[0]["ins"])
+            # hot body: the LIKELY path of one trip -- from the header, fall through every conditional branch (the rare paths are the
+            # taken ones: the kernels mark them with __builtin_expect, and the compiler lays the likely successor out next), follow
+            # unconditional branches, stop at the back-edge or when the walk leaves the loop
+            index = {bb["label"]: n for n, bb in enumerate(loop)}
+            hot, n_, seen = [], 0, set()
+            while n_ is not None and n_ < len(loop) and n_ not in seen:
+                seen.add(n_)
+                bb = loop[n_]
+                hot += bb["ins"]
+                last = bb["ins"][-1] if bb["ins"] else ("", "")
+                if last[0] == "s_branch":
+                    tgt = last[1].strip().split()[0]
+                    n_ = index.get(tgt) if tgt != loop[0]["label"] else None
+                else:
+                    n_ = n_ + 1
             tail = [bb for bb in loop[1:] if bb["depth"] == 1]
             out.append((f"depth-1 loop at {b['label']} ({len(loop)} blocks)", hot, [x for bb in loop for x in bb["ins"]], [x for bb in tail for x in bb["ins"]]))
             i = j
@@ -164,12 +177,15 @@ def main():
         allins = [x for b in blocks for x in b["ins"]]
         print("  whole kernel (static):", fmt(census(allins)))
         regs = regions(blocks)
-        best = max((r for r in regs if len(r) == 4), key=lambda r: census(r[1])["valu"], default=None)
+        # the LM iteration = the lean loop: the depth-1 loop whose likely path stores nothing (the general iteration's holds the J / e
+        # output stores) and is the longest of those
+        lean = [r for r in regs if len(r) == 4 and census(r[1])["vmem"] == 0 and census(r[1])["lds"] == 0]
+        best = max(lean or [r for r in regs if len(r) == 4], key=lambda r: census(r[1])["valu"], default=None)
         for r in regs:
             if len(r) == 4:
                 tag = "  <== the LM iteration (hot loop)" if r is best else ""
                 print(f"  {r[0]}{tag}")
-                print("      header block (the iteration up to its first rare branch):", fmt(census(r[1])))
+                print("      likely path of one trip (rare branches not taken):       ", fmt(census(r[1])))
                 print("      other depth-1 blocks (update / clamp, gate bookkeeping):  ", fmt(census(r[3])))
                 print("      whole loop incl. nested (gate re-solve rounds):            ", fmt(census(r[2])))
             else:

@@ -21,11 +21,14 @@ def test_isa_mix_finds_the_lm_iteration_of_the_headline_kernel():
     regs = isa_mix.regions(blocks)
     loops = [r for r in regs if len(r) == 4]
     assert len(loops) >= 2  # the lean loop and the general (last / early-out) iteration's loop at least
-    hot = max(loops, key=lambda r: isa_mix.census(r[1])["valu"])
+    lean = [r for r in loops if isa_mix.census(r[1])["vmem"] == 0 and isa_mix.census(r[1])["lds"] == 0]
+    hot = max(lean, key=lambda r: isa_mix.census(r[1])["valu"])
     c = isa_mix.census(hot[1])
-    # the lean LM iteration up to its one rare branch: ~590 VALU, >= 90 % of it multiply-adds, multiplies and adds, no fp64, no LDS
+    # the likely path of one lean LM iteration (update and clamp included): ~590 VALU, >= 90 % of it multiply-adds, multiplies and adds,
+    # at most five transcendentals (three block pivots, one shared reciprocal of the angle functions, none for asin on the fast path),
+    # no fp64, no LDS
     assert 500 <= c["valu"] <= 700, c["valu"]
-    assert (c["fma"] + c["mul"] + c["addsub"]) / c["valu"] >= 0.9 and c["fp64"] == 0 and c["lds"] == 0 and c["mfma"] == 0
+    assert (c["fma"] + c["mul"] + c["addsub"]) / c["valu"] >= 0.9 and c["fp64"] == 0 and c["mfma"] == 0 and c["trans"] <= 5, dict(c)
     whole = isa_mix.census([x for b in blocks for x in b["ins"]])
     assert whole["valu"] > 5000 and whole["fp64"] > 0  # the gate's double-precision rounds live behind the rare branches
 
