@@ -22,7 +22,6 @@ an eighth of the chip; eight consecutive requests' shards make one full-width la
 latency-bound: a 32 768-row launch takes ~26 us against 49 us for the unsharded 262 144 rows.
 """
 
-import contextlib
 import ctypes
 import sys
 import time

@@ -55,7 +55,7 @@ def compile_dev():
 
 
 def parse(path, flt):
-    """-> {kernel: [block]}, block = dict(label, depth, header (innermost loop header label or None), outer (depth-1 header), ins [(op, args)])"""
+    """-> {kernel: [block]}, block = dict(label, depth (LLVM's loop depth of the block), is_header, ins [(op, args)])"""
     kernels, cur, blocks = {}, None, None
     for ln in open(path):
         m = re.match(r"^(_Z\w+):", ln)
@@ -63,7 +63,7 @@ def parse(path, flt):
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
             cur = name if (flt in name and "lm_fused_kernel" in name or (flt and flt in name)) else None
             if cur is not None:
-                blocks = kernels.setdefault(cur, [dict(label="entry", depth=0, outer=None, ins=[])])
+                blocks = kernels.setdefault(cur, [dict(label="entry", depth=0, is_header=False, ins=[])])
             continue
         if cur is None:
             continue
@@ -74,14 +74,7 @@ def parse(path, flt):
         if m:
             c = m.group(2) or ""
             depth = int(re.search(r"Depth=(\d+)", c).group(1)) if "Depth=" in c else 0
-            outer = None
-            if "This Loop Header" in c and depth == 1:
-                outer = m.group(1)
-            elif "Parent Loop" in c:
-                outer = "." + re.search(r"Parent Loop (BB\w+)", c).group(1).replace("BB", "LBB") if False else None
-            hm = re.search(r"Header=(BB\w+)", c)
-            blocks.append(dict(label=m.group(1), depth=depth, hdr=("." + "L" + hm.group(1)) if hm else (m.group(1) if "This Loop Header" in c else None),
-                               is_header="This Loop Header" in c, ins=[]))
+            blocks.append(dict(label=m.group(1), depth=depth, is_header="This Loop Header" in c, ins=[]))
             continue
         m = re.match(r"^\t([a-z_0-9]+)\s*(.*)", ln)
         if m and not m.group(1).startswith(".") and blocks is not None:

@@ -1,10 +1,8 @@
 """Round-5 additions on the GPU (pytest -m gpu): the resident dp_search's fit check and the C-ABI lifetime rule through the
 Python wrapper (the C client exercises it from C, tests/c_client/abi_client.c)."""
 
-import ctypes
 import gc
 
-import numpy as np
 import pytest
 import torch
 
