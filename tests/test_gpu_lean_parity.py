@@ -183,3 +183,43 @@ def test_k_step_iterate_against_the_oracle_off_the_fixed_point(robots, name, sou
     print(f"{name} {source} K={K}: calm {calm.mean():.3f}, flagged {flagged.mean():.4f}, declined {declined.mean():.4f}, moved by the relative gate {moved.mean():.4f}, "
           f"smin q01 {np.quantile(smin, 0.01):.2e}, amp q99 {np.quantile(amp[calm], 0.99):.1f}")
     assert not bad, "\n".join(str(b) for b in bad)
+
+
+@pytest.mark.parametrize("name", ["panda", "fetch"])
+def test_lean_angle_functions_general_path_and_wave_independence(robots, name):
+    """The lean iterations evaluate roll / pitch / yaw on a principal-range FAST path when every row of the wavefront is within
+    |pitch| <= 30, |roll|, |yaw| <= 45 degrees, and in the general lean form otherwise (csrc/kernels_chain.h: pose_error<true>).  Rows with
+    FAR targets (rotation errors up to pi: the target of an unrelated configuration) force the general form; interleaved with near rows
+    they also put near rows into wavefronts that take it.  (1) a row's K-step result does not depend on which rows share its wavefront
+    -- the same rows in another order give the same bits; (2) near AND far rows stay inside the row-wise bar of the test above against
+    the fp64 oracle."""
+    from cppflow_amd import _hip
+
+    rb = robots[name]
+    ch = H.chain(name)
+    K, n = 3, 2048
+    rng = np.random.RandomState(9)
+    q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(n, ch.ndof)))
+    tgt = H.f32(H.oracle64(name).fk(q_star))
+    x0 = np.clip(q_star + 0.05 * rng.randn(n, ch.ndof), ch.lo, ch.hi)
+    far = rng.rand(n) < 0.25  # a quarter of the rows start at an unrelated configuration
+    x0[far] = rng.uniform(ch.lo, ch.hi, size=(int(far.sum()), ch.ndof))
+    x0 = H.f32(x0)
+    o64 = H.oracle64(name)
+    e0 = o64.lm_step(x0, tgt, solver=0, **LM)[2].reshape(n, 6)
+    rot0 = np.abs(e0[:, :3] / 0.35).max(axis=1)
+    assert (rot0[far] > np.pi / 4).mean() > 0.5 and (rot0[~far] < 0.5).all()  # the far rows do leave the principal range, the near ones do not
+    x = host(rb.lm_pose_steps(dev(x0), dev(tgt), n_steps=K, shape=_hip.SHAPE_ROW, **LM)["x"])
+    # (1) another order of the same rows: near rows first, far rows last -> wavefronts of near rows only take the fast path
+    order = np.argsort(far, kind="stable")
+    xp = host(rb.lm_pose_steps(dev(x0[order]), dev(tgt[order]), n_steps=K, shape=_hip.SHAPE_ROW, **LM)["x"])
+    assert np.array_equal(xp, x[order])
+    # (2) against the oracle
+    xs, Js, _ = oracle_trace(o64, x0, tgt, K)
+    _, JK, _, _ = o64.lm_step(xs[-1], tgt, solver=0, **LM)
+    steps = np.max([np.abs(xs[k + 1] - xs[k]).max(axis=1) for k in range(K)], axis=0)
+    amp, _ = _amplification(Js + [JK], steps)
+    calm = steps < 1.0
+    ts = task_space(JK, x - xs[-1])
+    assert (ts / (K * FLOOR32_PER_STEP * amp))[calm].max() <= 1.0, (name, (ts / (K * FLOOR32_PER_STEP * amp))[calm].max())
+    assert np.quantile(ts[calm & ~far], 0.5) <= 1e-6 and calm[~far].mean() > 0.95 and (calm & far).sum() > 50
