@@ -189,7 +189,7 @@ def test_k_step_iterate_against_the_oracle_off_the_fixed_point(robots, name, sou
 def test_lean_angle_functions_general_path_and_wave_independence(robots, name):
     """The lean iterations evaluate roll / pitch / yaw on a principal-range FAST path when every row of the wavefront is within
     |pitch| <= 30, |roll|, |yaw| <= 45 degrees, and in the general lean form otherwise (csrc/kernels_chain.h: pose_error<true>).  Rows with
-    FAR targets (rotation errors up to pi: the target of an unrelated configuration) force the general form; interleaved with near rows
+    rotation errors of a radian (a start 0.45 rad per joint from the solution) force the general form; interleaved with near rows
     they also put near rows into wavefronts that take it.  (1) a row's K-step result does not depend on which rows share its wavefront
     -- the same rows in another order give the same bits; (2) near AND far rows stay inside the row-wise bar of the test above against
     the fp64 oracle."""
@@ -202,13 +202,13 @@ def test_lean_angle_functions_general_path_and_wave_independence(robots, name):
     q_star = H.f32(rng.uniform(ch.lo, ch.hi, size=(n, ch.ndof)))
     tgt = H.f32(H.oracle64(name).fk(q_star))
     x0 = np.clip(q_star + 0.05 * rng.randn(n, ch.ndof), ch.lo, ch.hi)
-    far = rng.rand(n) < 0.25  # a quarter of the rows start at an unrelated configuration
-    x0[far] = rng.uniform(ch.lo, ch.hi, size=(int(far.sum()), ch.ndof))
+    far = rng.rand(n) < 0.25  # a quarter of the rows start 0.45 rad (per joint, 1 sigma) from their solution: rotation errors of a radian
+    x0[far] = np.clip(q_star[far] + 0.45 * rng.randn(int(far.sum()), ch.ndof), ch.lo, ch.hi)
     x0 = H.f32(x0)
     o64 = H.oracle64(name)
-    e0 = o64.lm_step(x0, tgt, solver=0, **LM)[2].reshape(n, 6)
-    rot0 = np.abs(e0[:, :3] / 0.35).max(axis=1)
-    assert (rot0[far] > np.pi / 4).mean() > 0.5 and (rot0[~far] < 0.5).all()  # the far rows do leave the principal range, the near ones do not
+    e0 = o64.lm_step(x0, tgt, solver=0, **LM)[2].reshape(n, 6) / 0.35  # (the scaled residual's rotation rows -> radians)
+    general = (np.abs(e0[:, [0, 2]]).max(axis=1) > np.pi / 4) | (np.abs(e0[:, 1]) > np.pi / 6)  # rows that leave the principal range
+    assert general[far].mean() > 0.4 and not general[~far].any()
     x = host(rb.lm_pose_steps(dev(x0), dev(tgt), n_steps=K, shape=_hip.SHAPE_ROW, **LM)["x"])
     # (1) another order of the same rows: near rows first, far rows last -> wavefronts of near rows only take the fast path
     order = np.argsort(far, kind="stable")
@@ -222,4 +222,5 @@ def test_lean_angle_functions_general_path_and_wave_independence(robots, name):
     calm = steps < 1.0
     ts = task_space(JK, x - xs[-1])
     assert (ts / (K * FLOOR32_PER_STEP * amp))[calm].max() <= 1.0, (name, (ts / (K * FLOOR32_PER_STEP * amp))[calm].max())
-    assert np.quantile(ts[calm & ~far], 0.5) <= 1e-6 and calm[~far].mean() > 0.95 and (calm & far).sum() > 20  # (most far rows take a step beyond 1 rad: the calm ones are still dozens)
+    # ... and that bar was held on rows that DID go through the general form (not only on the near rows of mixed wavefronts)
+    assert np.quantile(ts[calm & ~far], 0.5) <= 1e-6 and calm[~far].mean() > 0.95 and (calm & far & general).sum() > 50
