@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Opcode census of the headline kernel, region by region, from `hipcc -S` output (no GPU needed).
 
-    python scripts/isa_mix.py [file.s | --compile] [kernel-name filter]
+    python scripts/isa_mix.py [file.s | --compile] [-DMACRO=value ...] [kernel-name filter]
 
 `--compile` (the default when no file is given) compiles scripts/fused_dev.hip -- lm_fused_kernel<StaRobot<Panda>, 1> alone -- with
 the flags cppflow_amd/build.py gives csrc/fused_static.hip (5 s) into build_var/fused_dev.s.
@@ -46,10 +46,10 @@ EIGHT = re.compile(r"_e64|^v_fma_f32$|^v_fmaak|^v_fmamk|^v_med3|^v_max3|^v_min3|
                    r"^v_fma_f64|^v_mul_f64|^v_add_f64|^v_mad|_dpp$|^v_alignbit|^v_div|^v_cndmask_b32_e64|^v_ldexp|^v_pk_")
 
 
-def compile_dev():
+def compile_dev(defines=()):
     out = os.path.join(ROOT, "build_var", "fused_dev.s")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd = ["hipcc"] + FLAGS + [f"-I{ROOT}/cppflow_amd/csrc", f"-I{ROOT}/include", "-S", "--cuda-device-only", "-o", out, os.path.join(ROOT, "scripts", "fused_dev.hip")]
+    cmd = ["hipcc"] + FLAGS + list(defines) + [f"-I{ROOT}/cppflow_amd/csrc", f"-I{ROOT}/include", "-S", "--cuda-device-only", "-o", out, os.path.join(ROOT, "scripts", "fused_dev.hip")]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return out
 
@@ -103,13 +103,17 @@ def census(ins):
         elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
             c["vmem"] += 1
     c["flops_per_valu"] = (2 * c["fma"] + c["mul"] + c["addsub"]) / max(c["valu"], 1)
+    # issue-cycle estimate at four wavefronts per SIMD from the calibration (profiles/r4_valu_issue_rate_calibration.txt): 2.41 cycles for a
+    # 4-byte VALU instruction, 2.89 for an 8-byte one (2.65 for the literal forms), ~12 for a transcendental among multiply-adds
+    lit = sum(1 for op, _ in ins if op.startswith(("v_fmaak", "v_fmamk")))
+    c["issue_cycles"] = 2.41 * c["valu4"] + 2.89 * (c["valu8"] - lit) + 2.65 * lit + (12 - 2.41) * c["trans"]
     return c
 
 
 def fmt(c):
     cls = " ".join(f"{k} {c[k]}" for k in list(CLASSES) + ["other"] if c[k])
     return (f"VALU {c['valu']:5d} (4-byte {c['valu4']}, 8-byte {c['valu8']})  [{cls}]  SALU {c['salu']} LDS {c['lds']} VMEM {c['vmem']}  "
-            f"flops/VALU lane-op {c['flops_per_valu']:.3f}")
+            f"flops/VALU lane-op {c['flops_per_valu']:.3f}  est. issue cycles {c['issue_cycles']:.0f}")
 
 
 def regions(blocks):
@@ -162,9 +166,11 @@ def main():
         path = args.pop(0)
     if args and args[0] == "--compile":
         args.pop(0)
+    defines = [a for a in args if a.startswith("-D")]
+    args = [a for a in args if not a.startswith("-D")]
     flt = args[0] if args else ""
     if path is None:
-        path = compile_dev()
+        path = compile_dev(defines)
     for name, blocks in parse(path, flt).items():
         print(name[:150])
         allins = [x for b in blocks for x in b["ins"]]
