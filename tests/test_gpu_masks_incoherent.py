@@ -4,7 +4,7 @@ tests a row's wavefront executes depends on its neighbours -- the masks must not
 oracle (reference: cppflow/collision_detection.py:39-68, search.py:46-54) on independent random configurations (a wavefront then runs
 ~26 exact tests per row where its rows need ~3, profiles/r5_cull_stats.txt), on consecutive waypoints of a smooth path (coherent),
 on both within one launch, on partial wavefronts and tiny launches, for every shipped robot; and a row's masks are the same whatever
-rows share its wavefront.  `tests_per_wave` recomputes, from the oracle's capsule end points and the kernel's broad-phase thresholds,
+rows share its wavefront.  `exact_tests_in_wave` recomputes, from the oracle's capsule end points and the kernel's broad-phase thresholds,
 how many exact tests a wavefront executes, so that the test knows which regime each input is in.  (Written with the round-5 experiment
 that compacted the surviving (row, test) items into an LDS queue -- bit-exact, slower, not taken: profiles/r5_ab_coll_queue.txt.)"""
 
@@ -23,7 +23,7 @@ def dev(a):
     return torch.tensor(np.asarray(a), dtype=torch.float32, device=DEV)
 
 
-def tests_per_wave(name, x, lo, hi):
+def exact_tests_in_wave(name, x, lo, hi):
     """per wavefront of 64 consecutive rows: exact tests the wavefront executes (any row within reach) and (row, test) items its rows need"""
     from cppflow_amd import gen_robots as G
 
@@ -88,9 +88,10 @@ def test_masks_bit_exact_on_independent_random_configurations(name):
     q = H.random_configs(name, n, seed=12)
     res = fused_masks(rb, q, target)
     x, want = check_against_oracle(name, rb, res, lo, hi)
-    tests, need = tests_per_wave(name, x, lo, hi)
-    if H.chain(name).pairs.shape[0] > 0:
-        assert np.median(tests) > 3 * np.median(need), (name, np.median(tests), np.median(need))  # the incoherent regime
+    tests, need = exact_tests_in_wave(name, x, lo, hi)
+    if name == "panda":  # the incoherent regime (a compact arm like fetch_arm needs most of its pairs on every row anyway)
+        assert np.median(tests) > 3 * np.median(need), (name, np.median(tests), np.median(need))
+    assert np.median(tests) >= np.median(need)
     assert 0.005 < want["self_mask"].mean() < 0.995 or H.chain(name).pairs.shape[0] == 0
     # the standalone mask kernel at the same x
     alone = rb.collision_masks(res["x"].reshape(96, 64, -1))
@@ -120,7 +121,7 @@ def test_coherent_and_incoherent_wavefronts_in_one_launch():
     mix[::2] = q.reshape(S, W, -1)[::2]  # every other wavefront: independent rows
     res = fused_masks(rb, mix.reshape(S * W, -1), target, n_steps=1)
     xk, want = check_against_oracle(name, rb, res, lo, hi)
-    tests, need = tests_per_wave(name, xk, lo, hi)
+    tests, need = exact_tests_in_wave(name, xk, lo, hi)
     assert np.median(tests[::2]) > 3 * np.median(need[::2]) and np.median(tests[1::2]) < 2 * np.median(need[1::2]) + 1, (tests[:4], need[:4])
     restore(rb)
 
