@@ -73,6 +73,13 @@ __device__ __forceinline__ void pace_wait(unsigned long long t0, int k, float pa
         if (mode != 2) set_prio(3 - (cnt > 3 ? 3 : cnt));
         return;
     }
+    if (mode >= 5 && mode <= 7) {  // static bands (no clock, no constant): band = quarter of the grid = age rank on the SIMD
+        const int band = (int)((blockIdx.x * 4u) / gridDim.x);
+        if (mode == 5) set_prio(band < 2 ? 3 : (((k + band) & 1) ? 2 : 1));          // the two youngest bands take turns behind the two oldest
+        else if (mode == 6) set_prio(((k + band) & 1) ? 2 : 1);                      // neighbours take turns, all four bands
+        else set_prio(band < 2 ? 3 : (band == 2 ? 1 : 2));                           // the youngest band ahead of the third, statically
+        return;
+    }
     if (pace == 0.f) return;  // (scalar)
     const unsigned long long due = t0 + (unsigned long long)((float)k * fabsf(pace));
     if (pace > 0.f) {

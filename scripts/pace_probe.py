@@ -16,7 +16,7 @@ from cppflow_amd.problems_synthetic import PANDA_2CUBES_OBSTACLES, obstacle_arra
 from cppflow_amd.robots import get_robot  # noqa: E402
 
 DEV = torch.device("cuda:0")
-paces = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "-300", "-300/4", "0", "-270/4", "-330/4", "-300", "0", "-360/4", "-300/4"]  # "-P" = two-level schedule priority, "-P/4" four levels (CPPF_FAIR=4), "fairN" = lag-ranked priority through a table, CPPF_FAIR=N
+paces = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "fair5", "fair6", "fair7", "0", "fair5", "-300/4", "fair7", "0"]  # "-P" = two-level schedule priority, "-P/4" four levels (CPPF_FAIR=4), "fairN" = lag-ranked priority through a table, CPPF_FAIR=N
 rb = get_robot("panda")
 obs = obstacle_arrays(PANDA_2CUBES_OBSTACLES)
 rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
