@@ -76,6 +76,57 @@ __global__ __launch_bounds__(512) void k_row(uint32_t* rows, size_t row_words, i
     }
 }
 
+// FORM 4: the row form with all W workgroups on ONE accelerator die (XCD: one L2).  The grid is 8 W workgroups; the first to arrive
+// claims its die (ctrl[0]), workgroups on other dies leave at once, the ones on the claimed die take logical ids (ctrl[1]).  PLAIN:
+// the row is published with a plain store (the line stays in that die's L2: MI355X_MICROARCH.md, "stores of each flavour") and
+// polled with sc1 loads (L1 bypassed, L2-served) -- an L2 round trip instead of a trip through the fabric.
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xf;
+}
+template <bool PLAIN>
+__global__ __launch_bounds__(512) void k_row_xcd(uint32_t* rows, int k, int T, int W, uint32_t* ctrl, uint32_t* fail) {
+    __shared__ uint32_t img[2][BP][512];
+    __shared__ int s_id;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const uint32_t me = xcc_id();
+        const uint32_t old = atomicCAS(ctrl, 0xFFFFFFFFu, me);
+        const uint32_t die = old == 0xFFFFFFFFu ? me : old;
+        int id = -1;
+        if (die == me) id = (int)atomicAdd(ctrl + 1, 1u);
+        s_id = id < W ? id : -1;
+    }
+    __syncthreads();
+    const int id = s_id;
+    if (id < 0) return;
+    const int b0 = id * BP;
+    for (int t = 1; t < T; ++t) {
+        const uint32_t* prev = rows + (size_t)(t - 1) * k;
+        uint32_t mine = kSentinel - 1;
+        for (int a = tid; a < k; a += 512) {
+            const uint32_t* p = prev + a;
+            uint32_t v = ld_sc1(p);
+            for (uint32_t s = 0; v == kSentinel && s < kBudget; ++s) {
+                __builtin_amdgcn_s_sleep(1);
+                v = ld_sc1(p);
+                if ((s & 1023u) == 1023u && ld_sc1(fail)) break;
+            }
+            if (v == kSentinel) atomicAdd(fail, 1u);
+            mine = min(mine, v);
+        }
+        const uint32_t v = reduce_step(img[t & 1], mine, tid);
+        if ((tid & 63) == 0 && (tid >> 6) < BP && b0 + (tid >> 6) < k) {
+            uint32_t* dst = rows + (size_t)t * k + b0 + (tid >> 6);
+            if (PLAIN)
+                *reinterpret_cast<volatile uint32_t*>(dst) = v + 1;
+            else
+                st_sc1(dst, v + 1);
+        }
+    }
+}
+
 // FORM 2: counter.  data[t][k] written sc1, drained; lane 0 adds 1 to counter[t][blockIdx % nsh] (each on a line of its own).
 __global__ __launch_bounds__(512) void k_counter(uint32_t* data, uint32_t* counters, int nsh, int k, int T, uint32_t* fail) {
     __shared__ uint32_t img[2][BP][512];
@@ -190,6 +241,30 @@ int main() {
             CHECK(hipMemcpy(&last, rows + (size_t)(T - 1) * row_words, 4, hipMemcpyDeviceToHost));
             printf("  %s %6.2f%s", line_words == 32 ? "row" : (line_words == 1056 ? "spread4K" : "spread32K"), ms * 1e3 / (T - 1), last == (uint32_t)(T - 1) ? "" : "(!)");
             CHECK(hipFree(rows));
+        }
+        // one die
+        if (W <= 64) {
+            for (int plain = 0; plain < 2; ++plain) {
+                uint32_t *rows, *ctrl;
+                CHECK(hipMalloc(&rows, (size_t)k * T * 4));
+                CHECK(hipMalloc(&ctrl, 64));
+                std::vector<uint32_t> first(k, 0u);
+                auto reset = [&] {
+                    CHECK(hipMemset(rows, 0xFF, (size_t)k * T * 4));
+                    CHECK(hipMemcpy(rows, first.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+                    const uint32_t c0[2] = {0xFFFFFFFFu, 0u};
+                    CHECK(hipMemcpy(ctrl, c0, 8, hipMemcpyHostToDevice));
+                };
+                const float ms = time_launch(reset, [&] {
+                    if (plain) hipLaunchKernelGGL(k_row_xcd<true>, dim3(8 * W), dim3(512), 0, 0, rows, k, T, W, ctrl, fail);
+                    else hipLaunchKernelGGL(k_row_xcd<false>, dim3(8 * W), dim3(512), 0, 0, rows, k, T, W, ctrl, fail);
+                });
+                uint32_t last;
+                CHECK(hipMemcpy(&last, rows + (size_t)(T - 1) * k, 4, hipMemcpyDeviceToHost));
+                printf("  %s %6.2f%s", plain ? "one-die/plain-store" : "one-die/sc1-store", ms * 1e3 / (T - 1), last == (uint32_t)(T - 1) ? "" : "(!)");
+                CHECK(hipFree(rows));
+                CHECK(hipFree(ctrl));
+            }
         }
         // counter
         for (int nsh : {1, 8, 32}) {
