@@ -3,7 +3,7 @@
 set -o pipefail
 ROOT="$(pwd)"; OUT="$ROOT/gpurun_out/r5"; mkdir -p "$OUT"; export TMPDIR=/tmp
 D="$OUT/coupled_trace"; rm -rf "$D"
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$D" -o kt -- python3 "$ROOT/scripts/coupled_trace_probe.py" > /dev/null 2> "$D.stderr")
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$D" -o kt -- python3 "$ROOT/scripts/coupled_trace_probe.py" fetch > /dev/null 2> "$D.stderr")
 python3 - "$D" <<'PY' | tee "$OUT/coupled_trace.txt"
 import csv, glob, sys, collections
 import numpy as np
