@@ -76,6 +76,33 @@ __global__ __launch_bounds__(512) void k_row(uint32_t* rows, size_t row_words, i
     }
 }
 
+// FORM 5: the row form with the workgroup's four words published by ONE store instruction (lanes 0..3 of wavefront 0, after an LDS
+// gather and a second LDS-only barrier): one fabric write per workgroup and step instead of four partial ones into the same line
+__global__ __launch_bounds__(512) void k_row_1store(uint32_t* rows, int k, int T, uint32_t* fail) {
+    __shared__ uint32_t img[2][BP][512];
+    __shared__ uint32_t red[2][BP];
+    const int tid = threadIdx.x, b0 = blockIdx.x * BP;
+    for (int t = 1; t < T; ++t) {
+        const uint32_t* prev = rows + (size_t)(t - 1) * k;
+        uint32_t mine = kSentinel - 1;
+        for (int a = tid; a < k; a += 512) {
+            const uint32_t* p = prev + a;
+            uint32_t v = ld_sc1(p);
+            for (uint32_t s = 0; v == kSentinel && s < kBudget; ++s) {
+                __builtin_amdgcn_s_sleep(1);
+                v = ld_sc1(p);
+                if ((s & 1023u) == 1023u && ld_sc1(fail)) break;
+            }
+            if (v == kSentinel) atomicAdd(fail, 1u);
+            mine = min(mine, v);
+        }
+        const uint32_t v = reduce_step(img[t & 1], mine, tid);
+        if ((tid & 63) == 0 && (tid >> 6) < BP) red[t & 1][tid >> 6] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < BP && b0 + tid < k) st_sc1(rows + (size_t)t * k + b0 + tid, red[t & 1][tid] + 1);
+    }
+}
+
 // FORM 4: the row form with all W workgroups on ONE accelerator die (XCD: one L2).  The grid is 8 W workgroups; the first to arrive
 // claims its die (ctrl[0]), workgroups on other dies leave at once, the ones on the claimed die take logical ids (ctrl[1]).  PLAIN:
 // the row is published with a plain store (the line stays in that die's L2: MI355X_MICROARCH.md, "stores of each flavour") and
@@ -240,6 +267,21 @@ int main() {
             uint32_t last;
             CHECK(hipMemcpy(&last, rows + (size_t)(T - 1) * row_words, 4, hipMemcpyDeviceToHost));
             printf("  %s %6.2f%s", line_words == 32 ? "row" : (line_words == 1056 ? "spread4K" : "spread32K"), ms * 1e3 / (T - 1), last == (uint32_t)(T - 1) ? "" : "(!)");
+            CHECK(hipFree(rows));
+        }
+        // one store instruction per workgroup
+        {
+            uint32_t* rows;
+            CHECK(hipMalloc(&rows, (size_t)k * T * 4));
+            std::vector<uint32_t> first(k, 0u);
+            auto reset = [&] {
+                CHECK(hipMemset(rows, 0xFF, (size_t)k * T * 4));
+                CHECK(hipMemcpy(rows, first.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+            };
+            const float ms = time_launch(reset, [&] { hipLaunchKernelGGL(k_row_1store, dim3(W), dim3(512), 0, 0, rows, k, T, fail); });
+            uint32_t last;
+            CHECK(hipMemcpy(&last, rows + (size_t)(T - 1) * k, 4, hipMemcpyDeviceToHost));
+            printf("  row/1-store %6.2f%s", ms * 1e3 / (T - 1), last == (uint32_t)(T - 1) ? "" : "(!)");
             CHECK(hipFree(rows));
         }
         // one die
