@@ -534,6 +534,14 @@ def main():
                 siblings[other + "_scaling"] = r
         else:
             siblings["one_stream"] = sibling(scaling, args.inputs, 1, sib_steps)
+            # the same with the opt-in fair-share pacing a caller in a dependency chain can turn on (CPPF_TUNE_LM_PACE, off by default:
+            # it costs overlapped launches 2 - 5 %; the headline never has it)
+            robot.debug_set("lm_pace", -1)
+            try:
+                paced = sibling(scaling, args.inputs, 1, sib_steps)
+            finally:
+                robot.debug_set("lm_pace")
+            siblings["one_stream"].update(ms_per_step_paced=paced["ms_per_step"], kernel_ms_paced=paced["kernel_ms"])
             if args.inputs == "problem":
                 siblings["random_inputs"] = sibling(scaling, "random", run.n_streams, sib_steps)
             if collide and d <= 12 and W >= 2:

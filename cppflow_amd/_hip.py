@@ -66,7 +66,7 @@ SOLVER_AUTO, SOLVER_F64, SOLVER_F32 = 0, 1, 2  # AUTO = fp32 with the conditioni
 # cppflow_hip_debug.h: per-handle test / tuning switches (cppf_debug_set)
 TUNE_DEFAULT = -(2**31)
 TUNE_KEYS = {"force_generic": 0, "pcr_max_rows": 1, "quad_max_rows": 2, "dp_persistent": 3, "full_rows": 4, "pcr_lds": 5,
-             "rows_pose": 6, "quad_mfma": 7, "spread_kb": 8, "dp_spin_log2": 9, "gate_rel_ppm": 10, "cu_count": 11}  # fmt: skip
+             "rows_pose": 6, "quad_mfma": 7, "spread_kb": 8, "dp_spin_log2": 9, "gate_rel_ppm": 10, "cu_count": 11, "lm_pace": 12}  # fmt: skip
 DP_AUTO, DP_RESIDENT, DP_LAUNCHES = 0, 1, 2  # cppf_dp_search's `mode`
 
 

@@ -118,6 +118,7 @@ constexpr int kTuneDefaults[CPPF_TUNE_COUNT] = {
     /* FORCE_GENERIC */ 0, /* PCR_MAX_ROWS */ -1, /* QUAD_MAX_ROWS */ 16384, /* DP_PERSISTENT */ 1,
     /* FULL_ROWS */ 1,     /* PCR_LDS */ 2,       /* ROWS_POSE */ 0,         /* QUAD_MFMA */ 0,
     /* SPREAD_KB */ 42,    /* DP_SPIN_LOG2 */ 22,    /* GATE_REL_PPM */ (int)(kGateRel * 1e6f + 0.5f), /* CU_COUNT */ -1,
+    /* LM_PACE */ 0,
 };
 inline int tune(const cppf_robot* rb, int key) { return rb->tune[key].load(std::memory_order_relaxed); }
 
@@ -677,6 +678,12 @@ int make_lm_kernel_params(const cppf_robot* robot, const cppf_lm_params* params,
     // reduces (kernels_fused.h: an intermediate iterate needs a step that is accurate RELATIVE to its residual)
     const float rel = 1e-6f * (float)tune(robot, CPPF_TUNE_GATE_REL_PPM) / (6e-8f * a_max);  // (kGateRel unless a test changed it)
     prm.gate_rel2 = rel * rel;
+    // fair-share pacing (kernels_fused.h: lm_pace), opt-in per handle: CPPF_TUNE_LM_PACE = 0 off (default), > 0 ticks per iteration,
+    // < 0 the built-in estimate: 0.55 x the iteration's ~(200 + 56 d) VALU instructions ~ four wavefronts' share of a SIMD that issues
+    // one every ~2.6 cycles (+ the longer first / last iterations), in 10 ns ticks (Panda: 326; the measured plateau is 300 .. 360).  launch_fused_rows drops it for launches
+    // that do not fill the chip; early-out launches have no schedule.
+    const int pace = tune(robot, CPPF_TUNE_LM_PACE);
+    prm.pace_ticks = (pace == 0 || params->tol_pos_m > 0.f || params->n_steps < 3) ? 0 : (pace > 0 ? pace : (int)(0.55f * (200.f + 56.f * (float)robot->desc.ndof) + 0.5f));
     prm.n_steps = params->n_steps;
     prm.clamp = params->clamp;
     prm.n = 0;
@@ -711,6 +718,8 @@ int launch_fused_rows(const cppf_robot* robot, int coll, size_t n_rows, unsigned
     fa.ch = robot->chain;
     fa.co = robot->coll;
     fa.prm = prm;
+    // (the schedule is that of FOUR wavefronts per SIMD: a launch that leaves a quarter of the chip's slots empty is not paced)
+    if ((unsigned long long)grid * 4ull < 3ull * (unsigned long long)(robot->cu_count > 0 ? robot->cu_count : 256) * 4ull) fa.prm.pace_ticks = 0;
     fa.single = single;
     fa.table = table;
     if (use_rtc(robot)) {

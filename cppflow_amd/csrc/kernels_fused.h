@@ -112,6 +112,31 @@ __device__ __forceinline__ void block_seed_summary(const RB& rb, int W, size_t r
     }
 }
 
+// ---- fair-share pacing of a launch that has the chip to itself (opt-in: CPPF_TUNE_LM_PACE) ------------------------------------
+// Two wavefronts saturate a SIMD's VALU issue and arbitration is strictly oldest-first, so of the four wavefronts a full-size launch
+// puts on every SIMD the two oldest run at the lone-wavefront rate, the third gets the remainder, the fourth nothing, and the last one
+// ends up doing half its work alone at half the SIMD's rate (band ends 22 / 27 / 35 / 43 us, profiles/r5_pace_probe.txt).  With
+// prm.pace_ticks set, a wavefront compares its progress before every LM iteration with the schedule  start + k x pace  on the chip-wide
+// 100 MHz counter and takes one of four priorities (behind by more than half an iteration 3, behind 2, ahead 1, ahead by more than
+// half an iteration 0): the bands equalise to 37 - 38 us and a launch in a dependency chain (one stream) takes 43.2 - 44.5 instead of
+// 46.4 - 47.2 us.  It COSTS launches that overlap on several streams 2 - 5 % (equalised launches overlap less): off by default, and
+// the throughput engine (cppflow_amd.distributed.ShardedRefiner with two streams) never turns it on.  Results do not depend on it.
+#ifndef CPPF_LM_PACE
+#define CPPF_LM_PACE 1  // 0: compiled out (the A/B build of the headline)
+#endif
+__device__ __forceinline__ void lm_pace(uint32_t t0, int k, int pace) {
+    if (CPPF_LM_PACE == 0 || pace == 0) return;  // (everything here is scalar: wave-uniform integers)
+    const int lag = (int)((uint32_t)__builtin_amdgcn_s_memrealtime() - t0) - k * pace, half = pace >> 1;  // (ticks; a launch lasts far less than 2^31 of them)
+    if (lag > half)
+        __builtin_amdgcn_s_setprio(3);
+    else if (lag > 0)
+        __builtin_amdgcn_s_setprio(2);
+    else if (lag > -half)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(0);
+}
+
 // ---- one row of the fused launch, in three pieces: load, one LM iteration, finish (store, metrics, collision stage) -----------
 template <class RB>
 __device__ __forceinline__ void lm_row_load(int W, const float* __restrict__ x_in, const float* __restrict__ target,
@@ -418,6 +443,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
         unsigned long long bad_mask = __builtin_amdgcn_ballot_w64(!(fabsf(chk) < INFINITY));
         asm volatile("" : "+s"(bad_mask));
         float* const gate_lds = s_gate[__builtin_amdgcn_readfirstlane(tid >> 6)];  // wave-uniform: a scalar base
+        const uint32_t pace_t0 = (CPPF_LM_PACE != 0 && prm.pace_ticks != 0) ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;  // (lm_pace)
         int iters = 0, it = 0;
         // A plain launch: the FIRST iteration lean too, but with the polynomials behind a reduction by whole turns (the launch's own
         // input need not lie inside the joint limits, which the plain lean iteration's sine / cosine assumes, CPPF_LEAD_SINCOS = 2;
@@ -431,8 +457,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
                 (void)lm_row_iterate<RB, CPPF_FIRST_LEAN != 0, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
                 it = 1;
             }
-            for (; it < prm.n_steps - 1; ++it) (void)lm_row_iterate<RB, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
+            for (; it < prm.n_steps - 1; ++it) {
+                lm_pace(pace_t0, it, prm.pace_ticks);
+                (void)lm_row_iterate<RB, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
+            }
             iters = it;
+            lm_pace(pace_t0, it, prm.pace_ticks);  // (the last, canonical iteration; the finish stage keeps its priority)
         }
         // the general iteration: the last one of a plain launch, every one of an early-out launch
         for (; it < prm.n_steps; ++it) {
@@ -451,6 +481,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
 #pragma unroll
             for (int j = 0; j < D; ++j) q[j] = __builtin_nanf("");
         }
+        lm_pace(pace_t0, prm.n_steps, prm.pace_ticks);  // (the finish stage: one more slot of the schedule)
         lm_row_finish<RB, COLL>(rb, co, out, lds, tid_b, row_b, Rt, tt, q, rs);
     }
     if constexpr (COLL != 0) {

@@ -66,6 +66,8 @@ struct LmK {
     float gate_thr;            // conditioning gate of the damped solve: a row whose  max diag(A) * max |y|  exceeds this redoes the
                                // solve in double precision (lm_solve_gated); +inf = never (pure fp32), -inf = always (pure fp64)
     float gate_rel2;           // lean iterations only (kernels_fused.h): ... and exceeds sqrt(gate_rel2) x the scaled residual norm
+    int32_t pace_ticks;        // 0 = off; else the fair-share schedule of a launch that fills the chip by itself, in 10 ns ticks of
+                               // s_memrealtime per LM iteration (kernels_fused.h: lm_pace; CPPF_TUNE_LM_PACE, the host decides)
 };
 
 // One problem of a fused launch: what cppf_lm_pose_steps takes as (x_in, target, S * W, W, outputs).  The same layout sits in the

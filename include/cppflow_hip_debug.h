@@ -61,7 +61,13 @@ extern "C" {
  * one launch per waypoint in CPPF_DP_AUTO and CPPF_ERR_UNSUPPORTED for a forced CPPF_DP_RESIDENT) instead of the device's own: how
  * the tests reach that decision on a full MI355X.  Default -1 = the device's. */
 #define CPPF_TUNE_CU_COUNT 11
-#define CPPF_TUNE_COUNT 12
+/* Fair-share pacing of a fused launch that has the chip to itself (kernels_fused.h: lm_pace): every wavefront takes one of four
+ * priorities by its progress against a clock schedule, so that the four wavefronts of a SIMD finish together instead of in age
+ * order.  0 (default) off; > 0: the schedule in 10 ns ticks per LM iteration; < 0: the built-in estimate for this robot.  For a
+ * caller that steps ONE full-size batch in a dependency chain (one stream: -6 %); launches that overlap on several streams lose
+ * 2 - 5 % with it.  Only launches that fill at least three quarters of the chip's wavefront slots are paced.  No effect on results. */
+#define CPPF_TUNE_LM_PACE 12
+#define CPPF_TUNE_COUNT 13
 
 int cppf_debug_set(cppf_robot* robot, int key, int value);
 int cppf_debug_get(const cppf_robot* robot, int key, int* value);

@@ -71,3 +71,49 @@ def test_a_batch_outlives_its_robot_handle_without_a_fault():
     gc.collect()
     rb2 = get_robot("panda")  # the library is intact
     assert torch.equal(rb2.lm_pose_steps(x0, target, 1e-6, 3.5, 0.35, n_steps=3, shape=_hip.SHAPE_ROW)["x"], want)
+
+
+@pytest.mark.parametrize("name,S,W", [("panda", 1024, 256), ("fetch", 1024, 256), ("panda", 96, 64)])
+def test_fair_share_pacing_changes_no_result(name, S, W):
+    """CPPF_TUNE_LM_PACE (include/cppflow_hip_debug.h; csrc/kernels_fused.h: lm_pace): wavefront priorities by progress against a clock
+    schedule, for a full-size launch in a dependency chain.  It is scheduling only: x, the packed per-row outputs and the per-seed
+    summary of a full-size launch (the kind that is paced) and of a small one (never paced) are bit for bit those of the unpaced
+    launch, through the plain entry point and through the batch entry point, with the built-in estimate and with explicit schedules."""
+    import numpy as np
+
+    from cppflow_amd import _hip
+    from cppflow_amd.robots import get_robot
+
+    rb = get_robot(name)
+    obs = H.PANDA_2CUBES
+    rb.set_obstacles([c for c, _ in obs], [T for _, T in obs])
+    rb.set_joint_limit_padding(float(np.deg2rad(1.5)), 0.03)
+    x0, target = H.lm_problem(name, S, W, seed=5)
+    x0d, td = torch.tensor(x0, dtype=torch.float32, device=DEV), torch.tensor(target, dtype=torch.float32, device=DEV)
+    n = S * W
+    LM = dict(lm_lambda=1e-6, alpha_position=3.5, alpha_rotation=0.35)
+
+    def run(batch):
+        xo = torch.empty_like(x0d)
+        pk = torch.zeros(rb.PACKED_BYTES_PER_ROW * n, dtype=torch.uint8, device=DEV)
+        sm = torch.zeros((S, 8), dtype=torch.float32, device=DEV)
+        if batch:
+            plan = rb.lm_batch_plan([dict(x=x0d, target=td, x_out=xo, packed_out=pk, summary_out=sm)], n_steps=10, **LM)
+            plan.launch()
+        else:
+            rb.lm_pose_steps(x0d, td, n_steps=10, x_out=xo, packed_out=pk, summary_out=sm, shape=_hip.SHAPE_ROW, **LM)
+        torch.cuda.synchronize()
+        return xo, pk, sm
+
+    try:
+        want = run(False)
+        for pace in (-1, 150, 300, 2000):
+            rb.debug_set("lm_pace", pace)
+            for batch in (False, True):
+                got = run(batch)
+                for a, b, what in zip(got, want, ("x", "packed", "summary")):
+                    assert torch.equal(a, b), (name, S, W, pace, batch, what)
+    finally:
+        rb.debug_set("lm_pace")
+        rb.set_obstacles([], [])
+        rb.set_joint_limit_padding(None, None)
