@@ -718,8 +718,15 @@ int launch_fused_rows(const cppf_robot* robot, int coll, size_t n_rows, unsigned
     fa.ch = robot->chain;
     fa.co = robot->coll;
     fa.prm = prm;
-    // (the schedule is that of FOUR wavefronts per SIMD: a launch that leaves a quarter of the chip's slots empty is not paced)
-    if ((unsigned long long)grid * 4ull < 3ull * (unsigned long long)(robot->cu_count > 0 ? robot->cu_count : 256) * 4ull) fa.prm.pace_ticks = 0;
+    // (the schedule is that of ONE resident round of FOUR wavefronts per SIMD: a launch that leaves a quarter of the chip's slots empty, or
+    // needs a second round, or whose kernel holds fewer wavefronts per SIMD -- lm_waves(): specialised chains beyond 7 joints, generic
+    // ones beyond 6 -- is not paced: measured on Fetch, 8 joints, three per SIMD: +2 .. 3 %, profiles/r5_pace_sweep.txt)
+    {
+        const unsigned long long slots = (unsigned long long)(robot->cu_count > 0 ? robot->cu_count : 256) * 4ull;  // workgroups of 256 rows at four wavefronts per SIMD
+        const int d = robot->desc.ndof;
+        const bool four = (use_rtc(robot) || (robot->static_id >= 0 && !tune(robot, CPPF_TUNE_FORCE_GENERIC))) ? d <= 7 : d <= 6;
+        if (!four || (unsigned long long)grid * 4ull < 3ull * slots || (unsigned long long)grid > slots) fa.prm.pace_ticks = 0;
+    }
     fa.single = single;
     fa.table = table;
     if (use_rtc(robot)) {

@@ -65,7 +65,8 @@ extern "C" {
  * priorities by its progress against a clock schedule, so that the four wavefronts of a SIMD finish together instead of in age
  * order.  0 (default) off; > 0: the schedule in 10 ns ticks per LM iteration; < 0: the built-in estimate for this robot.  For a
  * caller that steps ONE full-size batch in a dependency chain (one stream: -6 %); launches that overlap on several streams lose
- * 2 - 5 % with it.  Only launches that fill at least three quarters of the chip's wavefront slots are paced.  No effect on results. */
+ * 0 - 5 % with it.  Only launches of ONE resident round of four wavefronts per SIMD are paced (at least three quarters of the chip's
+ * slots, not more than all of them; kernels that hold three per SIMD -- chains beyond 7 joints -- never).  No effect on results. */
 #define CPPF_TUNE_LM_PACE 12
 #define CPPF_TUNE_COUNT 13
 
