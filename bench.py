@@ -150,6 +150,7 @@ def parse_args(argv=None):
                     help="problem: the named reference problem's target path + per-seed IK branches (SURVEY 8d); random: the 8d fall-back")
     ap.add_argument("--no-collide", action="store_true", help="FK+Jacobian+LM only (BASELINE configs[1] style)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pace", default="auto", choices=["auto", "on", "off"], help="fair-share pacing of the launches (ShardedRefiner(pace=...)): auto = the engine's default (on with one stream)")
     ap.add_argument("--no-siblings", action="store_true", help="skip the one_stream / random_inputs / weak_scaling / latency sibling measurements")
     ap.add_argument("--transport", choices=["cabi", "c10d", "none"], default="cabi", help="N > 1: the all-gather's transport (distributed.pick_transport)")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None, help="BASELINE.json configs[1..4] geometry (default = C4)")
@@ -409,12 +410,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def refiner(x, tgt, steps_hint, batch=None, streams=None, use_transport=True):
+    def refiner(x, tgt, steps_hint, batch=None, streams=None, use_transport=True, pace=None):
         B, G, G_req, n_streams = D.launch_plan(x.shape[0], steps_hint, args.batch if batch is None else batch, args.gather_every,
                                                args.streams if streams is None else streams, shape == _hip.SHAPE_QUAD, _hip.MAX_BATCH)
         graphs = args.graphs == "on" or (args.graphs == "auto" and x.shape[0] * B <= 65536)
         r = D.ShardedRefiner(robot, x, tgt, K, transport=transport if use_transport else None, collide=collide, batch=B, bucket=G,
-                             n_streams=n_streams, shape=shape, solver=solver, graphs=graphs)
+                             n_streams=n_streams, shape=shape, solver=solver, graphs=graphs,
+                             pace={"auto": pace, "on": True, "off": False}[args.pace])
         return r, G_req
 
     def measure(run, steps, warmup, prewarm_ms, repeats):
@@ -482,10 +484,10 @@ def main():
                        "what": "ShardedRefiner.gather_and_search: all-gather of the packed per-row outputs + candidate paths, then cppf_dp_search "
                        "over every rank's candidates (once per planning call; untimed, outside `value`)"}
 
-    def sibling(mode, kind, streams, steps, batch=None, use_transport=True):
+    def sibling(mode, kind, streams, steps, batch=None, use_transport=True, pace=None):
         """a second workload / pipeline depth measured like the headline (same barriers, same max over ranks)"""
         xs, tg, _ = inputs_for(mode, kind)
-        r2, _ = refiner(xs, tg, steps, batch=batch, streams=streams, use_transport=use_transport)
+        r2, _ = refiner(xs, tg, steps, batch=batch, streams=streams, use_transport=use_transport, pace=pace)
         el = float(np.median(measure(r2, steps, min(args.warmup, 100), min(args.prewarm_ms, 30.0), 3)[0]))
         km = kernel_ms(r2, 200, prewarm=200)["median"]
         res = {"value": float(r2.n) * run.world * K * steps / el, "ms_per_step": 1e3 * el / steps, "kernel_ms": km, "streams": r2.n_streams,
@@ -533,15 +535,11 @@ def main():
                 r.update(scaling=other, seeds_per_gpu=S_cfg if other == "weak" else S_cfg // world)
                 siblings[other + "_scaling"] = r
         else:
+            # one stream = a dependency chain: the engine paces its launches by default there (ShardedRefiner(pace=None); the headline's
+            # overlapping launches are never paced); the unpaced figure rides along
             siblings["one_stream"] = sibling(scaling, args.inputs, 1, sib_steps)
-            # the same with the opt-in fair-share pacing a caller in a dependency chain can turn on (CPPF_TUNE_LM_PACE, off by default:
-            # it costs overlapped launches 2 - 5 %; the headline never has it)
-            robot.debug_set("lm_pace", -1)
-            try:
-                paced = sibling(scaling, args.inputs, 1, sib_steps)
-            finally:
-                robot.debug_set("lm_pace")
-            siblings["one_stream"].update(ms_per_step_paced=paced["ms_per_step"], kernel_ms_paced=paced["kernel_ms"])
+            unpaced = sibling(scaling, args.inputs, 1, sib_steps, pace=False)
+            siblings["one_stream"].update(paced=True, ms_per_step_unpaced=unpaced["ms_per_step"], kernel_ms_unpaced=unpaced["kernel_ms"])
             if args.inputs == "problem":
                 siblings["random_inputs"] = sibling(scaling, "random", run.n_streams, sib_steps)
             if collide and d <= 12 and W >= 2:

@@ -348,6 +348,12 @@ def launch_plan(rows_step: int, steps_hint: int, batch: int = 0, gather_every: i
     return B, G, G_req, n_streams
 
 
+def _hip_keys():
+    from cppflow_amd import _hip
+
+    return _hip.TUNE_KEYS
+
+
 class ShardedRefiner:
     """One rank's engine for a stream of refinement steps over its shard of the seeds: S_local seeds x W waypoints per step, K
     fused LM iterations + pose metrics + collision masks + search cost + per-seed summary per row (cppf_lm_batch_launch).
@@ -362,11 +368,14 @@ class ShardedRefiner:
 
     `transport`: an object of this module (`pick_transport`), or None for a single rank that exchanges nothing.  `graphs=True`
     replays each bucket's launches as one captured hipGraph; the decision is made COLLECTIVELY when a group is given (a capture that
-    fails on one rank turns graphs off on all: the ranks must issue identical sequences of collectives)."""
+    fails on one rank turns graphs off on all: the ranks must issue identical sequences of collectives).
+    `pace`: fair-share pacing of the fused launches (include/cppflow_hip_debug.h: CPPF_TUNE_LM_PACE; csrc/kernels_fused.h: lm_pace) --
+    for launches that run ALONE on the chip, one after the other: None (default) = on exactly when there is one stream (a dependency
+    chain: -3 .. -6 % per step), off with several (overlapping launches lose up to 5 % with it).  No effect on results."""
 
     def __init__(self, robot, x0: torch.Tensor, target: torch.Tensor, n_lm_steps: int, *, transport=None, group=None,
                  collide: bool = True, batch: int = 1, bucket: int = 1, n_streams: int = 2, shape: int = 0, solver: int = 0,
-                 graphs: bool = False, constraints=None, lm=LM_POSE):
+                 graphs: bool = False, constraints=None, lm=LM_POSE, pace: Optional[bool] = None):
         from cppflow_amd import _hip
         from cppflow_amd.data_types import DEFAULT_CONSTRAINTS
 
@@ -378,6 +387,7 @@ class ShardedRefiner:
         self.transport = transport if collide else None
         self.world = self.transport.world if self.transport is not None else 1
         self.n_streams = max(1, int(n_streams))
+        self.pace = (self.n_streams == 1) if pace is None else bool(pace)
         self.shape, self.solver = shape, solver
         self.B = max(1, min(int(batch), _hip.MAX_BATCH))
         self.use_batch_api = shape != _hip.SHAPE_QUAD  # an explicit quad shape keeps the plain per-step launches (B = 1)
@@ -424,6 +434,17 @@ class ShardedRefiner:
         """launches[g][c - 1]: the launch of the first c steps of group g (c = B: the group; c < B: what is left at the end of a run)"""
         rb, B, K = self.robot, self.B, self.K
         self.launches = []
+        # (a launch plan takes the handle's scheduling switch as it is when the plan is made: set for the making only, then restored)
+        pace_was = rb._tuning.get(_hip_keys()["lm_pace"]) if hasattr(rb, "_tuning") else None
+        if self.pace and hasattr(rb, "debug_set"):
+            rb.debug_set("lm_pace", -1)
+        try:
+            self._make_launch_plans(rb, B, K)
+        finally:
+            if self.pace and hasattr(rb, "debug_set"):
+                rb.debug_set("lm_pace", pace_was)
+
+    def _make_launch_plans(self, rb, B, K):
         for g in range(self.NBUF // B):
             if self.use_batch_api:
                 self.launches.append([rb.lm_batch_plan([self._item(g * B + j) for j in range(c)], n_steps=K, solver=self.solver, **self.lm)

@@ -26,7 +26,7 @@ fi
 if want full quick pmc; then
     cd /tmp
     echo "== rocprofv3 kernel trace of the headline command (one launch in flight)"
-    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --no-siblings --streams 1 > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 "$ROOT/bench.py" --steps 200 --warmup 10 --no-cpu-baseline --no-siblings --streams 1 --pace off > "$OUT/kt_stdout.txt" 2> "$OUT/kt_stderr.txt"
     echo "== rocprofv3 pmc FETCH_SIZE / WRITE_SIZE"
     timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_fetch_stderr.txt"
     timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --prewarm-ms 0 --no-cpu-baseline --no-siblings --streams 1 > /dev/null 2> "$OUT/pmc_write_stderr.txt"

@@ -65,6 +65,40 @@ def test_refiner_ring_equals_separate_launches_and_selects_like_one_process(grap
     rb.set_joint_limit_padding(None, None)
 
 
+def test_one_stream_refiner_paces_full_size_launches_and_changes_nothing():
+    """`ShardedRefiner(pace=None)`: with ONE stream (launches in a dependency chain) the engine makes its launch plans with the
+    fair-share pacing on (CPPF_TUNE_LM_PACE; csrc/kernels_fused.h: lm_pace), with several it does not; the robot's own switch is as
+    it was afterwards, and a paced full-size engine writes bit for bit what an unpaced one writes."""
+    import ctypes
+
+    from cppflow_amd import _hip
+    from cppflow_amd import distributed as D
+
+    rb = _panda_with_cubes()
+    S, W, K = 1024, 256, 10
+    x0, target = H.lm_problem("panda", S, W, seed=9)
+    x0, target = torch.tensor(x0, dtype=torch.float32, device=DEV), torch.tensor(target, dtype=torch.float32, device=DEV)
+
+    def switch():
+        got = ctypes.c_int(-7)
+        _hip.check(_hip.lib().cppf_debug_get(rb._handle(torch.device(DEV)), _hip.TUNE_KEYS["lm_pace"], ctypes.byref(got)))
+        return got.value
+
+    outs = {}
+    for label, kw in (("one stream", dict(n_streams=1)), ("one stream, unpaced", dict(n_streams=1, pace=False)), ("two streams", dict(n_streams=2))):
+        r = D.ShardedRefiner(rb, x0, target, K, **kw)
+        assert r.pace == (label == "one stream") and switch() == 0, label
+        r.run_region(3)
+        r.synchronize()
+        outs[label] = (r.x_outs[0].clone(), r.packeds[0].clone(), r.summ_all[0].clone())
+        r.close()
+    for label in ("one stream, unpaced", "two streams"):
+        for a, b in zip(outs["one stream"], outs[label]):
+            assert torch.equal(a, b), label
+    rb.set_obstacles([], [])
+    rb.set_joint_limit_padding(None, None)
+
+
 def test_refiner_without_a_transport_alternates_streams_and_matches():
     from cppflow_amd import distributed as D
 
