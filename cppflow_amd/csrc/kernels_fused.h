@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(lm_waves
                 (void)lm_row_iterate<RB, true>(rb, prm, out, row, false, Rt, tt, gate_lds, q);
             }
             iters = it;
-            lm_pace(pace_t0, it, prm.pace_ticks);  // (the last, canonical iteration; the finish stage keeps its priority)
+            lm_pace(pace_t0, it, prm.pace_ticks);  // (the last, canonical iteration)
         }
         // the general iteration: the last one of a plain launch, every one of an early-out launch
         for (; it < prm.n_steps; ++it) {
